@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the x-vector / c-vector extraction hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per
+GPU with torch.distributed.run.  One "step" = one pass of the hot path (prep -> TDNN GEMMs -> pooling -> embedding
+affine) over one batch of synthetic feature chunks per GPU; inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+
+  metric   utterance-embeddings/sec on 400-frame chunks (BASELINE.json), whole job over all N GPUs
+  workload BASELINE.json configs[1]: v2 x-vector TDNN, batch = 256 chunks x 400 frames per GPU ("weak" scaling:
+           per-GPU work is fixed, utterances are sharded, the only collective is ONE RCCL broadcast of the packed
+           weights at start-up - SURVEY.md §8(e))
+  dtype    bf16x3 by default = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate): the mode that meets the
+           1e-4 parity bar.  --precision bf16|fp16 measure the single-pass modes (their error is reported).
+  roofline dominant kernel = tdnn_gemm_kernel<.., act>; achieved = algorithmic FLOPs per launch / average launch
+           duration measured with HIP events on the launch stream inside the timed region; peak = 2.5 PFLOP/s
+           dense bf16 MFMA (MI355X_MICROARCH.md).  Note the split mode executes 3 MFMAs per algorithmic MAC.
+  cpu_baseline  the numpy/OpenBLAS fp32 oracle ("port": this repo's restatement of Kaldi's semantics, NOT Kaldi,
+           which is neither vendored by the reference nor installed) timed on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+def cpu_baseline(net, cfg_line, frames, seconds):
+    """Oracle (numpy fp32 sgemm formulation = how Kaldi's CPU path spends its time) on a bounded sample."""
+    import numpy as np
+    import helpers as H
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(cfg_line)
+    ev = H.xo.GraphEvaluator(n2, np.float32)
+    x = [H.features(i, frames) for i in range(4)]
+    ev.compute(x[0])  # warm
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        ev.compute(x[n % 4])
+        n += 1
+    dt = time.time() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [threads])
+    except Exception:
+        pass
+    return {"value": n / dt, "unit": "utt/s", "cores": int(threads), "kind": "port",
+            "sample": "%d x %d-frame utterances in %.1f s, numpy/OpenBLAS fp32 oracle, one utterance at a time" % (n, frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16"])
+    ap.add_argument("--topology", default="v2_xvector")
+    ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-modes", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import helpers as H
+    P = importlib.import_module("speaker-embedding-with-phonetic-information_amd")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a visible MI355X; there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- model: read/packed ONCE on rank 0, broadcast over RCCL -------------------------------------------
+    prec = P.PRECISIONS[args.precision]
+    net = cfg_line = None
+    if rank == 0:
+        net, cfg_line = H.synth_model(args.topology)
+        model = P.Model(raw=net.to_bytes(True), nnet_config=cfg_line)
+        blob = model.pack(prec)
+        macs = model.macs(args.frames)
+        meta = torch.tensor([len(blob), int(macs)], dtype=torch.int64, device=dev)
+    else:
+        meta = torch.zeros(2, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(meta, 0)
+    nbytes, macs = int(meta[0].item()), float(meta[1].item())
+    if rank == 0:
+        wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    else:
+        wt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.broadcast(wt, 0)       # the ONE collective of this path (weights over xGMI)
+    ctx = P.Context(blob=wt.cpu().numpy().tobytes(), device=local_rank)
+    del wt
+
+    # ---- synthetic inputs resident in HBM (N(0,1)*sigma_d, sigma_d = 8*0.9^d) ---------------
+    B, T, D = args.batch, args.frames, ctx.info.input_dim
+    g = torch.Generator(device=dev).manual_seed(20180101 + rank)
+    sigma = (8.0 * 0.9 ** torch.arange(D, dtype=torch.float32)).to(dev)
+    feats = torch.randn(B * T, D, generator=g, device=dev, dtype=torch.float32) * sigma
+    out = torch.empty(B, ctx.info.output_dim, dtype=torch.float32, device=dev)
+    offs = np.arange(B + 1, dtype=np.int32) * T
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.forward_batch_device(feats.data_ptr(), offs, out.data_ptr(), out.shape[1], stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)        # HIP events on the launch stream, inside the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    prof = ctx.profile_report()
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        # ---- roofline of the dominant kernel (activation-producing spliced GEMM) -----------------------------
+        act = [(l, c, ms) for (l, c, ms) in prof if l.startswith("tdnn_gemm<act>")]
+        allg = [(l, c, ms) for (l, c, ms) in prof if l.startswith("tdnn_gemm<")]
+        info_layers = None
+        per_layer = {}
+        try:
+            desc = model.describe()
+            for line in desc.splitlines()[1:]:
+                parts = line.split()
+                name, dims = parts[1], parts[2]
+                k, n = dims.split("->")
+                per_layer[name] = (int(k), int(n))
+        except Exception:
+            pass
+        # algorithmic MACs per layer per chunk: unpadded dims x frames nnet3 would compute; computed by the library
+        # for the whole net (macs); per layer we apportion by K*N*(needed frames) using the same rule
+        def layer_macs(name):
+            # needed frames: library reports total only; recompute from the describe() table context columns
+            return None
+        act_ms = sum(ms for _, _, ms in act)
+        act_launches = sum(c for _, c, _ in act)
+        gemm_ms = sum(ms for _, _, ms in allg)
+        total_prof_ms = sum(ms for _, _, ms in prof)
+        # algorithmic FLOPs attributed to the <act> launches = total minus the pooled (stats) layer and the
+        # segment-level layers, which run in other instantiations
+        stats_names = [l.split(":", 1)[1] for (l, c, ms) in prof if l.startswith("tdnn_gemm<stats>")]
+        f32_names = [l.split(":", 1)[1] for (l, c, ms) in prof if l.startswith("tdnn_gemm<f32>")]
+        pool_frames = T - ctx.info.left_context - ctx.info.right_context
+        other_macs = 0.0
+        for nme in stats_names:
+            k, n = per_layer.get(nme, (0, 0))
+            other_macs += float(k) * n * pool_frames
+        for nme in f32_names:
+            k, n = per_layer.get(nme, (0, 0))
+            other_macs += float(k) * n
+        act_flops_step = 2.0 * (macs - other_macs) * B
+        n_act_per_step = max(1, len(act))
+        flops_per_launch = act_flops_step / n_act_per_step
+        avg_launch_ms = act_ms / max(1, act_launches)
+        achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
+                    "kernel": "tdnn_gemm_kernel<%s,act>" % args.precision, "launches_per_step": n_act_per_step,
+                    "avg_launch_ms": avg_launch_ms, "alg_flops_per_launch": flops_per_launch,
+                    "mfma_per_alg_mac": 3 if args.precision == "bf16x3" else 1,
+                    "whole_step_alg_tflops": 2.0 * macs * B * args.steps / dt / 1e12 * 1.0,
+                    "gemm_ms_per_step": gemm_ms / args.steps, "all_kernels_ms_per_step": total_prof_ms / args.steps}
+        # ---- parity spot check against the oracle on the same inputs (not timed) ------------------------------
+        n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+        n2.apply_nnet_config(cfg_line)
+        ev = H.xo.GraphEvaluator(n2, np.float32)
+        f_host = feats[:2 * T].cpu().numpy()
+        ref = np.stack([ev.compute(f_host[i * T:(i + 1) * T])[0] for i in range(2)])
+        parity = H.rel_err(out[:2].cpu().numpy(), ref)
+        res = {
+            "metric": "utterance-embeddings/sec (400-frame chunks)", "value": value, "unit": "utt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "%s TDNN, %d chunks x %d frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
+                                   % (args.topology, B, T), "topology": args.topology, "batch_chunks_per_gpu": B,
+                       "frames_per_chunk": T, "precision": args.precision,
+                       "alg_gflop_per_utt": 2.0 * macs / 1e9},
+            "roofline": roofline,
+            "parity_rel_err_vs_oracle_fp32": parity,
+            "kernels_ms_per_step": {l: ms / max(1, c) for (l, c, ms) in prof},
+        }
+        if world == 1 and not args.no_extra_modes and args.precision == "bf16x3":
+            # single-pass modes, reported next to the parity mode with their measured error (never `value`)
+            extra = {}
+            for pname in ("bf16", "fp16"):
+                c2 = P.Context(model, device=local_rank, precision=P.PRECISIONS[pname])
+                o2 = torch.empty_like(out)
+                for _ in range(3):
+                    c2.forward_batch_device(feats.data_ptr(), offs, o2.data_ptr(), o2.shape[1], stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    c2.forward_batch_device(feats.data_ptr(), offs, o2.data_ptr(), o2.shape[1], stream)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t1
+                extra[pname] = {"value": B * args.steps / d2, "unit": "utt/s",
+                                "alg_tflops": 2.0 * macs * B * args.steps / d2 / 1e12,
+                                "rel_err_vs_oracle_fp32": H.rel_err(o2[:2].cpu().numpy(), ref)}
+                del c2
+            res["single_pass_modes"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(net, cfg_line, T, args.cpu_seconds)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/* xvec_hip.h - C ABI of the MI355X-native x-vector / c-vector embedding extractor.
+ *
+ * The reference (mycrazycracy/speaker-embedding-with-phonetic-information) has no plugin, operator or
+ * FFI interface for this path: its boundary is the command line of Kaldi's `nnet3-xvector-compute`
+ * (call sites egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:86-87,92-93) plus Kaldi's file
+ * formats.  The drop-in for that boundary is the `nnet3-xvector-compute` executable built from
+ * csrc/nnet3_xvector_compute_main.cc; this header is the C ABI *underneath* it, i.e.
+ * what a maintainer who wants to call the extractor from a host language binds.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types; the caller owns every host buffer;
+ * the library owns device memory; no exception crosses the boundary (every entry returns xv_status and
+ * the message is available from xv_last_error(), thread-local); an xv_ctx may be used by one thread at
+ * a time, different xv_ctx objects are independent.  There is NO CPU compute path behind this ABI:
+ * creating a context without a gfx950 device fails with XV_ERR_DEVICE.
+ */
+#ifndef XVEC_HIP_H_
+#define XVEC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  XV_OK = 0,
+  XV_ERR_IO = 1,       /* unreadable rxfilename / malformed Kaldi object */
+  XV_ERR_MODEL = 2,    /* graph outside the supported TDNN grammar */
+  XV_ERR_DEVICE = 3,   /* no gfx950 device, HIP failure */
+  XV_ERR_ARG = 4,      /* invalid argument (e.g. a chunk shorter than the network context) */
+  XV_ERR_INTERNAL = 5
+} xv_status;
+
+typedef enum {
+  XV_PREC_BF16X3 = 0,  /* split-bf16 MFMA (3 products, fp32 accumulate): the <=1e-4 parity mode, default */
+  XV_PREC_BF16 = 1,    /* single-pass bf16 MFMA */
+  XV_PREC_FP16 = 2     /* single-pass fp16 MFMA */
+} xv_precision;
+
+typedef struct xv_model xv_model; /* host side: parsed nnet3 model lowered to a TDNN program */
+typedef struct xv_ctx xv_ctx;     /* device side: weights resident on one GPU + workspaces + stream */
+
+typedef struct {
+  int32_t input_dim;         /* feature dimension (23 in egs/sre, conf/mfcc.conf:5) */
+  int32_t output_dim;        /* embedding dimension (512) */
+  int32_t left_context;      /* frames not computable at the left edge of a chunk (7 / 13) */
+  int32_t right_context;     /* ... at the right edge (7) */
+  int32_t min_frames;        /* smallest chunk with >= 1 pooled frame (15 / 21) */
+  int32_t num_layers;        /* affine layers in the dependency cone of the output */
+  int32_t output_is_segment; /* 1: one vector per chunk (x-vector); 0: one row per frame */
+  int32_t reserved;
+} xv_model_info_t;
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char* xv_last_error(void);
+const char* xv_version(void);
+
+/* ---- model (replaces ReadKaldiObject + SetBatchnormTestMode + CollapseModel + Compile) -------------
+ * raw/n: the bytes of an nnet3 "raw" model, binary or text (what `$srcdir/final.raw` holds,
+ *        extract_xvectors_new.sh:53).
+ * nnet_config: optional text applied like `nnet3-copy --nnet-config=<file>` (extract_xvectors_new.sh:58-59
+ *        writes "output-node name=output input=tdnn6.affine" into extract.config); may be NULL.
+ * output_node: name of the output-node to compute; NULL means "output". */
+xv_status xv_model_load(const void* raw, size_t n, const char* nnet_config, const char* output_node,
+                        xv_model** out);
+/* Same, reading a Kaldi rxfilename: "file", "file:offset", "-", or "command |" (the form every recipe
+ * call uses: "nnet3-copy --nnet-config=... final.raw - |"). */
+xv_status xv_model_load_rxfilename(const char* rxfilename, const char* nnet_config, const char* output_node,
+                                   xv_model** out);
+void xv_model_free(xv_model* m);
+xv_status xv_model_info(const xv_model* m, xv_model_info_t* info);
+/* Algorithmic multiply-accumulates of one chunk of `frames` frames (unpadded dims, only the frames
+ * nnet3 would compute). */
+double xv_model_macs(const xv_model* m, int32_t frames);
+/* Human-readable layer table; returns the number of bytes needed (including the NUL). */
+size_t xv_model_describe(const xv_model* m, char* buf, size_t n);
+/* Packed, padded, precision-split weight image: what one rank broadcasts to the others over RCCL
+ * (SURVEY.md §8(e)).  Call with blob == NULL to get the size. */
+xv_status xv_model_pack(const xv_model* m, int precision, void* blob, size_t* nbytes);
+
+/* ---- device context ---------------------------------------------------------------------------- */
+xv_status xv_ctx_create(const xv_model* m, int device, int precision, xv_ctx** out);
+xv_status xv_ctx_create_from_blob(const void* blob, size_t nbytes, int device, xv_ctx** out);
+void xv_ctx_free(xv_ctx* c);
+xv_status xv_ctx_info(const xv_ctx* c, xv_model_info_t* info, int32_t* precision, int32_t* device);
+
+/* One forward pass over a batch of B chunks (replaces RunNnetComputation for B chunks at once).
+ * feats: packed rows [row_offsets[B]][input_dim] fp32; chunk b = rows row_offsets[b] .. row_offsets[b+1]-1;
+ * out: [B][output_dim] fp32.  Every chunk must have >= min_frames rows (XV_ERR_ARG otherwise; nnet3
+ * would refuse to compile the same request).  Host-buffer flavour: blocking. */
+xv_status xv_forward_batch(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float* out);
+/* Device-buffer flavour: feats/out are device pointers on the context's GPU, row_offsets is a HOST array;
+ * asynchronous on hip_stream (a hipStream_t, NULL = the context's own stream). out rows are out_ld apart. */
+xv_status xv_forward_batch_device(xv_ctx* c, const float* feats_dev, const int32_t* row_offsets, int32_t B,
+                                  float* out_dev, int32_t out_ld, void* hip_stream);
+xv_status xv_ctx_synchronize(xv_ctx* c);
+/* Per-kernel timing with HIP events recorded on the stream the kernels are launched on (used by bench.py for
+ * the roofline figure).  xv_ctx_profile_report synchronises, writes "label<TAB>launches<TAB>total_ms" lines for
+ * everything recorded since the previous report into buf (NUL terminated), resets the record, and returns
+ * the number of bytes needed; call it often enough - every recorded forward keeps a handful of events alive. */
+xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable);
+size_t xv_ctx_profile_report(xv_ctx* c, char* buf, size_t n);
+
+/* The per-utterance loop of nnet3-xvector-compute (chunking + length-weighted average):
+ * utterance u = rows row_offsets[u] .. row_offsets[u+1]-1 of feats (host).  chunk_size <= 0 means the whole
+ * utterance; pad_input != 0 replicates edge frames of chunks shorter than min_chunk_size, pad_input == 0
+ * skips them.  ok[u] = 1 if an embedding was written to out[u][:], 0 if the utterance counts as failed
+ * (zero frames, too short).  Blocking. */
+xv_status xv_extract_utterances(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t n_utts,
+                                int32_t chunk_size, int32_t min_chunk_size, int32_t pad_input, float* out,
+                                int32_t* ok);
+
+/* ---- multi-GPU: weights read once, broadcast over RCCL/xGMI --------------------------
+ * Single-process form: creates one context per device in devices[0..n) from the model, reading/packing once
+ * on the host, uploading to devices[0] and broadcasting device-to-device with one ncclBroadcast. */
+xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, int precision, xv_ctx** out);
+
+/* ---- kernel-level entry (unit tests of the HIP GEMM against a plain fp32 reference) ------------------- */
+typedef struct {
+  const void* hi;   /* device plane (bf16 / fp16) at logical row 0 */
+  const void* lo;   /* residual plane (XV_PREC_BF16X3 only) */
+  int32_t ld;       /* leading dimension in elements */
+  int32_t row_shift;
+  int32_t k_len;    /* multiple of 32 */
+} xv_seg_desc;
+typedef struct {
+  int32_t precision, epilogue; /* epilogue: 0 planes out, 1 fp32 out, 2 per-16-row (sum, sumsq) partials */
+  int32_t nseg;
+  xv_seg_desc seg[8];
+  const void* w_hi; const void* w_lo; int32_t ldw;
+  int32_t rows;     /* multiple of 128 */
+  int32_t n_pad;    /* multiple of 128 */
+  const float* bias; const float* scale; const float* offset;
+  int32_t relu, bn;
+  void* out_hi; void* out_lo; int32_t ldo;
+  float* out_f32; int32_t ldf; int32_t m_valid;
+  float* partial; int32_t ldp; const int8_t* grp_range;
+  void* hip_stream;
+} xv_gemm_desc;
+xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVEC_HIP_H_ */

@@ -1,0 +1,236 @@
+"""Host-side Python mirror of the C ABI in include/xvec_hip.h (ctypes; no torch types cross it).
+
+The reference's interface for this path is a command line (Kaldi's `nnet3-xvector-compute`, call sites
+egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:86-93); the product is the C++/HIP library
+`libxvec_hip.so` plus the drop-in executables under bin/.  This module only exists so that tests/ and
+bench.py can drive the same C ABI from Python; it contains no compute and no fallback: if the shared
+library is missing or no gfx950 device is present, calls fail loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libxvec_hip.so")
+BIN_DIR = os.path.join(_HERE, "bin")
+
+XV_OK = 0
+PREC_BF16X3, PREC_BF16, PREC_FP16 = 0, 1, 2
+PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16}
+EPI_ACT, EPI_F32, EPI_STATS = 0, 1, 2
+
+
+class XvError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("xvec_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class ModelInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("input_dim", "output_dim", "left_context", "right_context",
+                                              "min_frames", "num_layers", "output_is_segment", "reserved")]
+
+
+class SegDesc(ctypes.Structure):
+    _fields_ = [("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p), ("ld", ctypes.c_int32),
+                ("row_shift", ctypes.c_int32), ("k_len", ctypes.c_int32)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("precision", ctypes.c_int32), ("epilogue", ctypes.c_int32), ("nseg", ctypes.c_int32),
+                ("seg", SegDesc * 8),
+                ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p), ("ldw", ctypes.c_int32),
+                ("rows", ctypes.c_int32), ("n_pad", ctypes.c_int32),
+                ("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("offset", ctypes.c_void_p),
+                ("relu", ctypes.c_int32), ("bn", ctypes.c_int32),
+                ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("ldo", ctypes.c_int32),
+                ("out_f32", ctypes.c_void_p), ("ldf", ctypes.c_int32), ("m_valid", ctypes.c_int32),
+                ("partial", ctypes.c_void_p), ("ldp", ctypes.c_int32), ("grp_range", ctypes.c_void_p),
+                ("hip_stream", ctypes.c_void_p)]
+
+
+# every symbol include/xvec_hip.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = [
+    "xv_last_error", "xv_version", "xv_model_load", "xv_model_load_rxfilename", "xv_model_free", "xv_model_info",
+    "xv_model_macs", "xv_model_describe", "xv_model_pack", "xv_ctx_create", "xv_ctx_create_from_blob", "xv_ctx_free",
+    "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
+    "xv_ctx_profile_report", "xv_extract_utterances",
+    "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
+]
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP/C++ source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libxvec_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no Python/CPU fallback for the HIP path)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.xv_last_error.restype = ctypes.c_char_p
+    L.xv_version.restype = ctypes.c_char_p
+    L.xv_model_macs.restype = ctypes.c_double
+    L.xv_model_macs.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    L.xv_model_describe.restype = ctypes.c_size_t
+    L.xv_model_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.xv_model_load.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p,
+                                ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_model_load_rxfilename.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                           ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_model_free.argtypes = [ctypes.c_void_p]
+    L.xv_model_free.restype = None
+    L.xv_model_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo)]
+    L.xv_model_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    L.xv_ctx_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_ctx_create_from_blob.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_ctx_free.argtypes = [ctypes.c_void_p]
+    L.xv_ctx_free.restype = None
+    L.xv_ctx_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo), ctypes.POINTER(ctypes.c_int32),
+                              ctypes.POINTER(ctypes.c_int32)]
+    L.xv_forward_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    L.xv_forward_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    L.xv_ctx_synchronize.argtypes = [ctypes.c_void_p]
+    L.xv_ctx_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    L.xv_ctx_profile_report.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.xv_ctx_profile_report.restype = ctypes.c_size_t
+    L.xv_extract_utterances.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.xv_ctx_create_broadcast.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_kernel_tdnn_gemm.argtypes = [ctypes.POINTER(GemmDesc)]
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != XV_OK:
+        raise XvError(status, lib().xv_last_error().decode(errors="replace"))
+
+
+class Model:
+    """Parsed nnet3 model lowered to a TDNN program (host only; works without a GPU)."""
+
+    def __init__(self, raw=None, rxfilename=None, nnet_config=None, output_node=None):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        cfg = nnet_config.encode() if nnet_config else None
+        node = output_node.encode() if output_node else None
+        if raw is not None:
+            buf = ctypes.create_string_buffer(bytes(raw), len(raw))
+            _check(L.xv_model_load(buf, len(raw), cfg, node, ctypes.byref(self._h)))
+        else:
+            _check(L.xv_model_load_rxfilename(rxfilename.encode(), cfg, node, ctypes.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().xv_model_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    @property
+    def info(self):
+        mi = ModelInfo()
+        _check(lib().xv_model_info(self._h, ctypes.byref(mi)))
+        return mi
+
+    def macs(self, frames):
+        return lib().xv_model_macs(self._h, int(frames))
+
+    def describe(self):
+        n = lib().xv_model_describe(self._h, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        lib().xv_model_describe(self._h, buf, n)
+        return buf.value.decode()
+
+    def pack(self, precision=PREC_BF16X3):
+        n = ctypes.c_size_t(0)
+        _check(lib().xv_model_pack(self._h, precision, None, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        _check(lib().xv_model_pack(self._h, precision, buf, ctypes.byref(n)))
+        return buf.raw[:n.value]
+
+
+class Context:
+    """Weights resident on one MI355X + workspaces.  Raises XvError(XV_ERR_DEVICE) without a gfx950 GPU."""
+
+    def __init__(self, model=None, blob=None, device=0, precision=PREC_BF16X3):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        if blob is not None:
+            self._blob = ctypes.create_string_buffer(bytes(blob), len(blob))
+            _check(L.xv_ctx_create_from_blob(self._blob, len(blob), device, ctypes.byref(self._h)))
+        else:
+            _check(L.xv_ctx_create(model._h, device, precision, ctypes.byref(self._h)))
+        mi = ModelInfo()
+        p, d = ctypes.c_int32(), ctypes.c_int32()
+        _check(L.xv_ctx_info(self._h, ctypes.byref(mi), ctypes.byref(p), ctypes.byref(d)))
+        self.info, self.precision, self.device = mi, p.value, d.value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().xv_ctx_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def forward_batch(self, feats, row_offsets):
+        """feats: float32 numpy [rows, input_dim]; row_offsets: int32 [B+1] -> numpy [B, output_dim]."""
+        import numpy as np
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        B = len(offs) - 1
+        out = np.empty((B, self.info.output_dim), dtype=np.float32)
+        _check(lib().xv_forward_batch(self._h, feats.ctypes.data, offs.ctypes.data, B, out.ctypes.data))
+        return out
+
+    def forward_batch_device(self, feats_ptr, row_offsets, out_ptr, out_ld, stream=None):
+        """Device pointers (ints); asynchronous on `stream` (a hipStream_t as int, None = context stream)."""
+        import numpy as np
+        offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        _check(lib().xv_forward_batch_device(self._h, feats_ptr, offs.ctypes.data, len(offs) - 1, out_ptr, out_ld,
+                                             stream))
+
+    def synchronize(self):
+        _check(lib().xv_ctx_synchronize(self._h))
+
+    def set_profiling(self, on):
+        _check(lib().xv_ctx_set_profiling(self._h, 1 if on else 0))
+
+    def profile_report(self):
+        """[(label, launches, total_ms)] of everything recorded since the last call."""
+        n = lib().xv_ctx_profile_report(self._h, None, 0)
+        buf = ctypes.create_string_buffer(max(n, 1) + 65536)
+        lib().xv_ctx_profile_report(self._h, buf, len(buf))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            label, calls, ms = line.split("\t")
+            rows.append((label, int(calls), float(ms)))
+        return rows
+
+    def extract_utterances(self, feats, row_offsets, chunk_size=-1, min_chunk_size=100, pad_input=True):
+        import numpy as np
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        n = len(offs) - 1
+        out = np.zeros((n, self.info.output_dim), dtype=np.float32)
+        ok = np.zeros(n, dtype=np.int32)
+        _check(lib().xv_extract_utterances(self._h, feats.ctypes.data, offs.ctypes.data, n, chunk_size, min_chunk_size,
+                                           1 if pad_input else 0, out.ctypes.data, ok.ctypes.data))
+        return out, ok.astype(bool)
+
+
+def kernel_tdnn_gemm(desc):
+    _check(lib().xv_kernel_tdnn_gemm(ctypes.byref(desc)))

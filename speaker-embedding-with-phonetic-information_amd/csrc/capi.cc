@@ -1,0 +1,361 @@
+// extern "C" boundary of libxvec_hip.so - see include/xvec_hip.h.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/xvec_hip.h"
+#include "engine.h"
+#include "extractor.h"
+#include "kernels.h"
+#include "nnet3_raw.h"
+#include "program.h"
+
+struct xv_model {
+  xv::TdnnProgram prog;
+};
+
+struct xv_ctx {
+  std::unique_ptr<xv::Engine> eng;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+xv_status Fail(xv_status s, const std::string& m) {
+  g_err = m;
+  return s;
+}
+
+template <class F>
+xv_status Guard(F&& f) {
+  try {
+    g_err.clear();
+    return f();
+  } catch (const xv::KioError& e) {
+    return Fail(XV_ERR_IO, e.what());
+  } catch (const xv::EngineError& e) {
+    return Fail(XV_ERR_DEVICE, e.what());
+  } catch (const std::bad_alloc&) {
+    return Fail(XV_ERR_INTERNAL, "out of host memory");
+  } catch (const std::exception& e) {
+    return Fail(XV_ERR_INTERNAL, e.what());
+  } catch (...) {
+    return Fail(XV_ERR_INTERNAL, "unknown exception");
+  }
+}
+
+void FillInfo(const xv::BlobInfo& b, xv_model_info_t* info) {
+  memset(info, 0, sizeof *info);
+  info->input_dim = b.input_dim;
+  info->output_dim = b.output_dim;
+  info->left_context = b.left_context;
+  info->right_context = b.right_context;
+  info->min_frames = b.min_frames;
+  info->num_layers = (int32_t)b.layers.size();
+  info->output_is_segment = b.output_is_segment;
+}
+
+xv_status LoadCommon(xv::RawNnet& net, const char* nnet_config, const char* output_node, xv_model** out) {
+  if (nnet_config && *nnet_config) net.ApplyNnetConfig(nnet_config);
+  std::unique_ptr<xv_model> m(new xv_model);
+  try {
+    m->prog = xv::LowerToProgram(net, output_node && *output_node ? output_node : "output");
+  } catch (const xv::KioError& e) {
+    return Fail(XV_ERR_MODEL, e.what());
+  }
+  *out = m.release();
+  return XV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* xv_last_error(void) { return g_err.c_str(); }
+const char* xv_version(void) { return "xvec_hip 0.1 (gfx950)"; }
+
+xv_status xv_model_load(const void* raw, size_t n, const char* nnet_config, const char* output_node, xv_model** out) {
+  if (!raw || !out) return Fail(XV_ERR_ARG, "xv_model_load: null argument");
+  return Guard([&] {
+    xv::RawNnet net;
+    net.Read(std::string((const char*)raw, n));
+    return LoadCommon(net, nnet_config, output_node, out);
+  });
+}
+
+xv_status xv_model_load_rxfilename(const char* rxfilename, const char* nnet_config, const char* output_node,
+                                   xv_model** out) {
+  if (!rxfilename || !out) return Fail(XV_ERR_ARG, "xv_model_load_rxfilename: null argument");
+  return Guard([&] {
+    xv::RawNnet net;
+    net.ReadFrom(rxfilename);
+    return LoadCommon(net, nnet_config, output_node, out);
+  });
+}
+
+void xv_model_free(xv_model* m) { delete m; }
+
+xv_status xv_model_info(const xv_model* m, xv_model_info_t* info) {
+  if (!m || !info) return Fail(XV_ERR_ARG, "xv_model_info: null argument");
+  memset(info, 0, sizeof *info);
+  info->input_dim = m->prog.input_dim;
+  info->output_dim = m->prog.output_dim;
+  info->left_context = m->prog.left_context;
+  info->right_context = m->prog.right_context;
+  info->min_frames = m->prog.min_frames;
+  info->num_layers = (int32_t)m->prog.layers.size();
+  info->output_is_segment = m->prog.output_is_segment;
+  return XV_OK;
+}
+
+double xv_model_macs(const xv_model* m, int32_t frames) { return m ? m->prog.Macs(frames) : 0.0; }
+
+size_t xv_model_describe(const xv_model* m, char* buf, size_t n) {
+  if (!m) return 0;
+  const std::string s = m->prog.Describe();
+  if (buf && n) {
+    const size_t k = s.size() < n - 1 ? s.size() : n - 1;
+    memcpy(buf, s.data(), k);
+    buf[k] = 0;
+  }
+  return s.size() + 1;
+}
+
+xv_status xv_model_pack(const xv_model* m, int precision, void* blob, size_t* nbytes) {
+  if (!m || !nbytes) return Fail(XV_ERR_ARG, "xv_model_pack: null argument");
+  return Guard([&] {
+    std::vector<uint8_t> b = xv::PackModel(m->prog, precision);
+    if (blob) {
+      if (*nbytes < b.size()) return Fail(XV_ERR_ARG, "xv_model_pack: buffer too small");
+      memcpy(blob, b.data(), b.size());
+    }
+    *nbytes = b.size();
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_create(const xv_model* m, int device, int precision, xv_ctx** out) {
+  if (!m || !out) return Fail(XV_ERR_ARG, "xv_ctx_create: null argument");
+  return Guard([&] {
+    std::vector<uint8_t> b = xv::PackModel(m->prog, precision);
+    std::unique_ptr<xv_ctx> c(new xv_ctx);
+    c->eng.reset(new xv::Engine(b.data(), b.size(), device));
+    *out = c.release();
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_create_from_blob(const void* blob, size_t nbytes, int device, xv_ctx** out) {
+  if (!blob || !out) return Fail(XV_ERR_ARG, "xv_ctx_create_from_blob: null argument");
+  return Guard([&] {
+    std::unique_ptr<xv_ctx> c(new xv_ctx);
+    c->eng.reset(new xv::Engine((const uint8_t*)blob, nbytes, device));
+    *out = c.release();
+    return XV_OK;
+  });
+}
+
+void xv_ctx_free(xv_ctx* c) { delete c; }
+
+xv_status xv_ctx_info(const xv_ctx* c, xv_model_info_t* info, int32_t* precision, int32_t* device) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_info: null context");
+  if (info) FillInfo(c->eng->info(), info);
+  if (precision) *precision = c->eng->info().precision;
+  if (device) *device = c->eng->device();
+  return XV_OK;
+}
+
+xv_status xv_forward_batch(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float* out) {
+  if (!c || !feats || !row_offsets || !out) return Fail(XV_ERR_ARG, "xv_forward_batch: null argument");
+  return Guard([&] {
+    for (int b = 0; b < B; ++b)
+      if (row_offsets[b + 1] - row_offsets[b] < c->eng->info().min_frames)
+        return Fail(XV_ERR_ARG, "xv_forward_batch: chunk " + std::to_string(b) + " has fewer than min_frames rows");
+    c->eng->ForwardHost(feats, row_offsets, B, out);
+    return XV_OK;
+  });
+}
+
+xv_status xv_forward_batch_device(xv_ctx* c, const float* feats_dev, const int32_t* row_offsets, int32_t B,
+                                  float* out_dev, int32_t out_ld, void* hip_stream) {
+  if (!c || !feats_dev || !row_offsets || !out_dev) return Fail(XV_ERR_ARG, "xv_forward_batch_device: null argument");
+  return Guard([&] {
+    for (int b = 0; b < B; ++b)
+      if (row_offsets[b + 1] - row_offsets[b] < c->eng->info().min_frames)
+        return Fail(XV_ERR_ARG, "xv_forward_batch_device: chunk " + std::to_string(b) + " has fewer than min_frames rows");
+    if (out_ld < c->eng->info().output_dim) return Fail(XV_ERR_ARG, "xv_forward_batch_device: out_ld < output_dim");
+    std::shared_ptr<xv::Engine::Plan> plan = c->eng->MakePlan(row_offsets, B);
+    c->eng->Forward(*plan, feats_dev, out_dev, out_ld, (hipStream_t)hip_stream);
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_synchronize(xv_ctx* c) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_synchronize: null context");
+  return Guard([&] {
+    if (hipSetDevice(c->eng->device()) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      return Fail(XV_ERR_DEVICE, "hipDeviceSynchronize failed");
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_profiling: null context");
+  c->eng->SetProfiling(enable != 0);
+  return XV_OK;
+}
+
+size_t xv_ctx_profile_report(xv_ctx* c, char* buf, size_t n) {
+  if (!c) return 0;
+  std::string s;
+  if (Guard([&] {
+        s = c->eng->ProfileReport();
+        return XV_OK;
+      }) != XV_OK)
+    return 0;
+  if (buf && n) {
+    const size_t k = s.size() < n - 1 ? s.size() : n - 1;
+    memcpy(buf, s.data(), k);
+    buf[k] = 0;
+  }
+  return s.size() + 1;
+}
+
+xv_status xv_extract_utterances(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t n_utts,
+                                int32_t chunk_size, int32_t min_chunk_size, int32_t pad_input, float* out, int32_t* ok) {
+  if (!c || !feats || !row_offsets || !out || !ok) return Fail(XV_ERR_ARG, "xv_extract_utterances: null argument");
+  return Guard([&] {
+    xv::ExtractOptions opt;
+    opt.chunk_size = chunk_size;
+    opt.min_chunk_size = min_chunk_size;
+    opt.pad_input = pad_input != 0;
+    xv::ExtractUtterances(c->eng.get(), opt, feats, row_offsets, n_utts, out, ok, nullptr);
+    return XV_OK;
+  });
+}
+
+// RCCL is bound lazily so that the library loads (and every non-collective entry works) on hosts where
+// librccl cannot initialise.
+xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, int precision, xv_ctx** out) {
+  if (!m || !devices || !out || n < 1) return Fail(XV_ERR_ARG, "xv_ctx_create_broadcast: bad argument");
+  return Guard([&]() -> xv_status {
+    std::vector<uint8_t> blob = xv::PackModel(m->prog, precision);
+    if (n == 1) {
+      std::unique_ptr<xv_ctx> c(new xv_ctx);
+      c->eng.reset(new xv::Engine(blob.data(), blob.size(), devices[0]));
+      out[0] = c.release();
+      return XV_OK;
+    }
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return Fail(XV_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
+    typedef void* comm_t;
+    typedef int (*CommInitAll_t)(comm_t*, int, const int*);
+    typedef int (*Broadcast_t)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
+    typedef int (*Group_t)(void);
+    typedef int (*CommDestroy_t)(comm_t);
+    CommInitAll_t comm_init_all = (CommInitAll_t)dlsym(lib, "ncclCommInitAll");
+    Broadcast_t bcast = (Broadcast_t)dlsym(lib, "ncclBroadcast");
+    Group_t gstart = (Group_t)dlsym(lib, "ncclGroupStart");
+    Group_t gend = (Group_t)dlsym(lib, "ncclGroupEnd");
+    CommDestroy_t cdestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
+    if (!comm_init_all || !bcast || !gstart || !gend || !cdestroy) return Fail(XV_ERR_DEVICE, "librccl lacks expected symbols");
+    std::vector<comm_t> comms(n, nullptr);
+    if (comm_init_all(comms.data(), n, devices) != 0) return Fail(XV_ERR_DEVICE, "ncclCommInitAll failed");
+    std::vector<void*> dbuf(n, nullptr);
+    std::vector<hipStream_t> st(n, nullptr);
+    xv_status rc = XV_OK;
+    for (int i = 0; i < n && rc == XV_OK; ++i) {
+      if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc(&dbuf[i], blob.size()) != hipSuccess ||
+          hipStreamCreate(&st[i]) != hipSuccess)
+        rc = Fail(XV_ERR_DEVICE, "device allocation for the weight broadcast failed");
+    }
+    if (rc == XV_OK) {
+      (void)hipSetDevice(devices[0]);
+      if (hipMemcpy(dbuf[0], blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess)
+        rc = Fail(XV_ERR_DEVICE, "upload of the weight blob failed");
+    }
+    if (rc == XV_OK) {
+      // ONE broadcast of the packed image, ncclChar elements (type id 0), root = rank 0
+      gstart();
+      for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(devices[i]);
+        if (bcast(dbuf[i], dbuf[i], blob.size(), /*ncclChar*/ 0, 0, comms[i], st[i]) != 0)
+          rc = Fail(XV_ERR_DEVICE, "ncclBroadcast failed");
+      }
+      gend();
+    }
+    std::vector<std::vector<uint8_t>> host(n);
+    for (int i = 0; i < n && rc == XV_OK; ++i) {
+      (void)hipSetDevice(devices[i]);
+      (void)hipStreamSynchronize(st[i]);
+      // every rank builds its context from the bytes *it received*, so a bad broadcast cannot go unnoticed
+      host[i].resize(blob.size());
+      if (hipMemcpy(host[i].data(), dbuf[i], blob.size(), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = Fail(XV_ERR_DEVICE, "readback of the broadcast blob failed");
+    }
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(devices[i]);
+      if (dbuf[i]) (void)hipFree(dbuf[i]);
+      if (st[i]) (void)hipStreamDestroy(st[i]);
+      if (comms[i]) cdestroy(comms[i]);
+    }
+    if (rc != XV_OK) return rc;
+    std::vector<std::unique_ptr<xv_ctx>> ctxs;
+    for (int i = 0; i < n; ++i) {
+      std::unique_ptr<xv_ctx> c(new xv_ctx);
+      c->eng.reset(new xv::Engine(host[i].data(), host[i].size(), devices[i]));
+      ctxs.push_back(std::move(c));
+    }
+    for (int i = 0; i < n; ++i) out[i] = ctxs[i].release();
+    return XV_OK;
+  });
+}
+
+xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
+  if (!d) return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: null descriptor");
+  return Guard([&] {
+    if (d->nseg < 1 || d->nseg > xv::kMaxSeg || d->rows % xv::kBM || d->n_pad % xv::kBN)
+      return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: bad geometry");
+    xv::GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.nseg = d->nseg;
+    for (int j = 0; j < d->nseg; ++j) {
+      if (d->seg[j].k_len % xv::kBK) return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: k_len must be a multiple of 32");
+      a.seg[j].hi = (const uint16_t*)d->seg[j].hi;
+      a.seg[j].lo = (const uint16_t*)d->seg[j].lo;
+      a.seg[j].ld = d->seg[j].ld;
+      a.seg[j].row_shift = d->seg[j].row_shift;
+      a.seg[j].ksteps = d->seg[j].k_len / xv::kBK;
+      a.total_ksteps += a.seg[j].ksteps;
+    }
+    a.w_hi = (const uint16_t*)d->w_hi;
+    a.w_lo = (const uint16_t*)d->w_lo;
+    a.ldw = d->ldw;
+    a.m_tiles = d->rows / xv::kBM;
+    a.n_tiles = d->n_pad / xv::kBN;
+    a.relu = d->relu;
+    a.bn = d->bn;
+    a.bias = d->bias;
+    a.scale = d->scale;
+    a.offset = d->offset;
+    a.out_hi = (uint16_t*)d->out_hi;
+    a.out_lo = (uint16_t*)d->out_lo;
+    a.ldo = d->ldo;
+    a.out_f32 = d->out_f32;
+    a.ldf = d->ldf;
+    a.m_valid = d->m_valid;
+    a.partial = d->partial;
+    a.ldp = d->ldp;
+    a.grp_range = d->grp_range;
+    hipError_t e = xv::launch_tdnn_gemm(a, d->precision, d->epilogue, (hipStream_t)d->hip_stream);
+    if (e != hipSuccess) return Fail(XV_ERR_DEVICE, std::string("tdnn_gemm launch: ") + hipGetErrorString(e));
+    return XV_OK;
+  });
+}
+
+}  // extern "C"

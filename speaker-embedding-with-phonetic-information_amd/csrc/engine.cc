@@ -1,0 +1,601 @@
+// Device engine.  See engine.h.
+#include "engine.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <sstream>
+
+namespace xv {
+
+namespace {
+
+constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
+constexpr uint32_t kBlobVersion = 1;
+constexpr uint64_t kNone = ~0ull;
+
+struct BlobHeader {
+  char magic[8];
+  uint32_t version;
+  int32_t precision;
+  int32_t input_dim, n_layers, pooled_layer, pool_dim, pool_left, pool_right;
+  float variance_floor;
+  int32_t output_layer, output_dim, output_is_segment, left_context, right_context, min_frames;
+  int32_t reserved[7];
+  uint64_t data_offset;
+  uint64_t total_bytes;
+};
+
+struct BlobLayer {
+  char name[64];
+  int32_t nsrc;
+  int32_t src_layer[kMaxSeg], src_offset[kMaxSeg], src_dim[kMaxSeg];
+  int32_t in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
+  uint64_t w_hi, w_lo, bias, scale, offset;  // relative to data_offset
+};
+
+inline int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
+inline uint64_t Align256(uint64_t x) { return (x + 255) & ~255ull; }
+
+}  // namespace
+
+std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
+  if (precision != kPrecBf16x3 && precision != kPrecBf16 && precision != kPrecFp16)
+    throw EngineError("unknown precision mode");
+  const bool split = precision == kPrecBf16x3;
+  const bool f16 = precision == kPrecFp16;
+  const int nl = (int)prog.layers.size();
+  std::vector<BlobLayer> bl(nl);
+  uint64_t cur = 0;
+  for (int i = 0; i < nl; ++i) {
+    const AffineLayer& L = prog.layers[i];
+    BlobLayer& b = bl[i];
+    memset(&b, 0, sizeof b);
+    snprintf(b.name, sizeof b.name, "%s", L.out_node.c_str());
+    if ((int)L.src.size() > kMaxSeg) throw EngineError("layer " + L.name + " has more than 8 Append() terms");
+    b.nsrc = (int)L.src.size();
+    int kp = 0;
+    for (int j = 0; j < b.nsrc; ++j) {
+      b.src_layer[j] = L.src[j].layer;
+      b.src_offset[j] = L.src[j].offset;
+      b.src_dim[j] = L.src[j].dim;
+      kp += RoundUp(L.src[j].dim, kBK);
+    }
+    b.in_dim = L.in_dim;
+    b.out_dim = L.out_dim;
+    b.k_pad = kp;
+    b.n_pad = RoundUp(L.out_dim, kBN);
+    b.relu = L.relu;
+    b.bn = L.bn;
+    b.log_softmax = L.log_softmax;
+    b.segment_level = L.segment_level;
+    b.left = L.left;
+    b.right = L.right;
+    const uint64_t wbytes = (uint64_t)b.n_pad * b.k_pad * 2;
+    b.w_hi = cur;
+    cur = Align256(cur + wbytes);
+    if (split) {
+      b.w_lo = cur;
+      cur = Align256(cur + wbytes);
+    } else {
+      b.w_lo = kNone;
+    }
+    b.bias = cur;
+    cur = Align256(cur + (uint64_t)b.n_pad * 4);
+    b.scale = cur;
+    cur = Align256(cur + (uint64_t)b.n_pad * 4);
+    b.offset = cur;
+    cur = Align256(cur + (uint64_t)b.n_pad * 4);
+  }
+  BlobHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "XVHIPBLB", 8);
+  h.version = kBlobVersion;
+  h.precision = precision;
+  h.input_dim = prog.input_dim;
+  h.n_layers = nl;
+  h.pooled_layer = prog.pooled_layer;
+  h.pool_dim = prog.pool_dim;
+  h.pool_left = prog.pool_left;
+  h.pool_right = prog.pool_right;
+  h.variance_floor = prog.variance_floor;
+  h.output_layer = prog.output_layer;
+  h.output_dim = prog.output_dim;
+  h.output_is_segment = prog.output_is_segment;
+  h.left_context = prog.left_context;
+  h.right_context = prog.right_context;
+  h.min_frames = prog.min_frames;
+  h.data_offset = Align256(sizeof(BlobHeader) + (uint64_t)nl * sizeof(BlobLayer));
+  h.total_bytes = h.data_offset + cur;
+  std::vector<uint8_t> blob(h.total_bytes, 0);
+  memcpy(blob.data(), &h, sizeof h);
+  memcpy(blob.data() + sizeof h, bl.data(), (size_t)nl * sizeof(BlobLayer));
+  uint8_t* data = blob.data() + h.data_offset;
+  for (int i = 0; i < nl; ++i) {
+    const AffineLayer& L = prog.layers[i];
+    const BlobLayer& b = bl[i];
+    uint16_t* whi = (uint16_t*)(data + b.w_hi);
+    uint16_t* wlo = split ? (uint16_t*)(data + b.w_lo) : nullptr;
+    for (int n = 0; n < L.out_dim; ++n) {
+      int kcol = 0, kpad = 0;
+      for (int j = 0; j < b.nsrc; ++j) {
+        for (int d = 0; d < b.src_dim[j]; ++d) {
+          const float w = L.w[(size_t)n * L.in_dim + kcol + d];
+          const size_t o = (size_t)n * b.k_pad + kpad + d;
+          if (f16) {
+            whi[o] = host_f32_to_f16(w);
+          } else {
+            whi[o] = host_f32_to_bf16(w);
+            if (split) wlo[o] = host_f32_to_bf16(w - host_bf16_to_f32(whi[o]));
+          }
+        }
+        kcol += b.src_dim[j];
+        kpad += RoundUp(b.src_dim[j], kBK);
+      }
+    }
+    float* bias = (float*)(data + b.bias);
+    float* scale = (float*)(data + b.scale);
+    float* offset = (float*)(data + b.offset);
+    for (int n = 0; n < L.out_dim; ++n) {
+      bias[n] = L.bias[n];
+      scale[n] = L.bn ? L.bn_scale[n] : 1.f;
+      offset[n] = L.bn ? L.bn_offset[n] : 0.f;
+    }
+    // padded output columns: bias 0, scale 0, offset 0 -> they stay exactly 0 downstream
+  }
+  return blob;
+}
+
+BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
+  if (n < sizeof(BlobHeader)) throw EngineError("model blob too small");
+  BlobHeader h;
+  memcpy(&h, blob, sizeof h);
+  if (memcmp(h.magic, "XVHIPBLB", 8) != 0 || h.version != kBlobVersion) throw EngineError("bad model blob header");
+  if (h.total_bytes != n) throw EngineError("model blob size mismatch");
+  BlobInfo info;
+  info.precision = h.precision;
+  info.input_dim = h.input_dim;
+  info.pooled_layer = h.pooled_layer;
+  info.pool_dim = h.pool_dim;
+  info.pool_left = h.pool_left;
+  info.pool_right = h.pool_right;
+  info.variance_floor = h.variance_floor;
+  info.output_layer = h.output_layer;
+  info.output_dim = h.output_dim;
+  info.output_is_segment = h.output_is_segment;
+  info.left_context = h.left_context;
+  info.right_context = h.right_context;
+  info.min_frames = h.min_frames;
+  for (int i = 0; i < h.n_layers; ++i) {
+    BlobLayer b;
+    memcpy(&b, blob + sizeof h + (size_t)i * sizeof(BlobLayer), sizeof b);
+    BlobLayerInfo li;
+    li.name = b.name;
+    li.in_dim = b.in_dim;
+    li.out_dim = b.out_dim;
+    li.k_pad = b.k_pad;
+    li.n_pad = b.n_pad;
+    li.relu = b.relu;
+    li.bn = b.bn;
+    li.log_softmax = b.log_softmax;
+    li.segment_level = b.segment_level;
+    li.left = b.left;
+    li.right = b.right;
+    for (int j = 0; j < b.nsrc; ++j) {
+      LayerSource s;
+      s.layer = b.src_layer[j];
+      s.offset = b.src_offset[j];
+      s.dim = b.src_dim[j];
+      li.src.push_back(s);
+    }
+    info.layers.push_back(li);
+  }
+  return info;
+}
+
+double BlobInfo::Macs(int T) const {
+  const int n = (int)layers.size();
+  std::vector<int> nl(n, 1 << 30), nr(n, 1 << 30);
+  const int root = output_is_segment ? pooled_layer : output_layer;
+  nl[root] = layers[root].left;
+  nr[root] = layers[root].right;
+  for (int i = n - 1; i >= 0; --i) {
+    if (layers[i].segment_level || nl[i] == (1 << 30)) continue;
+    for (const LayerSource& s : layers[i].src)
+      if (s.layer >= 0) {
+        nl[s.layer] = std::min(nl[s.layer], nl[i] + s.offset);
+        nr[s.layer] = std::min(nr[s.layer], nr[i] - s.offset);
+      }
+  }
+  double macs = 0;
+  for (int i = 0; i < n; ++i) {
+    if (layers[i].segment_level) macs += (double)layers[i].in_dim * layers[i].out_dim;
+    else if (nl[i] != (1 << 30)) macs += (double)layers[i].in_dim * layers[i].out_dim * std::max(0, T - nl[i] - nr[i]);
+  }
+  return macs;
+}
+
+// ------------------------------------------------------------------------------------------- Engine
+void Engine::Check(hipError_t e, const char* what) const {
+  if (e != hipSuccess) {
+    std::ostringstream m;
+    m << what << ": " << hipGetErrorString(e) << " (HIP error " << (int)e << ", device " << device_ << ")";
+    throw EngineError(m.str());
+  }
+}
+
+Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
+  info_ = ParseBlobInfo(blob, n);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    throw EngineError("no HIP device available: this library has no CPU path (hipGetDeviceCount: " +
+                      std::string(hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= count) throw EngineError("HIP device index out of range");
+  Check(hipSetDevice(device_), "hipSetDevice");
+  hipDeviceProp_t prop;
+  Check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    throw EngineError(std::string("kernels are built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+  if (!info_.output_is_segment)
+    throw EngineError("frame-level outputs are not supported by this engine build (output must follow the pooling)");
+  if (info_.pooled_layer < 0) throw EngineError("model has no statistics pooling");
+  for (size_t i = 0; i < info_.layers.size(); ++i)
+    for (const LayerSource& s : info_.layers[i].src)
+      if (s.layer == info_.pooled_layer)
+        throw EngineError("the pooled layer must feed only the statistics pooling");
+  nplanes_ = info_.precision == kPrecBf16x3 ? 2 : 1;
+  Check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+
+  BlobHeader h;
+  memcpy(&h, blob, sizeof h);
+  blob_data_bytes_ = (size_t)(h.total_bytes - h.data_offset);
+  Check(hipMalloc(&d_blob_, blob_data_bytes_), "hipMalloc(weights)");
+  Check(hipMemcpy(d_blob_, blob + h.data_offset, blob_data_bytes_, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+  layers_.resize(info_.layers.size());
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    BlobLayer b;
+    memcpy(&b, blob + sizeof h + i * sizeof(BlobLayer), sizeof b);
+    const uint8_t* base = (const uint8_t*)d_blob_;
+    layers_[i].w_hi = (const uint16_t*)(base + b.w_hi);
+    layers_[i].w_lo = b.w_lo == kNone ? nullptr : (const uint16_t*)(base + b.w_lo);
+    layers_[i].bias = (const float*)(base + b.bias);
+    layers_[i].scale = (const float*)(base + b.scale);
+    layers_[i].offset = (const float*)(base + b.offset);
+  }
+  in_ld_ = RoundUp(info_.input_dim, kBK);
+  stats_ld_ = RoundUp(2 * info_.pool_dim, kBK);
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  plan_cache_.clear();
+  auto fr = [](Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+  };
+  for (DevLayer& L : layers_) {
+    fr(L.act_hi);
+    fr(L.act_lo);
+  }
+  fr(in_hi_);
+  fr(in_lo_);
+  fr(partial_);
+  fr(stats_hi_);
+  fr(stats_lo_);
+  fr(out_f32_);
+  fr(feats_stage_);
+  fr(out_stage_);
+  if (d_blob_) (void)hipFree(d_blob_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::Ensure(Buf* b, size_t bytes, bool zero) {
+  if (b->bytes >= bytes && b->p) return;
+  if (b->p) Check(hipFree(b->p), "hipFree");
+  b->p = nullptr;
+  Check(hipMalloc(&b->p, bytes), "hipMalloc");
+  b->bytes = bytes;
+  if (zero) Check(hipMemset(b->p, 0, bytes), "hipMemset");
+}
+
+void Engine::EnsureCapacity(int rows, int b_pad) {
+  if (rows > cap_rows_) {
+    Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    const size_t r = (size_t)rows + 2 * kHalo;
+    Ensure(&in_hi_, r * in_ld_ * 2, true);
+    if (nplanes_ == 2) Ensure(&in_lo_, r * in_ld_ * 2, true);
+    for (size_t i = 0; i < layers_.size(); ++i) {
+      const BlobLayerInfo& li = info_.layers[i];
+      if (li.segment_level) continue;
+      if ((int)i == info_.pooled_layer) {
+        Ensure(&partial_, (size_t)(rows / kRowAlign) * 2 * li.n_pad * 4, true);
+        continue;
+      }
+      Ensure(&layers_[i].act_hi, r * li.n_pad * 2, true);
+      if (nplanes_ == 2) Ensure(&layers_[i].act_lo, r * li.n_pad * 2, true);
+    }
+    cap_rows_ = rows;
+  }
+  if (b_pad > cap_b_) {
+    Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    Ensure(&stats_hi_, (size_t)b_pad * stats_ld_ * 2, true);
+    if (nplanes_ == 2) Ensure(&stats_lo_, (size_t)b_pad * stats_ld_ * 2, true);
+    for (size_t i = 0; i < layers_.size(); ++i) {
+      const BlobLayerInfo& li = info_.layers[i];
+      if (!li.segment_level) continue;
+      if ((int)i == info_.output_layer) {
+        Ensure(&out_f32_, (size_t)b_pad * li.n_pad * 4, true);
+      } else {
+        Ensure(&layers_[i].act_hi, (size_t)b_pad * li.n_pad * 2, true);
+        if (nplanes_ == 2) Ensure(&layers_[i].act_lo, (size_t)b_pad * li.n_pad * 2, true);
+      }
+    }
+    cap_b_ = b_pad;
+  }
+}
+
+uint16_t* Engine::ActBase(const Buf& b, int ld) const {
+  return b.p ? (uint16_t*)b.p + (size_t)kHalo * ld : nullptr;
+}
+
+Engine::Plan::~Plan() {
+  if (d_tables) (void)hipFree(d_tables);
+}
+
+std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B) {
+  if (B <= 0) throw EngineError("empty batch");
+  std::vector<int32_t> key(B);
+  for (int b = 0; b < B; ++b) {
+    key[b] = row_offsets[b + 1] - row_offsets[b];
+    if (key[b] < info_.min_frames) {
+      std::ostringstream m;
+      m << "chunk " << b << " has " << key[b] << " frames; the network needs at least " << info_.min_frames;
+      throw EngineError(m.str());
+    }
+  }
+  key.push_back(row_offsets[0]);
+  auto hit = plan_cache_.find(key);
+  if (hit != plan_cache_.end()) return hit->second;
+
+  Check(hipSetDevice(device_), "hipSetDevice");
+  auto plan = std::make_shared<Plan>();
+  plan->B = B;
+  plan->b_pad = RoundUp(B, kBM);
+  plan->src_off.assign(row_offsets, row_offsets + B + 1);
+  plan->src_rows = row_offsets[B];
+  std::vector<int32_t> dev_off(B);
+  long off = 0;
+  for (int b = 0; b < B; ++b) {
+    dev_off[b] = (int32_t)off;
+    off += RoundUp(key[b], kRowAlign);
+    if (off > (1l << 30)) throw EngineError("batch too large (more than 2^30 device rows)");
+  }
+  plan->rows = RoundUp((int)off, kBM);
+  const int ngrp = plan->rows / kRowAlign;
+  std::vector<int32_t> grp_utt(ngrp, -1), g0(B), g1(B), cnt(B);
+  std::vector<int8_t> grp_range((size_t)ngrp * 2, 0);
+  const BlobLayerInfo& pl = info_.layers[info_.pooled_layer];
+  for (int b = 0; b < B; ++b) {
+    const int T = key[b];
+    // frames of the pooled layer that exist, intersected with the pooling window of output index t=0
+    const int first = std::max(pl.left, -info_.pool_left);
+    const int last = std::min(T - 1 - pl.right, info_.pool_right);
+    if (last < first) throw EngineError("chunk has no frame inside the pooling window");
+    cnt[b] = last - first + 1;
+    g0[b] = dev_off[b] / kRowAlign;
+    g1[b] = (dev_off[b] + RoundUp(T, kRowAlign)) / kRowAlign;
+    for (int g = g0[b]; g < g1[b]; ++g) {
+      grp_utt[g] = b;
+      const int t0 = (g - g0[b]) * kRowAlign;
+      grp_range[2 * g] = (int8_t)std::min(std::max(first - t0, 0), kRowAlign);
+      grp_range[2 * g + 1] = (int8_t)std::min(std::max(last + 1 - t0, 0), kRowAlign);
+    }
+  }
+  // one device allocation, 256-B aligned sections
+  size_t o_src = 0;
+  size_t o_dev = Align256(o_src + (size_t)(B + 1) * 4);
+  size_t o_gu = Align256(o_dev + (size_t)B * 4);
+  size_t o_gr = Align256(o_gu + (size_t)ngrp * 4);
+  size_t o_g0 = Align256(o_gr + (size_t)ngrp * 2);
+  size_t o_g1 = Align256(o_g0 + (size_t)B * 4);
+  size_t o_cn = Align256(o_g1 + (size_t)B * 4);
+  size_t total = Align256(o_cn + (size_t)B * 4);
+  std::vector<uint8_t> host(total, 0);
+  memcpy(host.data() + o_src, plan->src_off.data(), (size_t)(B + 1) * 4);
+  memcpy(host.data() + o_dev, dev_off.data(), (size_t)B * 4);
+  memcpy(host.data() + o_gu, grp_utt.data(), (size_t)ngrp * 4);
+  memcpy(host.data() + o_gr, grp_range.data(), (size_t)ngrp * 2);
+  memcpy(host.data() + o_g0, g0.data(), (size_t)B * 4);
+  memcpy(host.data() + o_g1, g1.data(), (size_t)B * 4);
+  memcpy(host.data() + o_cn, cnt.data(), (size_t)B * 4);
+  Check(hipMalloc(&plan->d_tables, total), "hipMalloc(plan)");
+  Check(hipMemcpy(plan->d_tables, host.data(), total, hipMemcpyHostToDevice), "hipMemcpy(plan)");
+  const uint8_t* d = (const uint8_t*)plan->d_tables;
+  plan->d_src_off = (const int32_t*)(d + o_src);
+  plan->d_dev_off = (const int32_t*)(d + o_dev);
+  plan->d_grp_utt = (const int32_t*)(d + o_gu);
+  plan->d_grp_range = (const int8_t*)(d + o_gr);
+  plan->d_utt_grp0 = (const int32_t*)(d + o_g0);
+  plan->d_utt_grp1 = (const int32_t*)(d + o_g1);
+  plan->d_utt_count = (const int32_t*)(d + o_cn);
+  if (plan_cache_.size() >= 64) plan_cache_.clear();
+  plan_cache_[key] = plan;
+  return plan;
+}
+
+void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream) {
+  Check(hipSetDevice(device_), "hipSetDevice");
+  hipStream_t s = stream ? stream : stream_;
+  EnsureCapacity(plan.rows, plan.b_pad);
+  const int prec = info_.precision;
+
+  PrepArgs pa;
+  pa.feats = feats_dev;
+  pa.src_off = plan.d_src_off;
+  pa.dev_off = plan.d_dev_off;
+  pa.grp_utt = plan.d_grp_utt;
+  pa.rows = plan.rows;
+  pa.dim = info_.input_dim;
+  pa.ld = in_ld_;
+  pa.out_hi = ActBase(in_hi_, in_ld_);
+  pa.out_lo = ActBase(in_lo_, in_ld_);
+  std::vector<hipEvent_t> prof_run;
+  const bool first_prof = prof_on_ && prof_labels_.empty();
+  if (prof_on_) ProfMark(s, &prof_run);
+  Check(launch_prep_input(pa, prec, s), "prep_input launch");
+  if (prof_on_) ProfMark(s, &prof_run);
+  if (first_prof) prof_labels_.push_back("prep_input");
+
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    const BlobLayerInfo& li = info_.layers[i];
+    DevLayer& dl = layers_[i];
+    GemmArgs ga;
+    memset(&ga, 0, sizeof ga);
+    ga.nseg = (int)li.src.size();
+    int ksteps = 0;
+    for (int j = 0; j < ga.nseg; ++j) {
+      const LayerSource& src = li.src[j];
+      Seg& sg = ga.seg[j];
+      if (src.layer == kSrcInput) {
+        sg.hi = ActBase(in_hi_, in_ld_);
+        sg.lo = ActBase(in_lo_, in_ld_);
+        sg.ld = in_ld_;
+      } else if (src.layer == kSrcPooled) {
+        sg.hi = (const uint16_t*)stats_hi_.p;
+        sg.lo = (const uint16_t*)stats_lo_.p;
+        sg.ld = stats_ld_;
+      } else {
+        const BlobLayerInfo& pi = info_.layers[src.layer];
+        if (pi.segment_level) {
+          sg.hi = (const uint16_t*)layers_[src.layer].act_hi.p;
+          sg.lo = (const uint16_t*)layers_[src.layer].act_lo.p;
+        } else {
+          sg.hi = ActBase(layers_[src.layer].act_hi, pi.n_pad);
+          sg.lo = ActBase(layers_[src.layer].act_lo, pi.n_pad);
+        }
+        sg.ld = pi.n_pad;
+      }
+      sg.row_shift = li.segment_level ? 0 : src.offset;
+      sg.ksteps = RoundUp(src.dim, kBK) / kBK;
+      ksteps += sg.ksteps;
+    }
+    ga.total_ksteps = ksteps;
+    ga.w_hi = dl.w_hi;
+    ga.w_lo = dl.w_lo;
+    ga.ldw = li.k_pad;
+    ga.n_tiles = li.n_pad / kBN;
+    ga.relu = li.relu;
+    ga.bn = li.bn;
+    ga.bias = dl.bias;
+    ga.scale = dl.scale;
+    ga.offset = dl.offset;
+    int epi;
+    if (!li.segment_level) {
+      ga.m_tiles = plan.rows / kBM;
+      if ((int)i == info_.pooled_layer) {
+        epi = kEpiStats;
+        ga.partial = (float*)partial_.p;
+        ga.ldp = li.n_pad;
+        ga.grp_range = plan.d_grp_range;
+      } else {
+        epi = kEpiAct;
+        ga.out_hi = ActBase(dl.act_hi, li.n_pad);
+        ga.out_lo = ActBase(dl.act_lo, li.n_pad);
+        ga.ldo = li.n_pad;
+      }
+    } else {
+      ga.m_tiles = plan.b_pad / kBM;
+      if ((int)i == info_.output_layer) {
+        epi = kEpiF32;
+        ga.out_f32 = (float*)out_f32_.p;
+        ga.ldf = li.n_pad;
+        ga.m_valid = plan.B;
+      } else {
+        epi = kEpiAct;
+        ga.out_hi = (uint16_t*)dl.act_hi.p;
+        ga.out_lo = (uint16_t*)dl.act_lo.p;
+        ga.ldo = li.n_pad;
+      }
+    }
+    Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
+    if (prof_on_) ProfMark(s, &prof_run);
+    if (first_prof)
+      prof_labels_.push_back(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
+
+    if ((int)i == info_.pooled_layer) {
+      PoolArgs po;
+      po.partial = (const float*)partial_.p;
+      po.ldp = li.n_pad;
+      po.utt_grp0 = plan.d_utt_grp0;
+      po.utt_grp1 = plan.d_utt_grp1;
+      po.utt_count = plan.d_utt_count;
+      po.B = plan.B;
+      po.dim = info_.pool_dim;
+      po.var_floor = info_.variance_floor;
+      po.out_hi = (uint16_t*)stats_hi_.p;
+      po.out_lo = (uint16_t*)stats_lo_.p;
+      po.ld = stats_ld_;
+      Check(launch_pool_finalise(po, prec, s), "pool_finalise launch");
+      if (prof_on_) ProfMark(s, &prof_run);
+      if (first_prof) prof_labels_.push_back("pool_finalise");
+    }
+  }
+  const BlobLayerInfo& ol = info_.layers[info_.output_layer];
+  Check(hipMemcpy2DAsync(out_dev, (size_t)out_ld * 4, out_f32_.p, (size_t)ol.n_pad * 4, (size_t)info_.output_dim * 4,
+                         (size_t)plan.B, hipMemcpyDeviceToDevice, s),
+        "hipMemcpy2DAsync(out)");
+  if (prof_on_) {
+    ProfMark(s, &prof_run);
+    if (first_prof) prof_labels_.push_back("copy_out");
+    prof_runs_.push_back(std::move(prof_run));
+  }
+}
+
+void Engine::ProfMark(hipStream_t s, std::vector<hipEvent_t>* run) {
+  hipEvent_t e;
+  Check(hipEventCreate(&e), "hipEventCreate");
+  Check(hipEventRecord(e, s), "hipEventRecord");
+  run->push_back(e);
+}
+
+std::string Engine::ProfileReport() {
+  Check(hipSetDevice(device_), "hipSetDevice");
+  Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  std::vector<double> tot(prof_labels_.size(), 0.0);
+  for (auto& run : prof_runs_) {
+    for (size_t i = 0; i + 1 < run.size() && i < tot.size(); ++i) {
+      float ms = 0.f;
+      Check(hipEventElapsedTime(&ms, run[i], run[i + 1]), "hipEventElapsedTime");
+      tot[i] += ms;
+    }
+    for (hipEvent_t e : run) (void)hipEventDestroy(e);
+  }
+  std::ostringstream o;
+  o.precision(9);
+  for (size_t i = 0; i < tot.size(); ++i) o << prof_labels_[i] << "\t" << prof_runs_.size() << "\t" << tot[i] << "\n";
+  prof_runs_.clear();
+  return o.str();
+}
+
+void Engine::ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out) {
+  Check(hipSetDevice(device_), "hipSetDevice");
+  std::shared_ptr<Plan> plan = MakePlan(row_offsets, B);
+  const size_t fbytes = (size_t)(row_offsets[B] - row_offsets[0]) * info_.input_dim * 4;
+  const size_t obytes = (size_t)B * info_.output_dim * 4;
+  if (feats_stage_.bytes < fbytes || out_stage_.bytes < obytes) Check(hipStreamSynchronize(stream_), "sync");
+  Ensure(&feats_stage_, std::max(fbytes, (size_t)4), false);
+  Ensure(&out_stage_, obytes, false);
+  // the device copy starts at the first row the caller referenced
+  Check(hipMemcpyAsync(feats_stage_.p, feats + (size_t)row_offsets[0] * info_.input_dim, fbytes, hipMemcpyHostToDevice,
+                       stream_),
+        "hipMemcpyAsync(feats)");
+  // plan offsets are absolute; shift the device base so that offset row_offsets[0] lands on byte 0
+  const float* dev_feats = (const float*)feats_stage_.p - (size_t)row_offsets[0] * info_.input_dim;
+  Forward(*plan, dev_feats, (float*)out_stage_.p, info_.output_dim, stream_);
+  Check(hipMemcpyAsync(out, out_stage_.p, obytes, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(out)");
+  Check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+}  // namespace xv

@@ -1,0 +1,127 @@
+// Device engine: packed weights resident in HBM + per-batch plans + the kernel sequence.
+//
+// Replaces NnetComputer::Run() / RunNnetComputation() of nnet3-xvector-compute (SURVEY.md §3.1 HOT
+// LOOP 3) for a whole batch of chunks at once.  A "plan" is the analogue of the cached compiled
+// computation Kaldi keeps per distinct chunk length (CachingOptimizingCompiler, §8(a) row a6): it
+// holds the row geometry of one batch shape.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "program.h"
+
+namespace xv {
+
+struct EngineError : public std::runtime_error {
+  explicit EngineError(const std::string& m) : std::runtime_error(m) {}
+};
+
+// Flat, position-independent image of a lowered + padded + precision-split model.  This is what one
+// rank broadcasts to the others over RCCL and what an Engine is built from.
+std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision);
+
+struct BlobLayerInfo {
+  std::string name;
+  int in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
+  std::vector<LayerSource> src;
+};
+
+struct BlobInfo {
+  int precision, input_dim, pooled_layer, pool_dim, pool_left, pool_right, output_layer, output_dim,
+      output_is_segment, left_context, right_context, min_frames;
+  float variance_floor;
+  std::vector<BlobLayerInfo> layers;
+  double Macs(int T) const;
+};
+BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n);
+
+class Engine {
+ public:
+  struct Plan;
+  // Throws EngineError when no usable HIP device exists - there is no CPU fallback in the product.
+  Engine(const uint8_t* blob, size_t n, int device);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  const BlobInfo& info() const { return info_; }
+  int device() const { return device_; }
+
+  // row_offsets: B+1 offsets (in rows) of the chunks inside the packed feature matrix.
+  std::shared_ptr<Plan> MakePlan(const int32_t* row_offsets, int B);
+  // feats_dev: packed fp32 rows [row_offsets[B]][input_dim] in device memory;
+  // out_dev: [B][out_ld] fp32 (device).  Asynchronous on `stream` (nullptr = the engine's stream).
+  void Forward(const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream);
+  // Host convenience: H2D, forward, D2H, synchronise.
+  void ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out);
+
+  hipStream_t stream() const { return stream_; }
+  // last forward's per-kernel launch list (name, m_tiles*n_tiles) for logging / tests
+  size_t weight_bytes() const { return blob_data_bytes_; }
+  // Per-launch timing with HIP events recorded on the stream the kernels are launched on.
+  void SetProfiling(bool on) { prof_on_ = on; }
+  // "label<TAB>launches<TAB>total_ms" lines for everything recorded since the last report; resets.
+  std::string ProfileReport();
+
+ private:
+  struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+  };
+  struct DevLayer {
+    const uint16_t* w_hi;
+    const uint16_t* w_lo;
+    const float* bias;
+    const float* scale;
+    const float* offset;
+    Buf act_hi, act_lo;   // frame-level: [halo + rows + halo][n_pad]; segment-level: [b_pad][n_pad]
+  };
+  void Check(hipError_t e, const char* what) const;
+  void Ensure(Buf* b, size_t bytes, bool zero);
+  void EnsureCapacity(int rows, int b_pad);
+  uint16_t* ActBase(const Buf& b, int ld) const;
+
+  BlobInfo info_;
+  int device_ = 0;
+  int nplanes_ = 1;
+  hipStream_t stream_ = nullptr;
+  void* d_blob_ = nullptr;
+  size_t blob_data_bytes_ = 0;
+  std::vector<DevLayer> layers_;
+  int in_ld_ = 0;
+  Buf in_hi_, in_lo_;
+  Buf partial_;
+  Buf stats_hi_, stats_lo_;
+  int stats_ld_ = 0;
+  Buf out_f32_;
+  Buf feats_stage_, out_stage_;
+  int cap_rows_ = 0, cap_b_ = 0;
+  std::map<std::vector<int32_t>, std::shared_ptr<Plan>> plan_cache_;
+  bool prof_on_ = false;
+  std::vector<std::string> prof_labels_;
+  std::vector<std::vector<hipEvent_t>> prof_runs_;
+  void ProfMark(hipStream_t s, std::vector<hipEvent_t>* run);
+};
+
+struct Engine::Plan {
+  int B = 0, b_pad = 0, rows = 0, src_rows = 0;
+  std::vector<int32_t> src_off;  // [B+1]
+  void* d_tables = nullptr;      // one device allocation holding all tables below
+  const int32_t* d_src_off = nullptr;
+  const int32_t* d_dev_off = nullptr;
+  const int32_t* d_grp_utt = nullptr;
+  const int8_t* d_grp_range = nullptr;
+  const int32_t* d_utt_grp0 = nullptr;
+  const int32_t* d_utt_grp1 = nullptr;
+  const int32_t* d_utt_count = nullptr;
+  ~Plan();
+};
+
+}  // namespace xv

@@ -1,0 +1,123 @@
+// Chunk loop + weighted average.  See extractor.h.
+#include "extractor.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <sstream>
+
+namespace xv {
+
+bool PlanChunks(int utt, int num_rows, int chunk_size, int min_chunk_size, bool pad_input, int min_net_frames,
+                std::vector<Chunk>* out, std::string* why) {
+  if (num_rows == 0) {
+    *why = "Zero-length utterance";
+    return false;
+  }
+  int this_chunk = chunk_size;
+  if (!pad_input && num_rows < min_chunk_size) {
+    std::ostringstream m;
+    m << "Minimum chunk size of " << min_chunk_size << " is greater than the number of rows in utterance";
+    *why = m.str();
+    return false;
+  } else if (num_rows < chunk_size) {
+    this_chunk = num_rows;
+  } else if (chunk_size <= 0) {
+    this_chunk = num_rows;
+  }
+  const int num_chunks = (int)ceil(num_rows / (double)this_chunk);
+  const size_t before = out->size();
+  for (int ci = 0; ci < num_chunks; ++ci) {
+    const int len = std::min(this_chunk, num_rows - ci * this_chunk);
+    if (!pad_input && len < min_chunk_size) continue;  // short tail: skipped, carries no weight
+    Chunk c;
+    c.utt = utt;
+    c.start = ci * this_chunk;
+    c.len = len;
+    c.left_pad = c.right_pad = 0;
+    if (pad_input && len < min_chunk_size) {
+      c.left_pad = (min_chunk_size - len) / 2;
+      c.right_pad = min_chunk_size - len - c.left_pad;
+    }
+    if (c.len + c.left_pad + c.right_pad < min_net_frames) {
+      std::ostringstream m;
+      m << "chunk of " << (c.len + c.left_pad + c.right_pad) << " frames is shorter than the network context ("
+        << min_net_frames << " frames needed)";
+      *why = m.str();
+      out->resize(before);
+      return false;
+    }
+    out->push_back(c);
+  }
+  if (out->size() == before) {
+    *why = "no chunk of the utterance is long enough";
+    return false;
+  }
+  return true;
+}
+
+void ExtractUtterances(Engine* eng, const ExtractOptions& opt, const float* feats, const int32_t* row_offsets, int n_utts,
+                       float* out, int32_t* ok, std::vector<std::string>* why) {
+  const int D = eng->info().input_dim, E = eng->info().output_dim;
+  std::vector<Chunk> chunks;
+  if (why) why->assign(n_utts, std::string());
+  for (int u = 0; u < n_utts; ++u) {
+    std::string reason;
+    ok[u] = PlanChunks(u, row_offsets[u + 1] - row_offsets[u], opt.chunk_size, opt.min_chunk_size, opt.pad_input,
+                       eng->info().min_frames, &chunks, &reason)
+                ? 1
+                : 0;
+    if (!ok[u] && why) (*why)[u] = reason;
+  }
+  std::vector<float> tot(n_utts, 0.f);
+  for (int u = 0; u < n_utts; ++u)
+    if (ok[u]) memset(out + (size_t)u * E, 0, (size_t)E * 4);
+
+  std::vector<float> pack;
+  std::vector<int32_t> offs;
+  std::vector<float> emb;
+  size_t i = 0;
+  while (i < chunks.size()) {
+    // assemble one batch of chunks
+    size_t j = i;
+    long rows = 0;
+    while (j < chunks.size() && (j == i || (rows + chunks[j].len + chunks[j].left_pad + chunks[j].right_pad <= opt.max_batch_rows &&
+                                            (int)(j - i) < opt.max_batch_chunks))) {
+      rows += chunks[j].len + chunks[j].left_pad + chunks[j].right_pad;
+      ++j;
+    }
+    const int B = (int)(j - i);
+    pack.resize((size_t)rows * D);
+    offs.assign(1, 0);
+    size_t r = 0;
+    for (size_t k = i; k < j; ++k) {
+      const Chunk& c = chunks[k];
+      const float* src = feats + ((size_t)row_offsets[c.utt] + c.start) * D;
+      for (int p = 0; p < c.left_pad; ++p, ++r) memcpy(&pack[r * D], src, (size_t)D * 4);
+      memcpy(&pack[r * D], src, (size_t)c.len * D * 4);
+      r += c.len;
+      for (int p = 0; p < c.right_pad; ++p, ++r) memcpy(&pack[r * D], src + (size_t)(c.len - 1) * D, (size_t)D * 4);
+      offs.push_back((int32_t)r);
+    }
+    emb.resize((size_t)B * E);
+    eng->ForwardHost(pack.data(), offs.data(), B, emb.data());
+    // xvector_avg.AddVec(len, xvector) in fp32, like the reference binary
+    for (size_t k = i; k < j; ++k) {
+      const Chunk& c = chunks[k];
+      float* dst = out + (size_t)c.utt * E;
+      const float* e = &emb[(k - i) * E];
+      const float w = (float)c.len;
+      for (int d = 0; d < E; ++d) dst[d] += w * e[d];
+      tot[c.utt] += w;
+    }
+    i = j;
+  }
+  for (int u = 0; u < n_utts; ++u)
+    if (ok[u]) {
+      const float s = 1.0f / tot[u];
+      float* dst = out + (size_t)u * E;
+      for (int d = 0; d < E; ++d) dst[d] *= s;
+    }
+}
+
+}  // namespace xv

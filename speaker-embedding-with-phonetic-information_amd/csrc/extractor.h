@@ -1,0 +1,40 @@
+// The per-utterance loop of nnet3-xvector-compute: chunking, edge padding of short chunks, batched
+// forward passes and the length-weighted average (the parameters come
+// from egs/sre/v2/local/nnet3/xvector/run_xvector_new.sh:83,88 and extract_xvectors_new.sh:62-68).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace xv {
+
+struct Chunk {
+  int utt;       // index of the utterance in the call
+  int start;     // first source row inside the utterance
+  int len;       // frames taken from the utterance (= the averaging weight)
+  int left_pad;  // copies of the first row put in front (pad_input)
+  int right_pad; // copies of the last row appended
+};
+
+// Chunk list of one utterance of `num_rows` frames.  Returns false (with a reason) when Kaldi would
+// count the utterance as failed.  `min_net_frames` is the network's own minimum (left+right context+1).
+bool PlanChunks(int utt, int num_rows, int chunk_size, int min_chunk_size, bool pad_input, int min_net_frames,
+                std::vector<Chunk>* out, std::string* why);
+
+struct ExtractOptions {
+  int chunk_size = -1;
+  int min_chunk_size = 100;
+  bool pad_input = true;
+  int max_batch_rows = 1 << 17;   // rows of (padded) chunks per forward pass
+  int max_batch_chunks = 4096;
+};
+
+// feats: packed host rows; utterance u = rows row_offsets[u] .. row_offsets[u+1]-1.
+// out[u*output_dim ..] receives the embedding when ok[u] == 1; why[u] (optional) gets the failure reason.
+void ExtractUtterances(Engine* eng, const ExtractOptions& opt, const float* feats, const int32_t* row_offsets, int n_utts,
+                       float* out, int32_t* ok, std::vector<std::string>* why);
+
+}  // namespace xv

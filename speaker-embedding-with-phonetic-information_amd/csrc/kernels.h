@@ -1,0 +1,118 @@
+// Device-kernel interface of the MI355X (gfx950) x-vector / c-vector extractor.
+//
+// Everything here is plain C++ (no torch, no HIP types beyond hipStream_t) so that the
+// engine (engine.cc) and the kernel unit-test entry points in the C ABI can share it.
+//
+// Data layout in HBM ("flat packed frames"):
+//   * every frame-level activation is a pair of 16-bit planes  hi[rows][ld], lo[rows][ld]
+//     (bf16 hi + bf16 residual in the split-precision mode, a single bf16/fp16 plane in
+//     the single-pass modes); rows are the frames of ALL utterances of the batch packed
+//     back to back, each utterance starting on a 16-row boundary;
+//   * a spliced affine layer  z[t] = W . concat_j y_src_j[t + off_j] + b  (SURVEY.md B.7;
+//     reference graphs: egs/sre/v2/local/nnet3/xvector/run_xvector_new.sh:95-99) is a
+//     GEMM whose K axis is the concatenation of "segments": segment j reads rows shifted
+//     by off_j of plane pair src_j.  No spliced matrix is ever materialised.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xv {
+
+constexpr int kBM = 128;      // rows (frames) per workgroup tile
+constexpr int kBN = 128;      // output columns per workgroup tile
+constexpr int kBK = 32;       // K elements per pipeline step (one 16x16x32 MFMA deep)
+constexpr int kMaxSeg = 8;    // K segments (Append() terms) per layer
+constexpr int kRowAlign = 16; // every utterance starts on a multiple of this many rows
+
+enum Precision : int {
+  kPrecBf16x3 = 0,  // split bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate (parity mode)
+  kPrecBf16 = 1,    // single-pass bf16 MFMA
+  kPrecFp16 = 2,    // single-pass fp16 MFMA
+};
+
+enum Epilogue : int {
+  kEpiAct = 0,    // bias -> ReLU? -> BatchNorm? -> split to 16-bit planes
+  kEpiF32 = 1,    // bias -> ReLU? -> BatchNorm? -> fp32 rows (embedding / raw affine output)
+  kEpiStats = 2,  // bias -> ReLU? -> BatchNorm? -> per-16-row partial (sum, sum of squares)
+  kEpiLogSoftmaxPartial = 3,  // reserved
+};
+
+struct Seg {
+  const uint16_t* hi;  // plane pointer at logical row 0 (halo rows live at negative indices)
+  const uint16_t* lo;  // may be null in single-pass modes
+  int ld;              // leading dimension in elements
+  int row_shift;       // time offset of this Append() term
+  int ksteps;          // K length of the segment / kBK
+  int pad_;
+};
+
+struct GemmArgs {
+  Seg seg[kMaxSeg];
+  int nseg;
+  int total_ksteps;
+  const uint16_t* w_hi;  // [n_pad][ldw] row-major (Kaldi <LinearParams> orientation)
+  const uint16_t* w_lo;
+  int ldw;
+  int m_tiles;           // rows / kBM
+  int n_tiles;           // n_pad / kBN
+  int relu;
+  int bn;
+  const float* bias;     // [n_pad]
+  const float* scale;    // [n_pad] test-mode BatchNorm scale
+  const float* offset;   // [n_pad] test-mode BatchNorm offset
+  // kEpiAct
+  uint16_t* out_hi;
+  uint16_t* out_lo;
+  int ldo;
+  // kEpiF32
+  float* out_f32;
+  int ldf;
+  int m_valid;           // rows >= m_valid are not stored (kEpiF32 only)
+  // kEpiStats
+  float* partial;        // [rows/16][2][ldp]
+  int ldp;
+  const int8_t* grp_range;  // [rows/16][2] first/last(exclusive) valid row inside the 16-row group
+};
+
+// Launches the spliced-affine GEMM. Returns hipSuccess or the launch error.
+hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipStream_t s);
+
+// fp32 packed features [src rows][dim] -> 16-bit planes [dev rows][ld] (zero padded columns,
+// zero rows for alignment padding).  grp_utt[g] = utterance of 16-row group g or -1.
+struct PrepArgs {
+  const float* feats;       // packed rows as handed over by the caller
+  const int32_t* src_off;   // [B+1] row offsets into feats
+  const int32_t* dev_off;   // [B]   first device row of each utterance (multiple of 16)
+  const int32_t* grp_utt;   // [rows/16]
+  int rows;                 // device rows (multiple of kBM)
+  int dim;                  // feature dimension (e.g. 23)
+  int ld;                   // plane leading dimension (multiple of kBK)
+  uint16_t* out_hi;
+  uint16_t* out_lo;
+};
+hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s);
+
+// Statistics pooling finalise (mean, stddev with variance floor), SURVEY.md B.7:
+//   mu = S/n ; sigma = sqrt(max(Q/n - mu^2, floor)) ; out row b = [mu | sigma] as planes.
+struct PoolArgs {
+  const float* partial;     // [rows/16][2][ldp]
+  int ldp;
+  const int32_t* utt_grp0;  // [B] first 16-row group of the utterance
+  const int32_t* utt_grp1;  // [B] one past its last group
+  const int32_t* utt_count; // [B] number of pooled frames
+  int B;
+  int dim;                  // pooled layer dimension (e.g. 1500)
+  float var_floor;
+  uint16_t* out_hi;         // [B_pad][ld]
+  uint16_t* out_lo;
+  int ld;
+};
+hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s);
+
+// 16-bit helpers shared by host packing code (round-to-nearest-even, like v_cvt_pk_bf16_f32).
+uint16_t host_f32_to_bf16(float x);
+float host_bf16_to_f32(uint16_t h);
+uint16_t host_f32_to_f16(float x);
+float host_f16_to_f32(uint16_t h);
+
+}  // namespace xv

@@ -1,0 +1,489 @@
+// Hand-written gfx950 (CDNA4 / MI355X) kernels for the x-vector / c-vector forward pass.
+//
+// What replaces what (the reference runs these through Kaldi's nnet3 on CPU; the arithmetic
+// is upstream Kaldi):
+//   tdnn_gemm_kernel   <- Descriptor Append(Offset(..)) gather + NaturalGradientAffineComponent
+//                         ::Propagate + RectifiedLinearComponent + BatchNormComponent(test mode)
+//                         [+ StatisticsExtractionComponent in the kEpiStats epilogue]
+//                         graphs: egs/sre/v2/local/nnet3/xvector/run_xvector_new.sh:95-99
+//   pool_finalise      <- StatisticsPoolingComponent (mean+stddev(0:1:1:10000), run_xvector_new.sh:106)
+//   prep_input         <- the host->"CuMatrix" copy of one chunk of features
+//
+// Kernel design:
+//   * 128x128x32 workgroup tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 fragments;
+//   * both operands are K-contiguous ([rows][K] activations, [N][K] weights), staged with
+//     global_load_lds_dwordx4 straight into LDS (no VGPR round trip), double buffered, one
+//     workgroup barrier per K step;
+//   * LDS rows are 64 B; the 16-byte chunk index is XOR-swizzled with the row so that every
+//     ds_read_b128 lane group touches 16 distinct 16-B slots.  Because LDS-DMA writes are
+//     lane-linear the swizzle is applied to the per-lane *global source* address;
+//   * the splice (Append of time offsets) is a row shift of the activation tile per K segment;
+//   * split-bf16 (hi, lo planes) gives fp32-grade products from three bf16 MFMAs;
+//   * kEpiAct / kEpiF32 feed the weight tile as the MFMA *A* operand, with the weight rows of a
+//     wave permuted at load time, so each lane ends up owning 16 contiguous output columns of
+//     one frame (32-byte stores per plane); kEpiStats feeds activations as A so the 16-row
+//     reduction is 3 in-register adds + 2 cross-lane adds.
+#include "kernels.h"
+
+#include <string.h>
+
+namespace xv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define XV_AS1 __attribute__((address_space(1)))
+#define XV_AS3 __attribute__((address_space(3)))
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  // 16 bytes per lane, LDS destination = wave-uniform base + lane*16
+  __builtin_amdgcn_global_load_lds((const XV_AS1 void*)g, (XV_AS3 void*)l, 16, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+  if constexpr (F16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ uint16_t to16(float x) {
+  if constexpr (F16) {
+    _Float16 h = (_Float16)x;
+    return __builtin_bit_cast(uint16_t, h);
+  } else {
+    __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(uint16_t, h);
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ float from16(uint16_t u) {
+  if constexpr (F16) {
+    return (float)__builtin_bit_cast(_Float16, u);
+  } else {
+    return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+  }
+}
+
+// swap bit fields [5:4] and [3:2] of a 6-bit index (an involution)
+__device__ __forceinline__ int swap_fields(int x) {
+  return ((x & 0x30) >> 2) | ((x & 0x0c) << 2) | (x & 3);
+}
+
+constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
+
+template <int PREC, int EPI>
+__global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
+  constexpr bool SPLIT = (PREC == kPrecBf16x3);
+  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SWAP = (EPI != kEpiStats);  // weight tile is the MFMA A operand
+  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int STAGE = kTileBytes * 2 * NPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave & 1;
+  const int wave_n = wave >> 1;
+
+  // XCD-aware tile order: block b lands on XCD b%8 (observed dispatch); the column tiles of one
+  // row tile are consecutive on the same XCD so the activation rows are re-read from its L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int slot = bid >> 3;
+  const int nt = slot % a.n_tiles;
+  const int mt = (slot / a.n_tiles) * 8 + xcd;
+  if (mt >= a.m_tiles) return;
+  const int m0 = mt * kBM;
+  const int n0 = nt * kBN;
+
+  // ---- per-lane staging geometry -------------------------------------------------------
+  // one global_load_lds_dwordx4 per wave = 16 LDS rows x 64 B; lane l -> row l>>2, phys chunk l&3
+  const int ld_row = lane >> 2;
+  const int ld_chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);  // logical 16-B chunk fetched
+  const int c0 = wave * 2;                                           // this wave's two 16-row chunks
+
+  const uint16_t* wp_hi[2];
+  const uint16_t* wp_lo[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rho = (c0 + u) * 16 + ld_row;  // LDS row inside the 128-row weight tile
+    const int wrow = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
+    const long off = (long)(n0 + wrow) * a.ldw + ld_chunk * 8;
+    wp_hi[u] = a.w_hi + off;
+    wp_lo[u] = SPLIT ? a.w_lo + off : nullptr;
+  }
+
+  // activation-side staging pointers of the current K segment (one Append() term); they are
+  // re-derived only when the K loop crosses into the next segment.
+  const uint16_t* xp_hi[2];
+  const uint16_t* xp_lo[2];
+  int seg_left = 0;  // K steps left in the current segment (wave uniform)
+  int ld_seg = 0;
+  auto open_seg = [&](int j) {
+    const Seg& sg = a.seg[j];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long off = (long)(m0 + (c0 + u) * 16 + ld_row + sg.row_shift) * sg.ld + ld_chunk * 8;
+      xp_hi[u] = sg.hi + off;
+      xp_lo[u] = SPLIT ? sg.lo + off : nullptr;
+    }
+    seg_left = sg.ksteps;
+  };
+  open_seg(0);
+
+  auto stage_loads = [&](int stage) {
+    char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = c0 + u;
+      glds16(xp_hi[u], st + c * 1024);
+      if constexpr (SPLIT) glds16(xp_lo[u], st + kTileBytes + c * 1024);
+      glds16(wp_hi[u], st + NPL * kTileBytes + c * 1024);
+      if constexpr (SPLIT) glds16(wp_lo[u], st + (NPL + 1) * kTileBytes + c * 1024);
+      xp_hi[u] += kBK;
+      wp_hi[u] += kBK;
+      if constexpr (SPLIT) {
+        xp_lo[u] += kBK;
+        wp_lo[u] += kBK;
+      }
+    }
+    if (--seg_left == 0 && ld_seg + 1 < a.nseg) open_seg(++ld_seg);
+  };
+
+  // ---- per-lane fragment read geometry ---------------------------------------------------
+  const int fr_i = lane & 15;
+  const int fr_g = lane >> 4;
+  const int fr_chunk = fr_g ^ ((4 - (fr_i >> 2)) & 3);
+  const int x_rd = (wave_m * 64 + fr_i) * 64 + fr_chunk * 16;                     // + f*1024
+  const int w_rd = NPL * kTileBytes + (wave_n * 64 + fr_i) * 64 + fr_chunk * 16;  // + f*1024
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int S = a.total_ksteps;
+  stage_loads(0);
+  __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and orders the LDS writes
+
+  for (int s = 0; s < S; ++s) {
+    const char* st = smem + (s & 1) * STAGE;
+    s16x8 xh[4], xl[4], wh[4], wl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      xh[f] = *(const s16x8*)(st + x_rd + f * 1024);
+      wh[f] = *(const s16x8*)(st + w_rd + f * 1024);
+      if constexpr (SPLIT) {
+        xl[f] = *(const s16x8*)(st + x_rd + kTileBytes + f * 1024);
+        wl[f] = *(const s16x8*)(st + w_rd + kTileBytes + f * 1024);
+      }
+    }
+    // stage the next K step into the other buffer: every wave finished reading it before the
+    // barrier that ended the previous iteration.
+    if (s + 1 < S) stage_loads((s + 1) & 1);
+
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (SWAP) {
+          if constexpr (SPLIT) {
+            acc[p][q] = mfma16<F16>(wl[p], xh[q], acc[p][q]);
+            acc[p][q] = mfma16<F16>(wh[p], xl[q], acc[p][q]);
+          }
+          acc[p][q] = mfma16<F16>(wh[p], xh[q], acc[p][q]);
+        } else {
+          if constexpr (SPLIT) {
+            acc[p][q] = mfma16<F16>(xl[p], wh[q], acc[p][q]);
+            acc[p][q] = mfma16<F16>(xh[p], wl[q], acc[p][q]);
+          }
+          acc[p][q] = mfma16<F16>(xh[p], wh[q], acc[p][q]);
+        }
+      }
+    }
+    // keep the MFMAs above the wait: they are register-only and hipcc would otherwise sink them
+    // below the barrier, serialising the LDS-DMA flight with the matrix work.
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with this one
+  }
+
+  // ---- epilogues ---------------------------------------------------------------------------
+  if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
+    // lane owns frames q*16 + fr_i (q = 0..3) x 16 contiguous columns ncol + p*4 + r
+    const int ncol = n0 + wave_n * 64 + fr_g * 16;
+    float bs[16], sc[16], of[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4 b4 = *(const f32x4*)(a.bias + ncol + v * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[v * 4 + r] = b4[r];
+    }
+    if (a.bn) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 s4 = *(const f32x4*)(a.scale + ncol + v * 4);
+        const f32x4 o4 = *(const f32x4*)(a.offset + ncol + v * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[v * 4 + r] = s4[r];
+          of[v * 4 + r] = o4[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        sc[v] = 1.f;
+        of[v] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + wave_m * 64 + q * 16 + fr_i;
+      float y[16];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float z = acc[p][q][r] + bs[p * 4 + r];
+          if (a.relu) z = fmaxf(z, 0.f);
+          if (a.bn) z = z * sc[p * 4 + r] + of[p * 4 + r];
+          y[p * 4 + r] = z;
+        }
+      if constexpr (EPI == kEpiF32) {
+        if (row < a.m_valid) {
+          float* dst = a.out_f32 + (long)row * a.ldf + ncol;
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            *(f32x4*)(dst + v * 4) = f32x4{y[v * 4], y[v * 4 + 1], y[v * 4 + 2], y[v * 4 + 3]};
+        }
+      } else {
+        unsigned int hw[8], lw[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const uint16_t h0 = to16<F16>(y[2 * v]);
+          const uint16_t h1 = to16<F16>(y[2 * v + 1]);
+          hw[v] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+          if constexpr (SPLIT) {
+            const uint16_t l0 = to16<F16>(y[2 * v] - from16<F16>(h0));
+            const uint16_t l1 = to16<F16>(y[2 * v + 1] - from16<F16>(h1));
+            lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+          }
+        }
+        uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
+        *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+        *(u32x4*)(dh + 8) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+        if constexpr (SPLIT) {
+          uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
+          *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+          *(u32x4*)(dl + 8) = u32x4{lw[4], lw[5], lw[6], lw[7]};
+        }
+      }
+    }
+  } else {
+    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = n0 + wave_n * 64 + q * 16 + fr_i;
+      const float b = a.bias[col];
+      const float sc = a.bn ? a.scale[col] : 1.f;
+      const float of = a.bn ? a.offset[col] : 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int grp = (m0 + wave_m * 64 + p * 16) >> 4;
+        const int first = a.grp_range[2 * grp];
+        const int last = a.grp_range[2 * grp + 1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float z = acc[p][q][r] + b;
+          if (a.relu) z = fmaxf(z, 0.f);
+          if (a.bn) z = z * sc + of;
+          const int rr = fr_g * 4 + r;
+          const bool ok = (rr >= first) && (rr < last);
+          s1 += ok ? z : 0.f;
+          s2 += ok ? z * z : 0.f;
+        }
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        float* dst = a.partial + (long)grp * 2 * a.ldp + col;
+        if (fr_g == 0) dst[0] = s1;
+        if (fr_g == 1) dst[a.ldp] = s2;
+      }
+    }
+  }
+}
+
+template <int PREC, int EPI>
+static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+  constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
+  constexpr int lds = kTileBytes * 2 * NPL * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int mt8 = (a.m_tiles + 7) / 8 * 8;
+  dim3 grid(mt8 * a.n_tiles), block(256);
+  hipLaunchKernelGGL((tdnn_gemm_kernel<PREC, EPI>), grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
+template <int PREC>
+static hipError_t launch_prec(const GemmArgs& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case kEpiAct: return launch_one<PREC, kEpiAct>(a, s);
+    case kEpiF32: return launch_one<PREC, kEpiF32>(a, s);
+    case kEpiStats: return launch_one<PREC, kEpiStats>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipStream_t s) {
+  if (a.nseg < 1 || a.nseg > kMaxSeg || a.m_tiles < 1 || a.n_tiles < 1) return hipErrorInvalidValue;
+  switch (precision) {
+    case kPrecBf16x3: return launch_prec<kPrecBf16x3>(a, epilogue, s);
+    case kPrecBf16: return launch_prec<kPrecBf16>(a, epilogue, s);
+    case kPrecFp16: return launch_prec<kPrecFp16>(a, epilogue, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep_input: packed fp32 feature rows -> aligned 16-bit planes.  One thread = 8 columns of a row.
+template <int PREC>
+__global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
+  constexpr bool SPLIT = (PREC == kPrecBf16x3);
+  constexpr bool F16 = (PREC == kPrecFp16);
+  const int per_row = a.ld >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.rows * per_row;
+  if (idx >= total) return;
+  const int row = (int)(idx / per_row);
+  const int c8 = (int)(idx - (long)row * per_row) * 8;
+  const int u = a.grp_utt[row >> 4];
+  const float* src = nullptr;
+  if (u >= 0) {
+    const int t = row - a.dev_off[u];
+    const int len = a.src_off[u + 1] - a.src_off[u];
+    if (t < len) src = a.feats + (long)(a.src_off[u] + t) * a.dim;
+  }
+  unsigned int hw[4], lw[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    float x0 = 0.f, x1 = 0.f;
+    const int c = c8 + 2 * v;
+    if (src) {
+      if (c < a.dim) x0 = src[c];
+      if (c + 1 < a.dim) x1 = src[c + 1];
+    }
+    const uint16_t h0 = to16<F16>(x0), h1 = to16<F16>(x1);
+    hw[v] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+    if constexpr (SPLIT) {
+      const uint16_t l0 = to16<F16>(x0 - from16<F16>(h0));
+      const uint16_t l1 = to16<F16>(x1 - from16<F16>(h1));
+      lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+    }
+  }
+  *(u32x4*)(a.out_hi + (long)row * a.ld + c8) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+  if constexpr (SPLIT) *(u32x4*)(a.out_lo + (long)row * a.ld + c8) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+}
+
+hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s) {
+  const long total = (long)a.rows * (a.ld >> 3);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  switch (precision) {
+    case kPrecBf16x3: hipLaunchKernelGGL(prep_input_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
+    case kPrecBf16: hipLaunchKernelGGL(prep_input_kernel<kPrecBf16>, grid, block, 0, s, a); break;
+    case kPrecFp16: hipLaunchKernelGGL(prep_input_kernel<kPrecFp16>, grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// pool_finalise: fixed-order reduction of the 16-row partials of one utterance (the order depends
+// only on the position inside the utterance, so results do not depend on batch composition).
+template <int PREC>
+__global__ __launch_bounds__(256) void pool_finalise_kernel(const PoolArgs a) {
+  constexpr bool SPLIT = (PREC == kPrecBf16x3);
+  constexpr bool F16 = (PREC == kPrecFp16);
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= a.dim) return;
+  const int g0 = a.utt_grp0[b], g1 = a.utt_grp1[b];
+  double s1 = 0.0, s2 = 0.0;
+  for (int g = g0; g < g1; ++g) {
+    const float* p = a.partial + (long)g * 2 * a.ldp + col;
+    s1 += (double)p[0];
+    s2 += (double)p[a.ldp];
+  }
+  const double n = (double)a.utt_count[b];
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < (double)a.var_floor) var = (double)a.var_floor;
+  const float mu = (float)mean;
+  const float sd = (float)sqrt(var);
+  const long base = (long)b * a.ld;
+  const uint16_t mh = to16<F16>(mu), sh = to16<F16>(sd);
+  a.out_hi[base + col] = mh;
+  a.out_hi[base + a.dim + col] = sh;
+  if constexpr (SPLIT) {
+    a.out_lo[base + col] = to16<F16>(mu - from16<F16>(mh));
+    a.out_lo[base + a.dim + col] = to16<F16>(sd - from16<F16>(sh));
+  }
+}
+
+hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s) {
+  dim3 grid((a.dim + 255) / 256, a.B), block(256);
+  switch (precision) {
+    case kPrecBf16x3: hipLaunchKernelGGL(pool_finalise_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
+    case kPrecBf16: hipLaunchKernelGGL(pool_finalise_kernel<kPrecBf16>, grid, block, 0, s, a); break;
+    case kPrecFp16: hipLaunchKernelGGL(pool_finalise_kernel<kPrecFp16>, grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+uint16_t host_f32_to_bf16(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float host_bf16_to_f32(uint16_t h) {
+  uint32_t u = ((uint32_t)h) << 16;
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
+uint16_t host_f32_to_f16(float x) {
+  _Float16 h = (_Float16)x;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+float host_f16_to_f32(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
+
+}  // namespace xv

@@ -1,0 +1,740 @@
+// kio - Kaldi table / object I/O without Kaldi.  See kio.h for what it replaces and why.
+#include "kio.h"
+
+#include <ctype.h>
+#include <errno.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/wait.h>
+
+#include <algorithm>
+
+namespace xv {
+
+static std::string Trim(const std::string& s) {
+  size_t a = 0, b = s.size();
+  while (a < b && isspace((unsigned char)s[a])) ++a;
+  while (b > a && isspace((unsigned char)s[b - 1])) --b;
+  return s.substr(a, b - a);
+}
+
+// ------------------------------------------------------------------------------------- Input
+Input::~Input() {
+  try {
+    Close();
+  } catch (...) {
+  }
+}
+
+void Input::Open(const std::string& rx_in) {
+  Close();
+  std::string rx = Trim(rx_in);
+  name_ = rx;
+  if (rx.empty() || rx == "-") {
+    f_ = stdin;
+    is_stdin_ = true;
+    return;
+  }
+  if (rx.back() == '|') {
+    std::string cmd = Trim(rx.substr(0, rx.size() - 1));
+    f_ = popen(cmd.c_str(), "r");
+    if (!f_) throw KioError("failed to start input pipe: " + cmd);
+    is_pipe_ = true;
+    return;
+  }
+  // "file:offset"
+  std::string path = rx;
+  long offset = -1;
+  size_t c = rx.rfind(':');
+  if (c != std::string::npos && c + 1 < rx.size()) {
+    bool digits = true;
+    for (size_t i = c + 1; i < rx.size(); ++i) digits = digits && isdigit((unsigned char)rx[i]);
+    if (digits) {
+      path = rx.substr(0, c);
+      offset = strtol(rx.c_str() + c + 1, nullptr, 10);
+    }
+  }
+  f_ = fopen(path.c_str(), "rb");
+  if (!f_) throw KioError("cannot open " + path + " for reading: " + strerror(errno));
+  if (offset > 0 && fseek(f_, offset, SEEK_SET) != 0) {
+    fclose(f_);
+    f_ = nullptr;
+    throw KioError("cannot seek to offset in " + rx);
+  }
+}
+
+void Input::Seek(long offset) {
+  if (mem_) {
+    mem_pos_ = (size_t)offset;
+    return;
+  }
+  if (!f_ || is_pipe_ || is_stdin_ || fseek(f_, offset, SEEK_SET) != 0) throw KioError("cannot seek in " + name_);
+}
+
+void Input::OpenMemory(const void* data, size_t n) {
+  Close();
+  mem_ = (const unsigned char*)data;
+  mem_n_ = n;
+  mem_pos_ = 0;
+  name_ = "<memory>";
+}
+
+int Input::Close() {
+  int status = 0;
+  if (f_) {
+    if (is_pipe_) {
+      int st = pclose(f_);
+      status = (st == -1) ? -1 : (WIFEXITED(st) ? WEXITSTATUS(st) : 128);
+    } else if (!is_stdin_) {
+      fclose(f_);
+    }
+  }
+  f_ = nullptr;
+  is_pipe_ = is_stdin_ = false;
+  mem_ = nullptr;
+  mem_n_ = mem_pos_ = 0;
+  return status;
+}
+
+int Input::Peek() {
+  if (mem_) return mem_pos_ < mem_n_ ? mem_[mem_pos_] : -1;
+  if (!f_) return -1;
+  int c = fgetc(f_);
+  if (c == EOF) return -1;
+  ungetc(c, f_);
+  return c;
+}
+
+int Input::Get() {
+  if (mem_) return mem_pos_ < mem_n_ ? mem_[mem_pos_++] : -1;
+  if (!f_) return -1;
+  int c = fgetc(f_);
+  return c == EOF ? -1 : c;
+}
+
+void Input::Read(void* dst, size_t n) {
+  if (n == 0) return;
+  if (mem_) {
+    if (mem_pos_ + n > mem_n_) throw KioError("unexpected end of data in " + name_);
+    memcpy(dst, mem_ + mem_pos_, n);
+    mem_pos_ += n;
+    return;
+  }
+  if (!f_ || fread(dst, 1, n, f_) != n) throw KioError("unexpected end of file in " + name_);
+}
+
+// ------------------------------------------------------------------------------------- Output
+Output::~Output() {
+  try {
+    Close();
+  } catch (...) {
+  }
+}
+
+void Output::Open(const std::string& wx_in) {
+  Close();
+  std::string wx = Trim(wx_in);
+  name_ = wx;
+  pos_ = 0;
+  if (wx.empty() || wx == "-") {
+    f_ = stdout;
+    is_stdout_ = true;
+    return;
+  }
+  if (wx[0] == '|') {
+    std::string cmd = Trim(wx.substr(1));
+    f_ = popen(cmd.c_str(), "w");
+    if (!f_) throw KioError("failed to start output pipe: " + cmd);
+    is_pipe_ = true;
+    return;
+  }
+  f_ = fopen(wx.c_str(), "wb");
+  if (!f_) throw KioError("cannot open " + wx + " for writing: " + strerror(errno));
+}
+
+int Output::Close() {
+  int status = 0;
+  if (f_) {
+    if (is_pipe_) {
+      int st = pclose(f_);
+      status = (st == -1) ? -1 : (WIFEXITED(st) ? WEXITSTATUS(st) : 128);
+    } else if (is_stdout_) {
+      fflush(f_);
+    } else {
+      if (fclose(f_) != 0) status = -1;
+    }
+  }
+  f_ = nullptr;
+  is_pipe_ = is_stdout_ = false;
+  return status;
+}
+
+void Output::Write(const void* src, size_t n) {
+  if (!f_) throw KioError("write to closed output " + name_);
+  if (n && fwrite(src, 1, n, f_) != n) throw KioError("write failed on " + name_);
+  pos_ += (int64_t)n;
+}
+
+void Output::Flush() {
+  if (f_) fflush(f_);
+}
+
+// ------------------------------------------------------------------------------------- objects
+bool ReadBinaryHeader(Input& in) {
+  if (in.Peek() == 0) {
+    in.Get();
+    if (in.Get() != 'B') throw KioError("bad binary header in " + in.Name());
+    return true;
+  }
+  return false;
+}
+
+void ReadToken(Input& in, bool binary, std::string* tok) {
+  (void)binary;
+  tok->clear();
+  int c;
+  while ((c = in.Peek()) >= 0 && isspace(c)) in.Get();
+  while ((c = in.Peek()) >= 0 && !isspace(c)) tok->push_back((char)in.Get());
+  if (tok->empty()) throw KioError("expected a token, got end of input in " + in.Name());
+  if (c >= 0) in.Get();  // exactly one separator is consumed (the binary payload may follow)
+}
+
+void ExpectToken(Input& in, bool binary, const char* tok) {
+  std::string t;
+  ReadToken(in, binary, &t);
+  if (t != tok) throw KioError(std::string("expected token ") + tok + ", got " + t);
+}
+
+static std::string ReadTextWord(Input& in) {
+  std::string w;
+  int c;
+  while ((c = in.Peek()) >= 0 && isspace(c)) in.Get();
+  while ((c = in.Peek()) >= 0 && !isspace(c)) w.push_back((char)in.Get());
+  if (w.empty()) throw KioError("expected a value, got end of input in " + in.Name());
+  return w;
+}
+
+int32_t ReadInt32(Input& in, bool binary) {
+  if (binary) {
+    int sz = in.Get();
+    if (sz != 4) throw KioError("expected int32 (size byte 4) in " + in.Name());
+    int32_t v;
+    in.Read(&v, 4);
+    return v;
+  }
+  std::string w = ReadTextWord(in);
+  return (int32_t)strtol(w.c_str(), nullptr, 10);
+}
+
+double ReadFloatOrDouble(Input& in, bool binary) {
+  if (binary) {
+    int sz = in.Get();
+    if (sz == 4) {
+      float v;
+      in.Read(&v, 4);
+      return v;
+    }
+    if (sz == 8) {
+      double v;
+      in.Read(&v, 8);
+      return v;
+    }
+    throw KioError("expected float/double size byte in " + in.Name());
+  }
+  std::string w = ReadTextWord(in);
+  return strtod(w.c_str(), nullptr);
+}
+
+bool ReadBool(Input& in, bool binary) {
+  int c;
+  if (!binary)
+    while ((c = in.Peek()) >= 0 && isspace(c)) in.Get();
+  c = in.Get();
+  if (c != 'T' && c != 'F') throw KioError("expected T or F in " + in.Name());
+  return c == 'T';
+}
+
+void SkipScalar(Input& in, bool binary) {
+  if (!binary) {
+    ReadTextWord(in);
+    return;
+  }
+  int c = in.Peek();
+  if (c == 'T' || c == 'F') {
+    in.Get();
+  } else if (c == 4 || c == 8) {
+    char buf[8];
+    in.Get();
+    in.Read(buf, (size_t)c);
+  } else {
+    throw KioError("cannot skip unknown field payload in " + in.Name());
+  }
+}
+
+static void ReadTextNumbers(Input& in, std::vector<float>* vals, std::vector<int>* row_ends) {
+  // grammar: ws* '[' (number | newline)* ']' ; a newline (or ']') after >=1 numbers closes a row
+  int c;
+  while ((c = in.Peek()) >= 0 && isspace(c)) in.Get();
+  if (in.Get() != '[') throw KioError("expected '[' in text matrix/vector in " + in.Name());
+  std::string tok;
+  size_t row_start = 0;
+  for (;;) {
+    c = in.Get();
+    if (c < 0) throw KioError("end of input inside text matrix in " + in.Name());
+    if (isspace(c) || c == ']') {
+      if (!tok.empty()) {
+        const char* s = tok.c_str();
+        char* end = nullptr;
+        float v = strtof(s, &end);
+        if (end == s) throw KioError("bad number '" + tok + "' in text matrix");
+        vals->push_back(v);
+        tok.clear();
+      }
+      if (c == '\n' || c == ']') {
+        if (vals->size() > row_start) {
+          row_ends->push_back((int)vals->size());
+          row_start = vals->size();
+        }
+      }
+      if (c == ']') break;
+    } else {
+      tok.push_back((char)c);
+    }
+  }
+  // rest of the line
+  while ((c = in.Peek()) >= 0 && c != '\n' && isspace(c)) in.Get();
+  if (in.Peek() == '\n') in.Get();
+}
+
+void ReadVector(Input& in, bool binary, std::vector<float>* v) {
+  v->clear();
+  if (binary) {
+    std::string tok;
+    ReadToken(in, true, &tok);
+    int32_t n = ReadInt32(in, true);
+    if (n < 0) throw KioError("negative vector dimension");
+    v->resize((size_t)n);
+    if (tok == "FV") {
+      in.Read(v->data(), (size_t)n * 4);
+    } else if (tok == "DV") {
+      std::vector<double> d((size_t)n);
+      in.Read(d.data(), (size_t)n * 8);
+      for (int i = 0; i < n; ++i) (*v)[i] = (float)d[i];
+    } else {
+      throw KioError("expected FV or DV, got " + tok);
+    }
+    return;
+  }
+  std::vector<int> ends;
+  ReadTextNumbers(in, v, &ends);
+}
+
+static inline float U16ToFloat(float mn, float range, uint16_t v) { return mn + range * 1.52590218966964e-05F * v; }
+
+static void ReadCompressed(Input& in, const std::string& tok, Matrix* m) {
+  struct {
+    float min_value, range;
+    int32_t rows, cols;
+  } h;
+  in.Read(&h, 16);
+  if (h.rows < 0 || h.cols < 0) throw KioError("bad compressed-matrix header");
+  m->rows = h.rows;
+  m->cols = h.cols;
+  m->data.assign((size_t)h.rows * h.cols, 0.f);
+  if (tok == "CM") {
+    std::vector<uint16_t> hdr((size_t)h.cols * 4);
+    in.Read(hdr.data(), hdr.size() * 2);
+    std::vector<uint8_t> bytes((size_t)h.rows * h.cols);
+    in.Read(bytes.data(), bytes.size());
+    for (int c = 0; c < h.cols; ++c) {
+      const float p0 = U16ToFloat(h.min_value, h.range, hdr[4 * c]);
+      const float p25 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 1]);
+      const float p75 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 2]);
+      const float p100 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 3]);
+      const uint8_t* col = bytes.data() + (size_t)c * h.rows;  // column-major payload
+      for (int r = 0; r < h.rows; ++r) {
+        const int v = col[r];
+        float x;
+        if (v <= 64) x = p0 + (p25 - p0) * v * (1 / 64.0f);
+        else if (v <= 192) x = p25 + (p75 - p25) * (v - 64) * (1 / 128.0f);
+        else x = p75 + (p100 - p75) * (v - 192) * (1 / 63.0f);
+        m->data[(size_t)r * h.cols + c] = x;
+      }
+    }
+  } else if (tok == "CM2") {
+    std::vector<uint16_t> d((size_t)h.rows * h.cols);
+    in.Read(d.data(), d.size() * 2);
+    const float inc = h.range * (1.0f / 65535.0f);
+    for (size_t i = 0; i < d.size(); ++i) m->data[i] = d[i] * inc + h.min_value;
+  } else {  // CM3
+    std::vector<uint8_t> d((size_t)h.rows * h.cols);
+    in.Read(d.data(), d.size());
+    const float inc = h.range * (1.0f / 255.0f);
+    for (size_t i = 0; i < d.size(); ++i) m->data[i] = d[i] * inc + h.min_value;
+  }
+}
+
+void ReadMatrix(Input& in, bool binary, Matrix* m) {
+  if (binary) {
+    std::string tok;
+    ReadToken(in, true, &tok);
+    if (tok == "CM" || tok == "CM2" || tok == "CM3") {
+      ReadCompressed(in, tok, m);
+      return;
+    }
+    if (tok != "FM" && tok != "DM") throw KioError("expected FM/DM/CM, got " + tok + " in " + in.Name());
+    int32_t r = ReadInt32(in, true), c = ReadInt32(in, true);
+    if (r < 0 || c < 0) throw KioError("negative matrix dimension");
+    m->rows = r;
+    m->cols = c;
+    m->data.resize((size_t)r * c);
+    if (tok == "FM") {
+      in.Read(m->data.data(), m->data.size() * 4);
+    } else {
+      std::vector<double> d(m->data.size());
+      in.Read(d.data(), d.size() * 8);
+      for (size_t i = 0; i < d.size(); ++i) m->data[i] = (float)d[i];
+    }
+    return;
+  }
+  std::vector<int> ends;
+  m->data.clear();
+  ReadTextNumbers(in, &m->data, &ends);
+  m->rows = (int)ends.size();
+  m->cols = m->rows ? ends[0] : 0;
+  for (int r = 0; r < m->rows; ++r)
+    if (ends[r] != (r + 1) * m->cols) throw KioError("ragged text matrix in " + in.Name());
+}
+
+void WriteToken(Output& out, bool binary, const char* tok) {
+  (void)binary;
+  out.Puts(tok);
+  out.Put(' ');
+}
+
+void WriteInt32(Output& out, bool binary, int32_t v) {
+  if (binary) {
+    out.Put((char)4);
+    out.Write(&v, 4);
+  } else {
+    char buf[32];
+    snprintf(buf, sizeof buf, "%d ", v);
+    out.Puts(buf);
+  }
+}
+
+void WriteFloat(Output& out, bool binary, float v) {
+  if (binary) {
+    out.Put((char)4);
+    out.Write(&v, 4);
+  } else {
+    char buf[48];
+    snprintf(buf, sizeof buf, "%.9g ", (double)v);
+    out.Puts(buf);
+  }
+}
+
+void WriteDouble(Output& out, bool binary, double v) {
+  if (binary) {
+    out.Put((char)8);
+    out.Write(&v, 8);
+  } else {
+    char buf[48];
+    snprintf(buf, sizeof buf, "%.17g ", v);
+    out.Puts(buf);
+  }
+}
+
+void WriteBool(Output& out, bool binary, bool v) {
+  out.Put(v ? 'T' : 'F');
+  if (!binary) out.Put(' ');
+}
+
+static void PutFloatText(Output& out, float v) {
+  char buf[48];
+  if (isnan(v)) snprintf(buf, sizeof buf, "nan");
+  else if (isinf(v)) snprintf(buf, sizeof buf, v > 0 ? "inf" : "-inf");
+  else snprintf(buf, sizeof buf, "%.9g", (double)v);
+  out.Puts(buf);
+}
+
+void WriteVector(Output& out, bool binary, const float* v, int n) {
+  if (binary) {
+    out.Puts("FV ");
+    WriteInt32(out, true, n);
+    out.Write(v, (size_t)n * 4);
+  } else {
+    out.Puts(" [ ");
+    for (int i = 0; i < n; ++i) {
+      PutFloatText(out, v[i]);
+      out.Put(' ');
+    }
+    out.Puts("]\n");
+  }
+}
+
+void WriteMatrix(Output& out, bool binary, const Matrix& m) {
+  if (binary) {
+    out.Puts("FM ");
+    WriteInt32(out, true, m.rows);
+    WriteInt32(out, true, m.cols);
+    out.Write(m.data.data(), m.data.size() * 4);
+  } else {
+    if (m.rows == 0) {
+      out.Puts(" [ ]\n");
+      return;
+    }
+    out.Puts(" [");
+    for (int r = 0; r < m.rows; ++r) {
+      out.Puts("\n  ");
+      for (int c = 0; c < m.cols; ++c) {
+        PutFloatText(out, m.data[(size_t)r * m.cols + c]);
+        out.Put(' ');
+      }
+    }
+    out.Puts("]\n");
+  }
+}
+
+// ------------------------------------------------------------------------------------- specifiers
+static void SplitFirstColon(const std::string& spec, std::string* opts, std::string* rest) {
+  size_t c = spec.find(':');
+  if (c == std::string::npos) throw KioError("invalid table specifier (no ':'): " + spec);
+  *opts = spec.substr(0, c);
+  *rest = spec.substr(c + 1);
+}
+
+static std::vector<std::string> SplitComma(const std::string& s) {
+  std::vector<std::string> out;
+  size_t a = 0;
+  for (;;) {
+    size_t b = s.find(',', a);
+    out.push_back(s.substr(a, b == std::string::npos ? std::string::npos : b - a));
+    if (b == std::string::npos) break;
+    a = b + 1;
+  }
+  return out;
+}
+
+RspecifierOptions ParseRspecifier(const std::string& rspecifier) {
+  RspecifierOptions o;
+  std::string opts, rest;
+  SplitFirstColon(Trim(rspecifier), &opts, &rest);
+  bool kind = false;
+  for (const std::string& t : SplitComma(opts)) {
+    if (t == "ark") kind = true;
+    else if (t == "scp") { kind = true; o.is_scp = true; }
+    else if (t == "s") o.sorted = true;
+    else if (t == "ns") o.sorted = false;
+    else if (t == "cs") o.called_sorted = true;
+    else if (t == "ncs") o.called_sorted = false;
+    else if (t == "p") o.permissive = true;
+    else if (t == "np") o.permissive = false;
+    else if (t == "o") o.once = true;
+    else if (t == "no") o.once = false;
+    else if (t == "bg") o.background = true;
+    else if (t == "t" || t == "b") {}  // accepted, meaningless for reading
+    else throw KioError("invalid option '" + t + "' in rspecifier " + rspecifier);
+  }
+  if (!kind) throw KioError("rspecifier must contain ark or scp: " + rspecifier);
+  o.rxfilename = Trim(rest);
+  return o;
+}
+
+WspecifierOptions ParseWspecifier(const std::string& wspecifier) {
+  WspecifierOptions o;
+  std::string opts, rest;
+  SplitFirstColon(Trim(wspecifier), &opts, &rest);
+  std::vector<std::string> order;
+  for (const std::string& t : SplitComma(opts)) {
+    if (t == "ark") { o.has_ark = true; order.push_back(t); }
+    else if (t == "scp") { o.has_scp = true; order.push_back(t); }
+    else if (t == "t") o.binary = false;
+    else if (t == "b") o.binary = true;
+    else if (t == "f") o.flush = true;
+    else if (t == "nf") o.flush = false;
+    else if (t == "p") o.permissive = true;
+    else throw KioError("invalid option '" + t + "' in wspecifier " + wspecifier);
+  }
+  if (order.empty()) throw KioError("wspecifier must contain ark and/or scp: " + wspecifier);
+  if (order.size() == 1) {
+    if (o.has_scp) throw KioError("scp-only wspecifiers are not supported (Kaldi needs ark,scp): " + wspecifier);
+    o.ark_wxfilename = Trim(rest);
+  } else {
+    size_t c = rest.find(',');
+    if (c == std::string::npos) throw KioError("ark,scp wspecifier needs two file names: " + wspecifier);
+    std::string a = Trim(rest.substr(0, c)), b = Trim(rest.substr(c + 1));
+    if (order[0] == "ark") { o.ark_wxfilename = a; o.scp_wxfilename = b; }
+    else { o.scp_wxfilename = a; o.ark_wxfilename = b; }
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------- readers
+SequentialMatrixReader::SequentialMatrixReader(const std::string& rspecifier) {
+  opts_ = ParseRspecifier(rspecifier);
+  in_.Open(opts_.rxfilename);
+}
+
+SequentialMatrixReader::~SequentialMatrixReader() {}
+
+static bool ReadKey(Input& in, std::string* key) {
+  key->clear();
+  int c;
+  while ((c = in.Peek()) >= 0 && isspace(c)) in.Get();
+  if (c < 0) return false;
+  while ((c = in.Peek()) >= 0 && !isspace(c)) key->push_back((char)in.Get());
+  if (c >= 0 && c != '\n') in.Get();  // the single separator; keep '\n' for scp line logic
+  return true;
+}
+
+bool SequentialMatrixReader::Next(std::string* key, Matrix* m, std::string* error) {
+  error->clear();
+  if (!opts_.is_scp) {
+    if (!ReadKey(in_, key)) return false;
+    bool binary = ReadBinaryHeader(in_);
+    ReadMatrix(in_, binary, m);  // a corrupt archive is fatal, as in Kaldi
+    return true;
+  }
+  // scp: "key rxfilename\n"
+  if (!ReadKey(in_, key)) return false;
+  std::string rx;
+  int c;
+  while ((c = in_.Get()) >= 0 && c != '\n') rx.push_back((char)c);
+  rx = Trim(rx);
+  if (rx.empty()) {
+    *error = "empty rxfilename for key " + *key;
+    return true;
+  }
+  try {
+    // fast path: consecutive entries of the same archive
+    std::string path = rx;
+    long offset = -1;
+    size_t colon = rx.rfind(':');
+    if (rx.back() != '|' && colon != std::string::npos && colon + 1 < rx.size() &&
+        std::all_of(rx.begin() + colon + 1, rx.end(), [](char ch) { return isdigit((unsigned char)ch); })) {
+      path = rx.substr(0, colon);
+      offset = strtol(rx.c_str() + colon + 1, nullptr, 10);
+    }
+    if (offset >= 0 && path == data_path_ && data_in_.IsOpen()) {
+      data_in_.Seek(offset);
+    } else {
+      data_in_.Open(rx);
+      data_path_ = offset >= 0 ? path : std::string();
+    }
+    bool binary = ReadBinaryHeader(data_in_);
+    ReadMatrix(data_in_, binary, m);
+    if (data_path_.empty()) data_in_.Close();
+  } catch (const KioError& e) {
+    *error = e.what();
+  }
+  return true;
+}
+
+int SequentialMatrixReader::Close() { return in_.Close(); }
+
+RandomAccessVectorReader::RandomAccessVectorReader(const std::string& rspecifier) {
+  RspecifierOptions o = ParseRspecifier(rspecifier);
+  Input in;
+  in.Open(o.rxfilename);
+  std::string key;
+  if (o.is_scp) {
+    while (ReadKey(in, &key)) {
+      std::string rx;
+      int c;
+      while ((c = in.Get()) >= 0 && c != '\n') rx.push_back((char)c);
+      Entry e;
+      e.key = key;
+      e.rx = Trim(rx);
+      entries_.push_back(std::move(e));
+    }
+  } else {
+    while (ReadKey(in, &key)) {
+      Entry e;
+      e.key = key;
+      bool binary = ReadBinaryHeader(in);
+      ReadVector(in, binary, &e.v);
+      e.loaded = true;
+      entries_.push_back(std::move(e));
+    }
+  }
+}
+
+int RandomAccessVectorReader::Find(const std::string& key) {
+  for (size_t i = 0; i < entries_.size(); ++i)
+    if (entries_[i].key == key) return (int)i;
+  return -1;
+}
+
+bool RandomAccessVectorReader::HasKey(const std::string& key) { return Find(key) >= 0; }
+
+const std::vector<float>& RandomAccessVectorReader::Value(const std::string& key) {
+  int i = Find(key);
+  if (i < 0) throw KioError("key not found in table: " + key);
+  Entry& e = entries_[i];
+  if (!e.loaded) {
+    Input in;
+    in.Open(e.rx);
+    bool binary = ReadBinaryHeader(in);
+    ReadVector(in, binary, &e.v);
+    e.loaded = true;
+  }
+  return e.v;
+}
+
+// ------------------------------------------------------------------------------------- writer
+TableWriter::TableWriter(const std::string& wspecifier) {
+  opts_ = ParseWspecifier(wspecifier);
+  ark_.Open(opts_.ark_wxfilename);
+  if (opts_.has_scp) scp_.Open(opts_.scp_wxfilename);
+}
+
+TableWriter::~TableWriter() {
+  try {
+    Close();
+  } catch (...) {
+  }
+}
+
+void TableWriter::Begin(const std::string& key) {
+  if (key.empty() || key.find_first_of(" \t\n") != std::string::npos)
+    throw KioError("invalid table key '" + key + "'");
+  ark_.Puts(key);
+  ark_.Put(' ');
+  if (opts_.has_scp) {
+    char buf[64];
+    snprintf(buf, sizeof buf, ":%lld\n", (long long)ark_.Tell());
+    pending_scp_line_ = key + " " + opts_.ark_wxfilename + buf;
+  }
+  if (opts_.binary) ark_.Write("\0B", 2);
+}
+
+void TableWriter::End() {
+  if (opts_.flush) ark_.Flush();
+  if (opts_.has_scp) {
+    // the ark bytes are flushed before the scp line becomes visible (extract_xvectors_new.sh:99 cats the scp)
+    if (!opts_.flush) ark_.Flush();
+    scp_.Puts(pending_scp_line_);
+    if (opts_.flush) scp_.Flush();
+  }
+}
+
+void TableWriter::WriteVec(const std::string& key, const float* v, int n) {
+  Begin(key);
+  WriteVector(ark_, opts_.binary, v, n);
+  End();
+}
+
+void TableWriter::WriteMat(const std::string& key, const Matrix& m) {
+  Begin(key);
+  WriteMatrix(ark_, opts_.binary, m);
+  End();
+}
+
+void TableWriter::Close() {
+  if (ark_.IsOpen()) ark_.Close();
+  if (scp_.IsOpen()) scp_.Close();
+}
+
+}  // namespace xv

@@ -1,0 +1,176 @@
+// kio - Kaldi table / object I/O without Kaldi.
+//
+// Replaces, for the one hot path, what the reference gets from Kaldi's util/ and matrix/ libraries
+// (not vendored under /root/reference): rxfilename / wxfilename handling, rspecifier / wspecifier
+// parsing, `SequentialBaseFloatMatrixReader` (features, extract_xvectors_new.sh:79) and
+// `BaseFloatVectorWriter` (ark,scp output, extract_xvectors_new.sh:93).  The text matrix form is the
+// one the reference's own Python reads/writes (egs/sre/v2/steps/libs/common.py:354-470).
+// Formats: SURVEY.md App. B.1 / B.2.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace xv {
+
+struct KioError : public std::runtime_error {
+  explicit KioError(const std::string& m) : std::runtime_error(m) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// Byte source: regular file (optionally at an offset), stdin, or the stdout of `cmd |`.
+class Input {
+ public:
+  Input() = default;
+  ~Input();
+  Input(const Input&) = delete;
+  Input& operator=(const Input&) = delete;
+  // rxfilename forms: "file", "file:123", "-", "cmd args |"
+  void Open(const std::string& rxfilename);
+  void OpenMemory(const void* data, size_t n);
+  void Seek(long offset);           // regular files / memory only
+  bool IsOpen() const { return f_ != nullptr || mem_ != nullptr; }
+  // Close; for pipes returns the child's exit status (0 otherwise).
+  int Close();
+  int Peek();                       // next byte or EOF (-1), not consumed
+  int Get();                        // next byte or EOF
+  void Read(void* dst, size_t n);   // throws on short read
+  bool Eof() { return Peek() < 0; }
+  // memory sources only: look-ahead and position (used by the model parser)
+  int PeekAt(size_t k) const { return (mem_ && mem_pos_ + k < mem_n_) ? mem_[mem_pos_ + k] : -1; }
+  size_t Tell() const { return mem_pos_; }
+  const std::string& Name() const { return name_; }
+
+ private:
+  FILE* f_ = nullptr;
+  bool is_pipe_ = false, is_stdin_ = false;
+  const unsigned char* mem_ = nullptr;
+  size_t mem_n_ = 0, mem_pos_ = 0;
+  std::string name_;
+};
+
+// Byte sink: file, stdout ("-"), or the stdin of `| cmd`.
+class Output {
+ public:
+  Output() = default;
+  ~Output();
+  Output(const Output&) = delete;
+  Output& operator=(const Output&) = delete;
+  void Open(const std::string& wxfilename);
+  bool IsOpen() const { return f_ != nullptr; }
+  int Close();
+  void Write(const void* src, size_t n);
+  void Put(char c) { Write(&c, 1); }
+  void Puts(const std::string& s) { Write(s.data(), s.size()); }
+  void Flush();
+  int64_t Tell() const { return pos_; }  // bytes written so far (offset for scp lines)
+  const std::string& Name() const { return name_; }
+
+ private:
+  FILE* f_ = nullptr;
+  bool is_pipe_ = false, is_stdout_ = false;
+  int64_t pos_ = 0;
+  std::string name_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Object-level helpers (binary = the "\0B" flavour).
+bool ReadBinaryHeader(Input& in);  // consumes "\0B" if present, returns whether it was
+void ReadToken(Input& in, bool binary, std::string* tok);
+void ExpectToken(Input& in, bool binary, const char* tok);
+int32_t ReadInt32(Input& in, bool binary);
+// float or double (binary: size byte 4 or 8), returned as double
+double ReadFloatOrDouble(Input& in, bool binary);
+bool ReadBool(Input& in, bool binary);
+// Skips one self-describing scalar (int32/float/double/bool) - used for unknown optional fields.
+void SkipScalar(Input& in, bool binary);
+
+struct Matrix {
+  int rows = 0, cols = 0;
+  std::vector<float> data;  // row-major, no padding
+  float* Row(int r) { return data.data() + (size_t)r * cols; }
+  const float* Row(int r) const { return data.data() + (size_t)r * cols; }
+};
+
+// Reads FM / DM / CM / CM2 / CM3 (binary) or " [ ... ]" (text).
+void ReadMatrix(Input& in, bool binary, Matrix* m);
+// Reads FV / DV (binary) or " [ ... ]" (text).
+void ReadVector(Input& in, bool binary, std::vector<float>* v);
+void WriteToken(Output& out, bool binary, const char* tok);
+void WriteInt32(Output& out, bool binary, int32_t v);
+void WriteFloat(Output& out, bool binary, float v);
+void WriteDouble(Output& out, bool binary, double v);
+void WriteBool(Output& out, bool binary, bool v);
+void WriteVector(Output& out, bool binary, const float* v, int n);
+void WriteMatrix(Output& out, bool binary, const Matrix& m);
+
+// ---------------------------------------------------------------------------------------------
+// Table specifiers.
+struct RspecifierOptions {
+  bool is_scp = false;
+  bool sorted = false, called_sorted = false, permissive = false, once = false, background = false;
+  std::string rxfilename;
+};
+RspecifierOptions ParseRspecifier(const std::string& rspecifier);
+
+struct WspecifierOptions {
+  bool has_ark = false, has_scp = false;
+  bool binary = true, flush = true, permissive = false;
+  std::string ark_wxfilename, scp_wxfilename;
+};
+WspecifierOptions ParseWspecifier(const std::string& wspecifier);
+
+// Sequential reader of a table of float matrices ("ark:..." or "scp:...").
+class SequentialMatrixReader {
+ public:
+  explicit SequentialMatrixReader(const std::string& rspecifier);
+  ~SequentialMatrixReader();
+  // Advances to the next entry; returns false at the end.  Per-entry problems in scp mode
+  // (unreadable file) are reported through `error` (non-empty) with key set, and reading continues.
+  bool Next(std::string* key, Matrix* m, std::string* error);
+  // Exit status of an input pipe (valid after the table is exhausted); 0 if not a pipe.
+  int Close();
+
+ private:
+  RspecifierOptions opts_;
+  Input in_;         // the ark stream, or the scp file
+  Input data_in_;    // scp mode: currently open data file
+  std::string data_path_;
+};
+
+// Random-access reader over an scp (used by the front-end for vad.scp: "scp,s,cs:...").
+// Also accepts "ark:" by loading the whole archive.
+class RandomAccessVectorReader {
+ public:
+  explicit RandomAccessVectorReader(const std::string& rspecifier);
+  bool HasKey(const std::string& key);
+  const std::vector<float>& Value(const std::string& key);
+
+ private:
+  struct Entry { std::string key, rx; std::vector<float> v; bool loaded = false; };
+  std::vector<Entry> entries_;
+  int Find(const std::string& key);
+};
+
+// Writer of a table of float vectors / matrices: "ark:", "ark,t:", "ark,scp:a,b", "scp,ark:b,a".
+class TableWriter {
+ public:
+  explicit TableWriter(const std::string& wspecifier);
+  ~TableWriter();
+  void WriteVec(const std::string& key, const float* v, int n);
+  void WriteMat(const std::string& key, const Matrix& m);
+  void Close();
+
+ private:
+  void Begin(const std::string& key);
+  void End();
+  WspecifierOptions opts_;
+  Output ark_, scp_;
+  std::string pending_scp_line_;
+};
+
+}  // namespace xv

@@ -1,0 +1,400 @@
+// nnet3-xvector-compute - drop-in command line for the binary the reference's extraction scripts call:
+//   egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:86-87,92-93
+//   egs/sre/v2/sid/nnet3/xvector/extract_xvectors.sh:80-81,86-87, extract_output_new.sh:82-83,88-89
+//
+//   nnet3-xvector-compute [options] <raw-nnet-rxfilename> <features-rspecifier> <vector-wspecifier>
+//
+// Contract honoured: Kaldi-style --name=value options, the three positional forms
+// (model through a "nnet3-copy ... |" pipe, features through an "ark:cmd | cmd |" pipe, ark,scp output),
+// per-utterance warn-and-skip, "Done N utterances, failed for M", exit 0 iff N > 0, 255 on exception.
+// The compute path is the HIP library only: there is no CPU implementation behind --use-gpu=no (the flag
+// is accepted so that unchanged recipes run; it is reported and the job still runs on the MI355X).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.h"
+#include "extractor.h"
+#include "kio.h"
+#include "nnet3_raw.h"
+#include "program.h"
+
+namespace {
+
+const char* kProg = "nnet3-xvector-compute";
+int g_verbose = 0;
+
+void LogLine(const char* level, int line, const std::string& msg) {
+  fprintf(stderr, "%s (%s[xvec-hip-0.1]:main():nnet3_xvector_compute_main.cc:%d) %s\n", level, kProg, line, msg.c_str());
+}
+#define XLOG(msg)                        \
+  do {                                   \
+    std::ostringstream _o;               \
+    _o << msg;                           \
+    LogLine("LOG", __LINE__, _o.str());  \
+  } while (0)
+#define XWARN(msg)                          \
+  do {                                      \
+    std::ostringstream _o;                  \
+    _o << msg;                              \
+    LogLine("WARNING", __LINE__, _o.str()); \
+  } while (0)
+
+const char* kUsage =
+    "Propagate features through an xvector neural network model and write the output vectors.\n"
+    "\"Xvector\" is our term for a vector or embedding which is the output of a particular type of\n"
+    "neural network architecture found in speaker recognition.  MI355X (gfx950) native build.\n"
+    "\n"
+    "Usage: nnet3-xvector-compute [options] <raw-nnet-in> <features-rspecifier> <vector-wspecifier>\n"
+    "e.g.: nnet3-xvector-compute final.raw scp:feats.scp ark:nnet_prediction.ark\n"
+    "\n"
+    "Options:\n"
+    "  --use-gpu=yes|no|optional|wait   accepted for script compatibility; compute always runs on the HIP device\n"
+    "  --chunk-size=<int>               chunk length in frames, -1 = whole utterance (default -1)\n"
+    "  --min-chunk-size=<int>           minimum chunk length (default 100)\n"
+    "  --pad-input=true|false           pad short chunks by edge replication instead of skipping (default true)\n"
+    "  --output-node=<name>             compute this node as the output (native form of nnet3-copy --nnet-config)\n"
+    "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
+    "  --precision=bf16x3|bf16|fp16     arithmetic of the MFMA GEMMs (default bf16x3: fp32-grade)\n"
+    "  --batch-frames=<int>             frames per device batch (default 131072)\n"
+    "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
+    "  --config=<file>  --verbose=<int>  --print-args=true|false  --help\n";
+
+struct Options {
+  std::string use_gpu = "no";
+  int chunk_size = -1;
+  int min_chunk_size = 100;
+  bool pad_input = true;
+  std::string output_node;
+  std::string nnet_config;
+  std::string precision = "bf16x3";
+  int batch_frames = 1 << 17;
+  int device = -1;
+  bool print_args = true;
+};
+
+bool ParseBool(const std::string& v, bool* out) {
+  if (v == "true" || v == "t" || v == "1" || v.empty()) *out = true;
+  else if (v == "false" || v == "f" || v == "0") *out = false;
+  else return false;
+  return true;
+}
+
+// returns false on a fatal option error
+bool ApplyOption(const std::string& name, const std::string& value, bool has_value, Options* o, std::string* err);
+
+bool ReadConfigFile(const std::string& path, Options* o, std::string* err) {
+  std::ifstream f(path);
+  if (!f) {
+    *err = "cannot open config file " + path;
+    return false;
+  }
+  std::string line;
+  while (std::getline(f, line)) {
+    size_t h = line.find('#');
+    if (h != std::string::npos) line = line.substr(0, h);
+    size_t a = line.find_first_not_of(" \t\r");
+    if (a == std::string::npos) continue;
+    size_t b = line.find_last_not_of(" \t\r");
+    line = line.substr(a, b - a + 1);
+    if (line.compare(0, 2, "--") != 0) {
+      *err = "bad line in config file: " + line;
+      return false;
+    }
+    size_t eq = line.find('=');
+    std::string name = line.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+    std::string val = eq == std::string::npos ? "" : line.substr(eq + 1);
+    if (!ApplyOption(name, val, eq != std::string::npos, o, err)) return false;
+  }
+  return true;
+}
+
+bool ApplyOption(const std::string& name_in, const std::string& value, bool has_value, Options* o, std::string* err) {
+  std::string name = name_in;
+  for (char& c : name)
+    if (c == '_') c = '-';
+  auto need_int = [&](int* dst) {
+    char* end = nullptr;
+    long v = strtol(value.c_str(), &end, 10);
+    if (!has_value || end == value.c_str() || *end) {
+      *err = "invalid integer for --" + name + ": '" + value + "'";
+      return false;
+    }
+    *dst = (int)v;
+    return true;
+  };
+  if (name == "use-gpu") {
+    if (value != "yes" && value != "no" && value != "optional" && value != "wait" && value != "true" && value != "false") {
+      *err = "invalid value for --use-gpu: " + value;
+      return false;
+    }
+    o->use_gpu = value;
+  } else if (name == "chunk-size") return need_int(&o->chunk_size);
+  else if (name == "min-chunk-size") return need_int(&o->min_chunk_size);
+  else if (name == "batch-frames") return need_int(&o->batch_frames);
+  else if (name == "device") return need_int(&o->device);
+  else if (name == "verbose") return need_int(&g_verbose);
+  else if (name == "pad-input") {
+    if (!ParseBool(value, &o->pad_input)) {
+      *err = "invalid boolean for --pad-input: " + value;
+      return false;
+    }
+  } else if (name == "print-args") {
+    if (!ParseBool(value, &o->print_args)) {
+      *err = "invalid boolean for --print-args: " + value;
+      return false;
+    }
+  } else if (name == "output-node") o->output_node = value;
+  else if (name == "nnet-config") o->nnet_config = value;
+  else if (name == "precision") o->precision = value;
+  else if (name == "config") return ReadConfigFile(value, o, err);
+  else {
+    // the rest of upstream's surface (compiler / optimisation / cached-compiler options) has no meaning
+    // here: accept and ignore, like the contract in SURVEY.md §8(b) asks
+    XWARN("ignoring option --" << name << (has_value ? "=" + value : ""));
+  }
+  return true;
+}
+
+struct Utt {
+  std::string key;
+  xv::Matrix feats;
+};
+struct Batch {
+  std::vector<Utt> utts;
+  bool last = false;
+};
+
+int JobIndexFromWspecifier(const std::string& w) {
+  // ".../xvector_name.<JOB>.ark" (extract_xvectors_new.sh:87,93)
+  size_t ark = w.find(".ark");
+  if (ark == std::string::npos || ark == 0) return -1;
+  size_t e = ark, b = e;
+  while (b > 0 && isdigit((unsigned char)w[b - 1])) --b;
+  if (b == e || b == 0 || w[b - 1] != '.') return -1;
+  return atoi(w.substr(b, e - b).c_str());
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    Options opt;
+    std::vector<std::string> pos;
+    std::string err;
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i];
+      if (a == "--help" || a == "-h") {
+        fputs(kUsage, stderr);
+        return 0;
+      }
+      if (a.compare(0, 2, "--") == 0 && pos.empty()) {
+        size_t eq = a.find('=');
+        std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+        std::string val = eq == std::string::npos ? "" : a.substr(eq + 1);
+        if (!ApplyOption(name, val, eq != std::string::npos, &opt, &err)) {
+          fprintf(stderr, "%s: %s\n\n%s", kProg, err.c_str(), kUsage);
+          return 1;
+        }
+      } else {
+        pos.push_back(a);
+      }
+    }
+    if (opt.print_args) {
+      std::string cmd;
+      for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        bool quote = a.find_first_of(" |;&()<>") != std::string::npos;
+        cmd += (i ? " " : "") + (quote ? "'" + a + "'" : a);
+      }
+      fprintf(stderr, "%s\n", cmd.c_str());
+    }
+    if (pos.size() != 3) {
+      fputs(kUsage, stderr);
+      return 1;
+    }
+    const std::string nnet_rx = pos[0], feat_rspec = pos[1], vec_wspec = pos[2];
+
+    int precision;
+    if (opt.precision == "bf16x3") precision = xv::kPrecBf16x3;
+    else if (opt.precision == "bf16") precision = xv::kPrecBf16;
+    else if (opt.precision == "fp16") precision = xv::kPrecFp16;
+    else {
+      fprintf(stderr, "%s: invalid --precision=%s\n", kProg, opt.precision.c_str());
+      return 1;
+    }
+    if (opt.use_gpu == "no" || opt.use_gpu == "false")
+      XWARN("--use-gpu=no requested, but this build has no CPU compute path: running on the HIP device "
+            "(the option is accepted so that unchanged recipes work)");
+
+    // ---- model ---------------------------------------------------------------------------------
+    xv::RawNnet net;
+    net.ReadFrom(nnet_rx);
+    if (!opt.nnet_config.empty()) {
+      std::ifstream f(opt.nnet_config);
+      if (!f) throw xv::KioError("cannot open --nnet-config file " + opt.nnet_config);
+      std::stringstream ss;
+      ss << f.rdbuf();
+      net.ApplyNnetConfig(ss.str());
+    }
+    if (!opt.output_node.empty()) net.ApplyNnetConfig("output-node name=output input=" + opt.output_node);
+    xv::TdnnProgram prog = xv::LowerToProgram(net, "output");
+    if (g_verbose >= 1) XLOG("lowered model:\n" << prog.Describe());
+    if (!prog.output_is_segment)
+      throw xv::KioError("the output node is frame-level; nnet3-xvector-compute expects a pooled (x-vector) output");
+
+    // ---- device --------------------------------------------------------------------------------
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw xv::EngineError("no HIP device available and this build has no CPU path");
+    int device = opt.device;
+    if (device < 0 && getenv("XVEC_DEVICE")) device = atoi(getenv("XVEC_DEVICE"));
+    if (device < 0) {
+      int job = JobIndexFromWspecifier(vec_wspec);
+      device = job > 0 ? (job - 1) % ndev : 0;
+    }
+    if (device >= ndev) device %= ndev;
+    std::vector<uint8_t> blob = xv::PackModel(prog, precision);
+    xv::Engine engine(blob.data(), blob.size(), device);
+    XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
+                   << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
+                   << opt.precision << ", " << (engine.weight_bytes() >> 20) << " MiB of packed weights");
+
+    // ---- reader thread -> bounded queue -> compute + write ----------------------------------------
+    xv::TableWriter writer(vec_wspec);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Batch> queue;
+    std::string reader_error;
+    int reader_status = 0;
+    const int D = prog.input_dim;
+    int num_fail_read = 0;
+    std::thread reader([&] {
+      try {
+        xv::SequentialMatrixReader rd(feat_rspec);
+        Batch cur;
+        long rows = 0;
+        std::string key, e;
+        xv::Matrix m;
+        auto push = [&](bool last) {
+          cur.last = last;
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return queue.size() < 2; });
+          queue.push_back(std::move(cur));
+          cur = Batch();
+          rows = 0;
+          cv.notify_all();
+        };
+        while (rd.Next(&key, &m, &e)) {
+          if (!e.empty()) {
+            XWARN("failed to read features for " << key << ": " << e);
+            ++num_fail_read;
+            continue;
+          }
+          Utt u;
+          u.key = key;
+          u.feats = std::move(m);
+          rows += u.feats.rows;
+          cur.utts.push_back(std::move(u));
+          if (rows >= opt.batch_frames || cur.utts.size() >= 4096) push(false);
+        }
+        reader_status = rd.Close();
+        push(true);
+      } catch (const std::exception& ex) {
+        std::unique_lock<std::mutex> lk(mu);
+        reader_error = ex.what();
+        Batch b;
+        b.last = true;
+        queue.push_back(std::move(b));
+        cv.notify_all();
+      }
+    });
+
+    xv::ExtractOptions eo;
+    eo.chunk_size = opt.chunk_size;
+    eo.min_chunk_size = opt.min_chunk_size;
+    eo.pad_input = opt.pad_input;
+    eo.max_batch_rows = opt.batch_frames;
+    const auto t0 = std::chrono::steady_clock::now();
+    long num_success = 0, num_fail = 0;
+    double frame_count = 0;
+    std::vector<float> packed, emb;
+    std::vector<int32_t> offs, ok;
+    std::vector<std::string> why;
+    std::string fatal;
+    for (;;) {
+      Batch b;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !queue.empty(); });
+        b = std::move(queue.front());
+        queue.pop_front();
+        cv.notify_all();
+      }
+      if (!b.utts.empty() && fatal.empty()) {
+        try {
+          offs.assign(1, 0);
+          size_t total = 0;
+          for (const Utt& u : b.utts) total += (size_t)u.feats.rows;
+          packed.resize(total * D);
+          size_t r = 0;
+          std::vector<int> idx;  // utterances that enter the device batch
+          for (size_t i = 0; i < b.utts.size(); ++i) {
+            const Utt& u = b.utts[i];
+            if (u.feats.rows > 0 && u.feats.cols != D) {
+              XWARN("feature dimension " << u.feats.cols << " of utterance " << u.key << " does not match the model's " << D);
+              ++num_fail;
+              continue;
+            }
+            if (u.feats.rows > 0) memcpy(&packed[r * D], u.feats.data.data(), (size_t)u.feats.rows * D * 4);
+            r += u.feats.rows;
+            offs.push_back((int32_t)r);
+            idx.push_back((int)i);
+          }
+          const int n = (int)idx.size();
+          emb.resize((size_t)n * prog.output_dim);
+          ok.assign(n, 0);
+          if (n) xv::ExtractUtterances(&engine, eo, packed.data(), offs.data(), n, emb.data(), ok.data(), &why);
+          for (int k = 0; k < n; ++k) {
+            const Utt& u = b.utts[idx[k]];
+            if (!ok[k]) {
+              XWARN(why[k] << ": " << u.key);
+              ++num_fail;
+              continue;
+            }
+            writer.WriteVec(u.key, &emb[(size_t)k * prog.output_dim], prog.output_dim);
+            frame_count += u.feats.rows;
+            ++num_success;
+          }
+        } catch (const std::exception& ex) {
+          fatal = ex.what();  // keep draining the queue so the reader can finish
+        }
+      }
+      if (b.last) break;
+    }
+    reader.join();
+    writer.Close();
+    if (!fatal.empty()) throw std::runtime_error(fatal);
+    if (!reader_error.empty()) throw std::runtime_error(reader_error);
+    num_fail += num_fail_read;
+    if (reader_status != 0) XWARN("feature input command exited with status " << reader_status);
+
+    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    XLOG("Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is " << (elapsed * 100.0 / std::max(frame_count, 1.0)));
+    XLOG("Done " << num_success << " utterances, failed for " << num_fail);
+    return num_success != 0 ? 0 : 1;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ERROR (%s[xvec-hip-0.1]:main()) %s\n", kProg, e.what());
+    return -1;
+  }
+}

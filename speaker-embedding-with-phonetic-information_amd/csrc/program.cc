@@ -1,0 +1,277 @@
+// Graph lowering.  See program.h.
+#include "program.h"
+
+#include <math.h>
+
+#include <algorithm>
+#include <map>
+#include <sstream>
+
+namespace xv {
+
+namespace {
+
+bool IsAffineType(const std::string& t) {
+  return t == "NaturalGradientAffineComponent" || t == "AffineComponent" || t == "FixedAffineComponent" ||
+         t == "LinearComponent" || t == "NaturalGradientRepeatedAffineComponent";
+}
+bool IsIdentityAtTest(const std::string& t) {
+  return t == "NoOpComponent" || t == "DropoutComponent" || t == "GeneralDropoutComponent";
+}
+
+struct Lowerer {
+  const RawNnet& net;
+  TdnnProgram prog;
+  std::map<std::string, int> memo;  // node name -> layer index / kSrcInput / kSrcPooled
+  std::vector<int> need_left, need_right;
+
+  explicit Lowerer(const RawNnet& n) : net(n) {}
+
+  const RawNode& Node(const std::string& name) {
+    const RawNode* n = net.FindNode(name, "component-node");
+    if (!n) n = net.FindNode(name, "input-node");
+    if (!n) throw KioError("graph refers to unknown node '" + name + "'");
+    return *n;
+  }
+  const RawComponent& Comp(const RawNode& n) {
+    const RawComponent* c = net.FindComponent(n.component);
+    if (!c) throw KioError("node '" + n.name + "' refers to unknown component '" + n.component + "'");
+    return *c;
+  }
+  std::string SingleInput(const RawNode& n) {
+    std::vector<DescTerm> t = FlattenDescriptor(n.input);
+    if (t.size() != 1 || t[0].offset != 0)
+      throw KioError("node '" + n.name + "': expected a single un-spliced input, got " + n.input);
+    return t[0].node;
+  }
+
+  static void BatchNormVectors(const RawComponent& c, int dim, std::vector<float>* scale, std::vector<float>* offset) {
+    const int block = (int)c.Get("<BlockDim>", dim);
+    const double eps = c.Get("<Epsilon>", 1e-3), rms = c.Get("<TargetRms>", 1.0);
+    if ((int)c.stats_mean.size() != block || (int)c.stats_var.size() != block || block <= 0 || dim % block != 0)
+      throw KioError("BatchNormComponent " + c.name + ": inconsistent statistics dimension");
+    scale->resize(dim);
+    offset->resize(dim);
+    for (int i = 0; i < dim; ++i) {
+      const int b = i % block;
+      // test mode: y = x*s + o, s = target_rms * (var + eps)^-1/2, o = -mean*s   
+      const float s = (float)(rms * pow((double)c.stats_var[b] + eps, -0.5));
+      (*scale)[i] = s;
+      (*offset)[i] = -c.stats_mean[b] * s;
+    }
+  }
+
+  int Materialise(const std::string& name) {
+    auto it = memo.find(name);
+    if (it != memo.end()) return it->second;
+    const RawNode* inp = net.FindNode(name, "input-node");
+    if (inp) {
+      if (prog.input_dim && prog.input_dim != inp->dim) throw KioError("more than one input node is not supported");
+      prog.input_dim = inp->dim;
+      return memo[name] = kSrcInput;
+    }
+    // walk the element-wise chain down to the affine that produces it
+    std::vector<const RawComponent*> ops_rev;
+    std::string cur = name;
+    const RawNode* affine_node = nullptr;
+    const RawComponent* affine = nullptr;
+    for (;;) {
+      const RawNode& n = Node(cur);
+      if (n.kind == "input-node") throw KioError("element-wise component applied directly to the input at '" + name + "'");
+      const RawComponent& c = Comp(n);
+      if (IsAffineType(c.type)) {
+        affine_node = &n;
+        affine = &c;
+        break;
+      }
+      if (c.type == "StatisticsPoolingComponent") {
+        if (!ops_rev.empty()) throw KioError("element-wise components directly on the pooling output are not supported");
+        LowerPooling(n, c);
+        return memo[name] = kSrcPooled;
+      }
+      if (c.type == "RectifiedLinearComponent" || c.type == "BatchNormComponent" || c.type == "LogSoftmaxComponent" ||
+          IsIdentityAtTest(c.type)) {
+        ops_rev.push_back(&c);
+        cur = SingleInput(n);
+        continue;
+      }
+      throw KioError("component type " + c.type + " (node '" + n.name + "') is outside the supported TDNN grammar");
+    }
+    AffineLayer L;
+    L.name = affine_node->name;
+    L.out_node = name;
+    if (!affine->has_linear) throw KioError("affine component " + affine->name + " has no <LinearParams>");
+    L.out_dim = affine->linear.rows;
+    L.in_dim = affine->linear.cols;
+    L.w = affine->linear.data;
+    L.bias = affine->bias;
+    if (L.bias.empty()) L.bias.assign(L.out_dim, 0.f);
+    if ((int)L.bias.size() != L.out_dim) throw KioError("affine component " + affine->name + ": bias dimension mismatch");
+    // op chain after the affine, in graph order: [BatchNorm] [ReLU] [BatchNorm] [LogSoftmax]
+    int stage = 0;
+    for (auto r = ops_rev.rbegin(); r != ops_rev.rend(); ++r) {
+      const RawComponent& c = **r;
+      if (IsIdentityAtTest(c.type)) continue;
+      if (c.type == "BatchNormComponent" && stage == 0) {
+        // BatchNorm directly on the affine output: fold (what CollapseModel does), W' = sW, b' = sb + o
+        std::vector<float> s, o;
+        BatchNormVectors(c, L.out_dim, &s, &o);
+        for (int i = 0; i < L.out_dim; ++i) {
+          for (int k = 0; k < L.in_dim; ++k) L.w[(size_t)i * L.in_dim + k] *= s[i];
+          L.bias[i] = L.bias[i] * s[i] + o[i];
+        }
+        stage = 1;
+      } else if (c.type == "RectifiedLinearComponent" && stage <= 1) {
+        L.relu = true;
+        stage = 2;
+      } else if (c.type == "BatchNormComponent" && stage == 2) {
+        L.bn = true;
+        BatchNormVectors(c, L.out_dim, &L.bn_scale, &L.bn_offset);
+        stage = 3;
+      } else if (c.type == "LogSoftmaxComponent" && stage <= 3) {
+        L.log_softmax = true;
+        stage = 4;
+      } else {
+        throw KioError("unsupported element-wise chain after '" + L.name + "' (at component " + c.name + ")");
+      }
+    }
+    // sources
+    std::vector<DescTerm> terms = FlattenDescriptor(affine_node->input);
+    int seg = 0, frm = 0, ksum = 0;
+    for (const DescTerm& t : terms) {
+      LayerSource s;
+      s.layer = Materialise(t.node);
+      s.offset = t.offset;
+      if (s.layer == kSrcInput) {
+        s.dim = prog.input_dim;
+        ++frm;
+      } else if (s.layer == kSrcPooled) {
+        s.dim = 2 * prog.pool_dim;
+        s.offset = 0;
+        ++seg;
+      } else {
+        s.dim = prog.layers[s.layer].out_dim;
+        if (prog.layers[s.layer].log_softmax) throw KioError("a log-softmax output cannot feed another layer here");
+        if (prog.layers[s.layer].segment_level) {
+          ++seg;
+          s.offset = 0;
+        } else {
+          ++frm;
+        }
+      }
+      ksum += s.dim;
+      L.src.push_back(s);
+    }
+    if (seg && frm) throw KioError("layer '" + L.name + "' mixes frame-level and pooled inputs");
+    if (ksum != L.in_dim) {
+      std::ostringstream m;
+      m << "layer '" << L.name << "': input dimension " << L.in_dim << " != sum of Append() terms " << ksum;
+      throw KioError(m.str());
+    }
+    L.segment_level = seg > 0;
+    if (!L.segment_level) {
+      for (const LayerSource& s : L.src) {
+        const int sl = s.layer == kSrcInput ? 0 : prog.layers[s.layer].left;
+        const int sr = s.layer == kSrcInput ? 0 : prog.layers[s.layer].right;
+        L.left = std::max(L.left, sl - s.offset);
+        L.right = std::max(L.right, sr + s.offset);
+      }
+    }
+    prog.layers.push_back(std::move(L));
+    return memo[name] = (int)prog.layers.size() - 1;
+  }
+
+  void LowerPooling(const RawNode& pool_node, const RawComponent& pool) {
+    if (prog.pooled_layer >= 0) throw KioError("more than one statistics-pooling node is not supported");
+    if ((int)pool.Get("<InputPeriod>", 1) != 1 || (int)pool.Get("<NumLogCountFeatures>", 0) != 0 ||
+        pool.Get("<OutputStddevs>", 1) == 0.0)
+      throw KioError("StatisticsPoolingComponent " + pool.name + ": only period 1, no log-count, stddevs is supported");
+    const RawNode& ext_node = Node(SingleInput(pool_node));
+    const RawComponent& ext = Comp(ext_node);
+    if (ext.type != "StatisticsExtractionComponent")
+      throw KioError("pooling input must be a StatisticsExtractionComponent, got " + ext.type);
+    if ((int)ext.Get("<InputPeriod>", 1) != 1 || (int)ext.Get("<OutputPeriod>", 1) != 1 ||
+        ext.Get("<IncludeVarinance>", 1) == 0.0)
+      throw KioError("StatisticsExtractionComponent " + ext.name + ": only period 1 with variance is supported");
+    const int src = Materialise(SingleInput(ext_node));
+    if (src < 0 || prog.layers[src].segment_level) throw KioError("statistics pooling must pool a frame-level layer");
+    prog.pooled_layer = src;
+    prog.pool_dim = prog.layers[src].out_dim;
+    if ((int)ext.Get("<InputDim>", prog.pool_dim) != prog.pool_dim) throw KioError("statistics extraction dimension mismatch");
+    prog.pool_left = (int)pool.Get("<LeftContext>", 0);
+    prog.pool_right = (int)pool.Get("<RightContext>", 0);
+    prog.variance_floor = (float)pool.Get("<VarianceFloor>", 1e-10);
+  }
+};
+
+}  // namespace
+
+TdnnProgram LowerToProgram(const RawNnet& net, const std::string& output_name) {
+  const RawNode* out = net.FindNode(output_name, "output-node");
+  if (!out) throw KioError("model has no output-node named '" + output_name + "'");
+  Lowerer lw(net);
+  std::vector<DescTerm> t = FlattenDescriptor(out->input);
+  if (t.size() != 1 || t[0].offset != 0) throw KioError("output-node input must be a single node: " + out->input);
+  const int ol = lw.Materialise(t[0].node);
+  if (ol < 0) throw KioError("output-node '" + output_name + "' must be fed by a component node");
+  TdnnProgram p = std::move(lw.prog);
+  p.output_name = output_name;
+  p.output_layer = ol;
+  p.output_dim = p.layers[ol].out_dim;
+  p.output_is_segment = p.layers[ol].segment_level;
+  const int ctx_layer = p.output_is_segment ? p.pooled_layer : ol;
+  p.left_context = p.layers[ctx_layer].left;
+  p.right_context = p.layers[ctx_layer].right;
+  p.min_frames = p.left_context + p.right_context + 1;
+  for (const AffineLayer& L : p.layers)
+    for (const LayerSource& s : L.src)
+      if (std::abs(s.offset) > 15) throw KioError("time offsets beyond +-15 frames are not supported (layer " + L.name + ")");
+  return p;
+}
+
+double TdnnProgram::Macs(int T) const {
+  // frames each frame-level layer actually needs (backward from the pooled / output layer)
+  const int n = (int)layers.size();
+  std::vector<int> nl(n, 1 << 30), nr(n, 1 << 30);
+  const int root = output_is_segment ? pooled_layer : output_layer;
+  nl[root] = layers[root].left;
+  nr[root] = layers[root].right;
+  for (int i = n - 1; i >= 0; --i) {
+    if (layers[i].segment_level || nl[i] == (1 << 30)) continue;
+    for (const LayerSource& s : layers[i].src)
+      if (s.layer >= 0) {
+        nl[s.layer] = std::min(nl[s.layer], nl[i] + s.offset);
+        nr[s.layer] = std::min(nr[s.layer], nr[i] - s.offset);
+      }
+  }
+  double macs = 0;
+  for (int i = 0; i < n; ++i) {
+    const AffineLayer& L = layers[i];
+    if (L.segment_level) macs += (double)L.in_dim * L.out_dim;
+    else if (nl[i] != (1 << 30)) macs += (double)L.in_dim * L.out_dim * std::max(0, T - nl[i] - nr[i]);
+  }
+  return macs;
+}
+
+std::string TdnnProgram::Describe() const {
+  std::ostringstream o;
+  o << "input dim " << input_dim << ", " << layers.size() << " layers, context " << left_context << "/"
+    << right_context << ", output " << output_dim << (output_is_segment ? " per chunk" : " per frame") << "\n";
+  for (size_t i = 0; i < layers.size(); ++i) {
+    const AffineLayer& L = layers[i];
+    o << "  [" << i << "] " << L.out_node << "  " << L.in_dim << "->" << L.out_dim << (L.relu ? " relu" : "")
+      << (L.bn ? " bn" : "") << (L.log_softmax ? " log-softmax" : "") << (L.segment_level ? " (segment)" : "") << "  src:";
+    for (const LayerSource& s : L.src) {
+      if (s.layer == kSrcInput) o << " input";
+      else if (s.layer == kSrcPooled) o << " pooled";
+      else o << " [" << s.layer << "]";
+      if (s.offset) o << "@" << s.offset;
+    }
+    if (!L.segment_level) o << "  ctx " << L.left << "/" << L.right;
+    if ((int)i == pooled_layer) o << "  -> mean+stddev pooling";
+    o << "\n";
+  }
+  return o.str();
+}
+
+}  // namespace xv

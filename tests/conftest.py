@@ -1,0 +1,18 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run on the GPU box with -m gpu")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import importlib
+    return importlib.import_module("speaker-embedding-with-phonetic-information_amd")
