@@ -80,6 +80,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no Python/CPU fallback for the HIP path)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (+ HSA runtime).  If torch is
+    # going to be used in this process (tests, bench: device tensors / streams / torch.distributed) it must load
+    # its runtime BEFORE libxvec_hip.so resolves the same soname, otherwise torch ends up on a mixed runtime and
+    # reports "No HIP GPUs are available".  The command-line tools never load torch and use /opt/rocm's runtime.
+    if os.environ.get("XVEC_NO_TORCH_PRELOAD", "") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     L.xv_last_error.restype = ctypes.c_char_p
     L.xv_version.restype = ctypes.c_char_p
@@ -211,8 +220,7 @@ class Context:
 
     def profile_report(self):
         """[(label, launches, total_ms)] of everything recorded since the last call."""
-        n = lib().xv_ctx_profile_report(self._h, None, 0)
-        buf = ctypes.create_string_buffer(max(n, 1) + 65536)
+        buf = ctypes.create_string_buffer(1 << 18)   # one call: reading the report resets it
         lib().xv_ctx_profile_report(self._h, buf, len(buf))
         rows = []
         for line in buf.value.decode().splitlines():

@@ -433,12 +433,18 @@ __global__ __launch_bounds__(256) void pool_finalise_kernel(const PoolArgs a) {
     s1 += (double)p[0];
     s2 += (double)p[a.ldp];
   }
-  const double n = (double)a.utt_count[b];
-  const double mean = s1 / n;
-  double var = s2 / n - mean * mean;
-  if (var < (double)a.var_floor) var = (double)a.var_floor;
-  const float mu = (float)mean;
-  const float sd = (float)sqrt(var);
+  // Totals are accumulated in double (fixed order), then the moments are formed with the SAME fp32
+  // rounding sequence as Kaldi's StatisticsPoolingComponent (scale by 1/n, x2 - mean*mean with separately
+  // rounded product, floor, pow 0.5): degenerate columns (one pooled frame, constant activations) then
+  // cancel exactly like the reference instead of leaving ~1e-7*x^2 of rounding noise above the 1e-10 floor.
+  const float n = (float)a.utt_count[b];
+  const float mu = __fdiv_rn((float)s1, n);
+  const float ex2 = __fdiv_rn((float)s2, n);
+  float m2 = mu * mu;
+  asm volatile("" : "+v"(m2));  // keep the product separately rounded: hipcc would contract it into an FMA
+  float var = ex2 - m2;
+  var = fmaxf(var, a.var_floor);
+  const float sd = __fsqrt_rn(var);
   const long base = (long)b * a.ld;
   const uint16_t mh = to16<F16>(mu), sh = to16<F16>(sd);
   a.out_hi[base + col] = mh;
