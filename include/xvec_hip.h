@@ -111,6 +111,23 @@ xv_status xv_extract_utterances(xv_ctx* c, const float* feats, const int32_t* ro
                                 int32_t chunk_size, int32_t min_chunk_size, int32_t pad_input, float* out,
                                 int32_t* ok);
 
+/* The whole job of one nnet3-xvector-compute process on an existing context: read a Kaldi feature table
+ * (rspecifier, e.g. "scp:feats.scp" or "ark:apply-cmvn-sliding ... |"), extract, write a vector table
+ * (wspecifier, e.g. "ark,scp:xvector.1.ark,xvector.1.scp").  Per-utterance problems are warnings on stderr and
+ * are counted in *num_failed; the call fails only for fatal I/O or device errors.  batch_frames <= 0: default.
+ * This is what a multi-GPU launcher calls per rank after the weights were broadcast. */
+xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char* vector_wspecifier, int32_t chunk_size,
+                           int32_t min_chunk_size, int32_t pad_input, int32_t batch_frames, int64_t* num_done,
+                           int64_t* num_failed);
+
+/* Host-only: the chunk list nnet3-xvector-compute would build for one utterance of num_rows frames
+ * (SURVEY.md App. B.5).  Arrays of capacity `cap` receive per chunk: first source row, frames taken (= averaging
+ * weight), copies of the first / last frame added by --pad-input.  *n_chunks = number of chunks; returns XV_ERR_ARG
+ * with the reason in xv_last_error() when the utterance counts as failed (0 frames, too short). */
+xv_status xv_plan_chunks(int32_t num_rows, int32_t chunk_size, int32_t min_chunk_size, int32_t pad_input,
+                         int32_t min_net_frames, int32_t cap, int32_t* start, int32_t* len, int32_t* left_pad,
+                         int32_t* right_pad, int32_t* n_chunks);
+
 /* ---- multi-GPU: weights read once, broadcast over RCCL/xGMI --------------------------
  * Single-process form: creates one context per device in devices[0..n) from the model, reading/packing once
  * on the host, uploading to devices[0] and broadcasting device-to-device with one ncclBroadcast. */

@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "xv_model_macs", "xv_model_describe", "xv_model_pack", "xv_ctx_create", "xv_ctx_create_from_blob", "xv_ctx_free",
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances",
-    "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
+    "xv_extract_table", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
 ]
 
 _lib = None
@@ -228,6 +228,19 @@ class Context:
             rows.append((label, int(calls), float(ms)))
         return rows
 
+    def extract_table(self, feature_rspecifier, vector_wspecifier, chunk_size=-1, min_chunk_size=100, pad_input=True,
+                      batch_frames=0):
+        """What one nnet3-xvector-compute process does, on this context.  Returns (done, failed)."""
+        L = lib()
+        L.xv_extract_table.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_int64)]
+        done, failed = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(L.xv_extract_table(self._h, feature_rspecifier.encode(), vector_wspecifier.encode(), chunk_size,
+                                  min_chunk_size, 1 if pad_input else 0, batch_frames, ctypes.byref(done),
+                                  ctypes.byref(failed)))
+        return done.value, failed.value
+
     def extract_utterances(self, feats, row_offsets, chunk_size=-1, min_chunk_size=100, pad_input=True):
         import numpy as np
         feats = np.ascontiguousarray(feats, dtype=np.float32)
@@ -238,6 +251,19 @@ class Context:
         _check(lib().xv_extract_utterances(self._h, feats.ctypes.data, offs.ctypes.data, n, chunk_size, min_chunk_size,
                                            1 if pad_input else 0, out.ctypes.data, ok.ctypes.data))
         return out, ok.astype(bool)
+
+
+def plan_chunks(num_rows, chunk_size, min_chunk_size, pad_input, min_net_frames, cap=4096):
+    """[(start, len, left_pad, right_pad)] or None when the utterance counts as failed (host logic, no GPU)."""
+    arr = [(ctypes.c_int32 * cap)() for _ in range(4)]
+    n = ctypes.c_int32(0)
+    L = lib()
+    L.xv_plan_chunks.argtypes = [ctypes.c_int32] * 6 + [ctypes.c_void_p] * 4 + [ctypes.POINTER(ctypes.c_int32)]
+    st = L.xv_plan_chunks(num_rows, chunk_size, min_chunk_size, 1 if pad_input else 0, min_net_frames, cap,
+                          arr[0], arr[1], arr[2], arr[3], ctypes.byref(n))
+    if st != XV_OK:
+        return None
+    return [(arr[0][i], arr[1][i], arr[2][i], arr[3][i]) for i in range(n.value)]
 
 
 def kernel_tdnn_gemm(desc):

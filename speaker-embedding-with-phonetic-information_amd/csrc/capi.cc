@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "nnet3_raw.h"
 #include "program.h"
+#include "table_extract.h"
 
 struct xv_model {
   xv::TdnnProgram prog;
@@ -234,6 +235,47 @@ xv_status xv_extract_utterances(xv_ctx* c, const float* feats, const int32_t* ro
     opt.min_chunk_size = min_chunk_size;
     opt.pad_input = pad_input != 0;
     xv::ExtractUtterances(c->eng.get(), opt, feats, row_offsets, n_utts, out, ok, nullptr);
+    return XV_OK;
+  });
+}
+
+xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char* vector_wspecifier, int32_t chunk_size,
+                           int32_t min_chunk_size, int32_t pad_input, int32_t batch_frames, int64_t* num_done,
+                           int64_t* num_failed) {
+  if (!c || !feature_rspecifier || !vector_wspecifier) return Fail(XV_ERR_ARG, "xv_extract_table: null argument");
+  return Guard([&] {
+    xv::ExtractOptions opt;
+    opt.chunk_size = chunk_size;
+    opt.min_chunk_size = min_chunk_size;
+    opt.pad_input = pad_input != 0;
+    if (batch_frames > 0) opt.max_batch_rows = batch_frames;
+    xv::TableExtractResult r = xv::RunTableExtraction(
+        c->eng.get(), opt, feature_rspecifier, vector_wspecifier, [](const char* level, const std::string& m) {
+          fprintf(stderr, "%s (xvec_hip:xv_extract_table) %s\n", level, m.c_str());
+        });
+    if (num_done) *num_done = r.num_success;
+    if (num_failed) *num_failed = r.num_fail;
+    return XV_OK;
+  });
+}
+
+xv_status xv_plan_chunks(int32_t num_rows, int32_t chunk_size, int32_t min_chunk_size, int32_t pad_input,
+                         int32_t min_net_frames, int32_t cap, int32_t* start, int32_t* len, int32_t* left_pad,
+                         int32_t* right_pad, int32_t* n_chunks) {
+  if (!n_chunks) return Fail(XV_ERR_ARG, "xv_plan_chunks: null argument");
+  return Guard([&] {
+    std::vector<xv::Chunk> ch;
+    std::string why;
+    *n_chunks = 0;
+    if (!xv::PlanChunks(0, num_rows, chunk_size, min_chunk_size, pad_input != 0, min_net_frames, &ch, &why))
+      return Fail(XV_ERR_ARG, why);
+    *n_chunks = (int32_t)ch.size();
+    for (int i = 0; i < (int)ch.size() && i < cap; ++i) {
+      if (start) start[i] = ch[i].start;
+      if (len) len[i] = ch[i].len;
+      if (left_pad) left_pad[i] = ch[i].left_pad;
+      if (right_pad) right_pad[i] = ch[i].right_pad;
+    }
     return XV_OK;
   });
 }

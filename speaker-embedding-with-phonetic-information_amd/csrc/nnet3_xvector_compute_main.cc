@@ -28,6 +28,7 @@
 #include "kio.h"
 #include "nnet3_raw.h"
 #include "program.h"
+#include "table_extract.h"
 
 namespace {
 
@@ -166,15 +167,6 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   return true;
 }
 
-struct Utt {
-  std::string key;
-  xv::Matrix feats;
-};
-struct Batch {
-  std::vector<Utt> utts;
-  bool last = false;
-};
-
 int JobIndexFromWspecifier(const std::string& w) {
   // ".../xvector_name.<JOB>.ark" (extract_xvectors_new.sh:87,93)
   size_t ark = w.find(".ark");
@@ -270,129 +262,19 @@ int main(int argc, char** argv) {
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
                    << opt.precision << ", " << (engine.weight_bytes() >> 20) << " MiB of packed weights");
 
-    // ---- reader thread -> bounded queue -> compute + write ----------------------------------------
-    xv::TableWriter writer(vec_wspec);
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Batch> queue;
-    std::string reader_error;
-    int reader_status = 0;
-    const int D = prog.input_dim;
-    int num_fail_read = 0;
-    std::thread reader([&] {
-      try {
-        xv::SequentialMatrixReader rd(feat_rspec);
-        Batch cur;
-        long rows = 0;
-        std::string key, e;
-        xv::Matrix m;
-        auto push = [&](bool last) {
-          cur.last = last;
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return queue.size() < 2; });
-          queue.push_back(std::move(cur));
-          cur = Batch();
-          rows = 0;
-          cv.notify_all();
-        };
-        while (rd.Next(&key, &m, &e)) {
-          if (!e.empty()) {
-            XWARN("failed to read features for " << key << ": " << e);
-            ++num_fail_read;
-            continue;
-          }
-          Utt u;
-          u.key = key;
-          u.feats = std::move(m);
-          rows += u.feats.rows;
-          cur.utts.push_back(std::move(u));
-          if (rows >= opt.batch_frames || cur.utts.size() >= 4096) push(false);
-        }
-        reader_status = rd.Close();
-        push(true);
-      } catch (const std::exception& ex) {
-        std::unique_lock<std::mutex> lk(mu);
-        reader_error = ex.what();
-        Batch b;
-        b.last = true;
-        queue.push_back(std::move(b));
-        cv.notify_all();
-      }
-    });
-
+    // ---- the utterance loop (reader thread -> batches -> device -> ark,scp writer) ---------------------------
     xv::ExtractOptions eo;
     eo.chunk_size = opt.chunk_size;
     eo.min_chunk_size = opt.min_chunk_size;
     eo.pad_input = opt.pad_input;
     eo.max_batch_rows = opt.batch_frames;
-    const auto t0 = std::chrono::steady_clock::now();
-    long num_success = 0, num_fail = 0;
-    double frame_count = 0;
-    std::vector<float> packed, emb;
-    std::vector<int32_t> offs, ok;
-    std::vector<std::string> why;
-    std::string fatal;
-    for (;;) {
-      Batch b;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !queue.empty(); });
-        b = std::move(queue.front());
-        queue.pop_front();
-        cv.notify_all();
-      }
-      if (!b.utts.empty() && fatal.empty()) {
-        try {
-          offs.assign(1, 0);
-          size_t total = 0;
-          for (const Utt& u : b.utts) total += (size_t)u.feats.rows;
-          packed.resize(total * D);
-          size_t r = 0;
-          std::vector<int> idx;  // utterances that enter the device batch
-          for (size_t i = 0; i < b.utts.size(); ++i) {
-            const Utt& u = b.utts[i];
-            if (u.feats.rows > 0 && u.feats.cols != D) {
-              XWARN("feature dimension " << u.feats.cols << " of utterance " << u.key << " does not match the model's " << D);
-              ++num_fail;
-              continue;
-            }
-            if (u.feats.rows > 0) memcpy(&packed[r * D], u.feats.data.data(), (size_t)u.feats.rows * D * 4);
-            r += u.feats.rows;
-            offs.push_back((int32_t)r);
-            idx.push_back((int)i);
-          }
-          const int n = (int)idx.size();
-          emb.resize((size_t)n * prog.output_dim);
-          ok.assign(n, 0);
-          if (n) xv::ExtractUtterances(&engine, eo, packed.data(), offs.data(), n, emb.data(), ok.data(), &why);
-          for (int k = 0; k < n; ++k) {
-            const Utt& u = b.utts[idx[k]];
-            if (!ok[k]) {
-              XWARN(why[k] << ": " << u.key);
-              ++num_fail;
-              continue;
-            }
-            writer.WriteVec(u.key, &emb[(size_t)k * prog.output_dim], prog.output_dim);
-            frame_count += u.feats.rows;
-            ++num_success;
-          }
-        } catch (const std::exception& ex) {
-          fatal = ex.what();  // keep draining the queue so the reader can finish
-        }
-      }
-      if (b.last) break;
-    }
-    reader.join();
-    writer.Close();
-    if (!fatal.empty()) throw std::runtime_error(fatal);
-    if (!reader_error.empty()) throw std::runtime_error(reader_error);
-    num_fail += num_fail_read;
-    if (reader_status != 0) XWARN("feature input command exited with status " << reader_status);
-
-    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    XLOG("Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is " << (elapsed * 100.0 / std::max(frame_count, 1.0)));
-    XLOG("Done " << num_success << " utterances, failed for " << num_fail);
-    return num_success != 0 ? 0 : 1;
+    xv::TableExtractResult res = xv::RunTableExtraction(
+        &engine, eo, feat_rspec, vec_wspec, [](const char* level, const std::string& m) { LogLine(level, 0, m); });
+    if (res.reader_status != 0) XWARN("feature input command exited with status " << res.reader_status);
+    XLOG("Time taken " << res.seconds << "s: real-time factor assuming 100 frames/sec is "
+                       << (res.seconds * 100.0 / std::max(res.frames, 1.0)));
+    XLOG("Done " << res.num_success << " utterances, failed for " << res.num_fail);
+    return res.num_success != 0 ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "ERROR (%s[xvec-hip-0.1]:main()) %s\n", kProg, e.what());
     return -1;

@@ -1,0 +1,148 @@
+// Table-driven extraction loop.  See table_extract.h.
+#include "table_extract.h"
+
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <sstream>
+#include <thread>
+#include <vector>
+
+#include "kio.h"
+
+namespace xv {
+
+namespace {
+struct Utt {
+  std::string key;
+  Matrix feats;
+};
+struct Batch {
+  std::vector<Utt> utts;
+  bool last = false;
+};
+}  // namespace
+
+TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec,
+                                      const std::string& vec_wspec, const LogFn& log) {
+  TableExtractResult res;
+  const int D = engine->info().input_dim, E = engine->info().output_dim;
+  TableWriter writer(vec_wspec);
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Batch> queue;
+  std::string reader_error;
+  long num_fail_read = 0;
+  auto warn = [&](const std::string& m) { log("WARNING", m); };
+
+  std::thread reader([&] {
+    try {
+      SequentialMatrixReader rd(feat_rspec);
+      Batch cur;
+      long rows = 0;
+      std::string key, e;
+      Matrix m;
+      auto push = [&](bool last) {
+        cur.last = last;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return queue.size() < 2; });
+        queue.push_back(std::move(cur));
+        cur = Batch();
+        rows = 0;
+        cv.notify_all();
+      };
+      while (rd.Next(&key, &m, &e)) {
+        if (!e.empty()) {
+          warn("failed to read features for " + key + ": " + e);
+          ++num_fail_read;
+          continue;
+        }
+        Utt u;
+        u.key = key;
+        u.feats = std::move(m);
+        rows += u.feats.rows;
+        cur.utts.push_back(std::move(u));
+        if (rows >= opt.max_batch_rows || (int)cur.utts.size() >= opt.max_batch_chunks) push(false);
+      }
+      res.reader_status = rd.Close();
+      push(true);
+    } catch (const std::exception& ex) {
+      std::unique_lock<std::mutex> lk(mu);
+      reader_error = ex.what();
+      Batch b;
+      b.last = true;
+      queue.push_back(std::move(b));
+      cv.notify_all();
+    }
+  });
+
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<float> packed, emb;
+  std::vector<int32_t> offs, ok;
+  std::vector<std::string> why;
+  std::string fatal;
+  for (;;) {
+    Batch b;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !queue.empty(); });
+      b = std::move(queue.front());
+      queue.pop_front();
+      cv.notify_all();
+    }
+    if (!b.utts.empty() && fatal.empty()) {
+      try {
+        offs.assign(1, 0);
+        size_t total = 0;
+        for (const Utt& u : b.utts) total += (size_t)u.feats.rows;
+        packed.resize(total * D);
+        size_t r = 0;
+        std::vector<int> idx;  // utterances that enter the device batch
+        for (size_t i = 0; i < b.utts.size(); ++i) {
+          const Utt& u = b.utts[i];
+          if (u.feats.rows > 0 && u.feats.cols != D) {
+            std::ostringstream m;
+            m << "feature dimension " << u.feats.cols << " of utterance " << u.key << " does not match the model's " << D;
+            warn(m.str());
+            ++res.num_fail;
+            continue;
+          }
+          if (u.feats.rows > 0) memcpy(&packed[r * D], u.feats.data.data(), (size_t)u.feats.rows * D * 4);
+          r += u.feats.rows;
+          offs.push_back((int32_t)r);
+          idx.push_back((int)i);
+        }
+        const int n = (int)idx.size();
+        emb.resize((size_t)n * E);
+        ok.assign(n, 0);
+        if (n) ExtractUtterances(engine, opt, packed.data(), offs.data(), n, emb.data(), ok.data(), &why);
+        for (int k = 0; k < n; ++k) {
+          const Utt& u = b.utts[idx[k]];
+          if (!ok[k]) {
+            warn(why[k] + ": " + u.key);
+            ++res.num_fail;
+            continue;
+          }
+          writer.WriteVec(u.key, &emb[(size_t)k * E], E);
+          res.frames += u.feats.rows;
+          ++res.num_success;
+        }
+      } catch (const std::exception& ex) {
+        fatal = ex.what();  // keep draining the queue so the reader can finish
+      }
+    }
+    if (b.last) break;
+  }
+  reader.join();
+  writer.Close();
+  if (!fatal.empty()) throw std::runtime_error(fatal);
+  if (!reader_error.empty()) throw KioError(reader_error);
+  res.num_fail += num_fail_read;
+  res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return res;
+}
+
+}  // namespace xv

@@ -1,0 +1,28 @@
+// The utterance loop of nnet3-xvector-compute over Kaldi tables: feature rspecifier in, vector wspecifier out
+// (SURVEY.md §3.1 HOT LOOP 1; call sites egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:86-93).
+// A reader thread parses the feature table into batches while the GPU works on the previous batch; failures
+// are per utterance (warn + count), never fatal for the shard.
+#pragma once
+#include <functional>
+#include <string>
+
+#include "engine.h"
+#include "extractor.h"
+
+namespace xv {
+
+struct TableExtractResult {
+  long num_success = 0;
+  long num_fail = 0;
+  double frames = 0;        // frames of the utterances written
+  double seconds = 0;       // wall time of the loop
+  int reader_status = 0;    // exit status of the feature input pipe (0 if not a pipe)
+};
+
+// level: "LOG" or "WARNING"
+typedef std::function<void(const char* level, const std::string& msg)> LogFn;
+
+TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
+                                      const std::string& vector_wspecifier, const LogFn& log);
+
+}  // namespace xv

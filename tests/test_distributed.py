@@ -1,0 +1,64 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the multi-GPU launcher in --dry-run mode (sharding + the single
+weight broadcast; no device), plus the sharding rule against utils/split_scp.pl:208-217 semantics.  The GPU
+flavour (nccl = RCCL) runs the same code with --backend nccl."""
+import importlib
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import helpers as H
+
+D = importlib.import_module(H.PKG_NAME + ".dist_extract")
+
+
+def test_shard_bounds_matches_split_scp_rule():
+    # split_scp.pl: first (n % nj) jobs get floor(n/nj)+1 lines, the rest floor(n/nj); contiguous, in order
+    for n in (0, 1, 7, 8, 9, 100, 1000003):
+        for w in (1, 2, 3, 8, 32):
+            b = D.shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert sizes == [n // w + (1 if r < n % w else 0) for r in range(w)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world_size_2_gloo_dry_run(tmp_path):
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    keys = ["utt%04d" % i for i in range(11)]
+    (tmp_path / "feats.scp").write_text("".join("%s /data/feats.ark:%d\n" % (k, 100 * i) for i, k in enumerate(keys)))
+    out = tmp_path / "out"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(H.ROOT, H.PKG_NAME, "dist_extract.py"),
+           "--nnet", str(tmp_path / "final.raw"), "--output-node", "tdnn6.affine",
+           "--feats-scp", str(tmp_path / "feats.scp"), "--out-dir", str(out), "--name", "t",
+           "--backend", "gloo", "--dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout
+    ranks = dict((int(m.group(1)), m.groups()) for m in
+                 re.finditer(r"rank (\d)/2: blob (\d+) bytes sha1 (\w+), utterances \[(\d+), (\d+)\)", r.stdout))
+    assert set(ranks) == {0, 1}, r.stdout
+    # both ranks hold the identical packed weights after the ONE broadcast, and they are the image rank 0 packed
+    P = H.pkg()
+    import hashlib
+    want = hashlib.sha1(P.Model(raw=net.to_bytes(True), nnet_config=line).pack()).hexdigest()
+    assert ranks[0][2] == ranks[1][2] == want
+    # utterance shards: contiguous, disjoint, complete, 6 + 5
+    assert (ranks[0][3], ranks[0][4], ranks[1][3], ranks[1][4]) == ("0", "6", "6", "11")
+    merged = [l.split()[0] for l in open(out / "xvector_t.scp")]
+    assert merged == keys
+    assert [l.split()[0] for l in open(out / "feats_t.1.scp")] == keys[:6]
+    assert [l.split()[0] for l in open(out / "feats_t.2.scp")] == keys[6:]

@@ -1,0 +1,205 @@
+"""CPU tests of the product's host side through the C ABI and the command-line tools (no compute calls: there is
+no GPU here, and the product has no CPU compute path - which is itself asserted)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+P = H.pkg()
+BIN = os.path.join(H.ROOT, H.PKG_NAME, "bin")
+HEADER = os.path.join(H.ROOT, "include", "xvec_hip.h")
+
+
+def test_library_exports_every_declared_symbol():
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(xv_[a-z_0-9]+)\s*\(", text))
+    declared -= {"xv_status"}
+    lib = ctypes.CDLL(P.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(P.ABI_SYMBOLS), declared ^ set(P.ABI_SYMBOLS)
+    P.lib().xv_version.restype = ctypes.c_char_p
+    assert b"xvec_hip" in P.lib().xv_version()
+
+
+EXPECT = {  # topology -> (left, right, min_frames, layers in the cone, MACs at T=400)  
+    "v2_xvector": (7, 7, 15, 6, 1034332160),
+    "v3_multitask": (7, 7, 15, 6, 1034332160),
+    "v4_cvector": (13, 7, 21, 11, 2701279832),
+    "v5_cvector": (13, 7, 21, 11, 2701279832),
+    "pa_wo_pretrain": (13, 7, 21, 11, 2701279832),
+}
+
+
+@pytest.mark.parametrize("topology", sorted(EXPECT))
+@pytest.mark.parametrize("binary", [True, False])
+def test_model_load_and_lowering(topology, binary):
+    net, line = H.synth_model(topology)
+    if not binary and topology not in ("v2_xvector", "v5_cvector"):
+        pytest.skip("text flavour covered on two topologies")
+    m = P.Model(raw=net.to_bytes(binary), nnet_config=line)
+    i = m.info
+    left, right, minf, nl, macs = EXPECT[topology]
+    assert (i.input_dim, i.output_dim, i.left_context, i.right_context, i.min_frames, i.num_layers, i.output_is_segment) == \
+        (23, 512, left, right, minf, nl, 1)
+    assert m.macs(400) == macs
+    d = m.describe()
+    assert "mean+stddev pooling" in d and "(segment)" in d
+    # the oracle's independent context derivation agrees
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    assert H.xo.GraphEvaluator(n2, np.float32).context() == (left, right)
+
+
+def test_binary_and_text_models_pack_identically():
+    net, line = H.synth_model("v2_xvector")
+    a = P.Model(raw=net.to_bytes(True), nnet_config=line).pack(P.PREC_BF16X3)
+    b = P.Model(raw=net.to_bytes(False), nnet_config=line).pack(P.PREC_BF16X3)
+    assert a == b
+    c = P.Model(raw=net.to_bytes(True), nnet_config=line).pack(P.PREC_FP16)
+    assert len(c) < len(a)        # single plane instead of hi+lo
+
+
+def test_packed_weights_are_the_split_of_the_fp32_weights():
+    net = H.nm.synthesize(H.tiny_config(), seed=3)
+    blob = P.Model(raw=net.to_bytes(True)).pack(P.PREC_BF16X3)
+    # hi + lo reproduces every weight to ~2^-17 relative: find tdnn2's [12 x 24] block by value search
+    w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12x12, K padded to 32, N to 128
+    u16 = np.frombuffer(blob, dtype=np.uint16)
+    f = (u16.astype(np.uint32) << 16).view(np.float32)
+    hi = (np.frombuffer(w.tobytes(), np.uint32) + 0x7FFF + ((np.frombuffer(w.tobytes(), np.uint32) >> 16) & 1)) >> 16
+    first_row = hi[:12].astype(np.uint16)
+    pos = [i for i in range(len(u16) - 12) if np.array_equal(u16[i:i + 12], first_row)]
+    assert pos, "bf16(hi) image of tdnn4's first weight row not found in the blob"
+    p = pos[0]
+    n_pad, k_pad = 128, 32
+    hi_plane = f[p:p + n_pad * k_pad].reshape(n_pad, k_pad)
+    # the lo plane follows the hi plane (256-byte aligned; 128*32*2 bytes is already aligned)
+    lo_plane = f[p + n_pad * k_pad:p + 2 * n_pad * k_pad].reshape(n_pad, k_pad)
+    rec = hi_plane[:12, :12].astype(np.float64) + lo_plane[:12, :12].astype(np.float64)
+    assert np.abs(rec - w).max() <= 2.0 ** -16 * np.abs(w).max()
+    assert not hi_plane[12:, :].any() and not hi_plane[:, 12:].any()            # zero padding of rows / K
+
+
+def test_output_node_selection_and_nnet_config():
+    net, _ = H.synth_model("v2_xvector")
+    raw = net.to_bytes(True)
+    a = P.Model(raw=raw, nnet_config="output-node name=output input=tdnn6.affine")
+    assert "tdnn6.affine" in a.describe() and a.info.num_layers == 6
+    b = P.Model(raw=raw, nnet_config="output-node name=output input=tdnn7.affine")    # the "other" embedding layer
+    assert b.info.num_layers == 7 and "tdnn6.batchnorm" in b.describe()
+    # the unedited model's output is the speaker log-softmax: pooled, 5139 classes
+    c = P.Model(raw=raw)
+    assert c.info.output_dim == 5139 and "log-softmax" in c.describe()
+
+
+@pytest.mark.parametrize("mutation,needle", [
+    (lambda s: s.replace("Append(Offset(tdnn1.batchnorm, -2)", "Sum(Offset(tdnn1.batchnorm, -2)"), "not supported"),
+    (lambda s: s.replace("input=tdnn3.batchnorm", "input=nosuchnode"), "unknown node"),
+    (lambda s: s.replace("output-node name=output", "output-node name=out2"), "no output-node"),
+])
+def test_unsupported_graphs_fail_with_model_error(mutation, needle):
+    net = H.nm.synthesize(H.tiny_config(), seed=1)
+    net.config_lines = [mutation(l) for l in net.config_lines]
+    with pytest.raises(P.XvError) as e:
+        P.Model(raw=net.to_bytes(True))
+    assert e.value.status in (1, 2) and needle in str(e.value)
+
+
+def test_truncated_model_is_an_io_error():
+    net, _ = H.synth_model("v2_xvector")
+    raw = net.to_bytes(True)
+    with pytest.raises(P.XvError) as e:
+        P.Model(raw=raw[:len(raw) // 2])
+    assert e.value.status == 1
+    with pytest.raises(P.XvError):
+        P.Model(rxfilename="/nonexistent/final.raw")
+
+
+def test_no_cpu_compute_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    net, line = H.synth_model("v2_xvector")
+    m = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    with pytest.raises(P.XvError) as e:
+        P.Context(m)
+    assert e.value.status == 3 and "no CPU path" in str(e.value)
+
+
+def _py_plan(T, chunk, minc, pad):
+    """Chunk list per SURVEY.md App. B.5, written independently of csrc/extractor.cc."""
+    if T == 0 or (not pad and T < minc):
+        return None
+    this = T if (chunk <= 0 or T < chunk) else chunk
+    out = []
+    for ci in range(-(-T // this)):
+        ln = min(this, T - ci * this)
+        if ln < minc:
+            if not pad:
+                continue
+            left = (minc - ln) // 2
+            out.append((ci * this, ln, left, minc - ln - left))
+        else:
+            out.append((ci * this, ln, 0, 0))
+    return out or None
+
+
+@pytest.mark.parametrize("T", [0, 1, 14, 15, 24, 25, 26, 299, 300, 301, 920, 10001])
+@pytest.mark.parametrize("chunk,minc", [(-1, 25), (300, 25), (10000, 25), (300, 100)])
+@pytest.mark.parametrize("pad", [True, False])
+def test_chunk_planning(T, chunk, minc, pad):
+    got = P.plan_chunks(T, chunk, minc, pad, min_net_frames=15)
+    want = _py_plan(T, chunk, minc, pad)
+    if want is not None and any(ln + l + r < 15 for _, ln, l, r in want):
+        want = None       # a chunk shorter than the network context cannot be computed: utterance fails
+    assert got == want
+
+
+# ------------------------------------------------------------------------------------- command-line tools
+def _run(tool, *args, **kw):
+    return subprocess.run([os.path.join(BIN, tool)] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def test_nnet3_copy_shim_pipe_form(tmp_path):
+    net, line = H.synth_model("v2_xvector")
+    raw = net.to_bytes(True)
+    (tmp_path / "final.raw").write_bytes(raw)
+    (tmp_path / "extract.config").write_text(line + "\n")
+    # exactly the rxfilename extract_xvectors_new.sh:59 builds
+    rx = "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), tmp_path, tmp_path)
+    m = P.Model(rxfilename=rx)
+    assert m.info.num_layers == 6 and m.info.output_dim == 512
+    assert m.pack() == P.Model(raw=raw, nnet_config=line).pack()
+    # file -> file, components byte-identical, readable by the independent Python parser
+    r = _run("nnet3-copy", "--nnet-config=%s/extract.config" % tmp_path, str(tmp_path / "final.raw"), str(tmp_path / "out.raw"))
+    assert r.returncode == 0, r.stderr
+    n2 = H.nm.Nnet3.from_bytes((tmp_path / "out.raw").read_bytes())
+    assert any("output-node name=output input=tdnn6.affine" in l for l in n2.config_lines)
+    assert np.array_equal(n2.components["tdnn3.affine"].f["linear"], net.components["tdnn3.affine"].f["linear"])
+    r = _run("nnet3-copy", "--edits=foo", str(tmp_path / "final.raw"), "-")
+    assert r.returncode == 1 and b"not supported" in r.stderr
+
+
+def test_cli_contract_without_gpu(tmp_path):
+    r = _run("nnet3-xvector-compute", "--help")
+    assert r.returncode == 0 and b"Usage: nnet3-xvector-compute" in r.stderr
+    r = _run("nnet3-xvector-compute", "only-one-arg")
+    assert r.returncode == 1
+    r = _run("nnet3-xvector-compute", "--chunk-size=abc", "a", "b", "c")
+    assert r.returncode == 1 and b"invalid integer" in r.stderr
+    r = _run("nnet3-xvector-compute", "--use-gpu=no", "/nonexistent.raw", "ark:/dev/null", "ark:/dev/null")
+    assert r.returncode == 255 and b"cannot open" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        net, line = H.synth_model("v2_xvector")
+        (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+        r = _run("nnet3-xvector-compute", "--use-gpu=no", "--output-node=tdnn6.affine", str(tmp_path / "final.raw"),
+                 "ark:/dev/null", "ark:/dev/null")
+        # fails loudly: there is no CPU fallback behind --use-gpu=no
+        assert r.returncode == 255 and b"no CPU path" in r.stderr and b"--use-gpu=no requested" in r.stderr

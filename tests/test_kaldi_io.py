@@ -1,0 +1,149 @@
+"""CPU tests of the Kaldi I/O layers: hand-assembled format KATs, the text form that the
+reference's own Python helpers use (egs/sre/v2/steps/libs/common.py:354-470), and the C++ `kio` implementation
+(through the copy-feats / copy-vector tools built from csrc/) against the independent Python one in oracle/."""
+import io
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import kaldi_io as kio
+
+BIN = os.path.join(H.ROOT, H.PKG_NAME, "bin")
+
+
+def _run(tool, *args, **kw):
+    return subprocess.run([os.path.join(BIN, tool)] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def test_kat_binary_float_matrix_and_vector():
+    blob = b"utt1 \x00BFM \x04\x02\x00\x00\x00\x04\x03\x00\x00\x00" + struct.pack("<6f", 1, 2, 3, 4, 5, 6)
+    (key, m), = list(kio.read_ark(io.BytesIO(blob)))
+    assert key == "utt1" and m.shape == (2, 3) and np.array_equal(m, [[1, 2, 3], [4, 5, 6]])
+    vb = b"spk \x00BFV \x04\x03\x00\x00\x00" + struct.pack("<3f", 0.5, -1.0, 2.0)
+    (key, v), = list(kio.read_ark(io.BytesIO(vb), "vector"))
+    assert key == "spk" and np.array_equal(v, [0.5, -1.0, 2.0])
+    out = io.BytesIO()
+    out.write(b"spk ")
+    out.write(b"\x00B")
+    kio.write_vector(out, v)
+    assert out.getvalue() == vb
+
+
+def test_kat_compressed_matrix_formats():
+    # CM2: uint16 row-major, value = min + range*u/65535 ; CM3: uint8, /255 ; CM: per-column percentile headers
+    hdr = struct.pack("<ffii", -1.0, 2.0, 2, 2)
+    cm2 = b"CM2 " + hdr + struct.pack("<4H", 0, 65535, 32768, 16384)
+    m = kio.read_matrix(io.BytesIO(cm2))
+    assert np.allclose(m, [[-1.0, 1.0], [-1 + 2 * 32768 / 65535, -1 + 2 * 16384 / 65535]], atol=1e-6)
+    cm3 = b"CM3 " + hdr + bytes([0, 255, 51, 102])
+    m = kio.read_matrix(io.BytesIO(cm3))
+    assert np.allclose(m, [[-1.0, 1.0], [-1 + 2 * 51 / 255, -1 + 2 * 102 / 255]], atol=1e-6)
+    # CM: one column, percentiles (0, 16384, 49152, 65535) -> (-1, -0.5, 0.5, 1); bytes 0/64/192/255 hit them
+    cm = b"CM " + struct.pack("<ffii", -1.0, 2.0, 4, 1) + struct.pack("<4H", 0, 16384, 49152, 65535) + bytes([0, 64, 192, 255])
+    m = kio.read_matrix(io.BytesIO(cm))
+    assert np.allclose(m[:, 0], [-1.0, -0.5, 0.5, 1.0], atol=2e-5)
+
+
+def test_text_matrix_form_matches_reference_python_helpers():
+    # what steps/libs/common.py:write_matrix_ascii emits / read_matrix_ascii accepts: "key [\n  a b\n  c d ]\n"
+    text = b"utt [\n  1 2 3\n  4 5 6 ]\n"
+    (key, m), = list(kio.read_ark(io.BytesIO(text)))
+    assert key == "utt" and np.array_equal(m, [[1, 2, 3], [4, 5, 6]])
+    out = io.BytesIO()
+    kio.write_matrix(out, m, binary=False)
+    (k2, m2), = list(kio.read_ark(io.BytesIO(b"utt" + out.getvalue())))
+    assert np.array_equal(m, m2)
+
+
+@pytest.fixture(scope="module")
+def feats(tmp_path_factory):
+    d = tmp_path_factory.mktemp("io")
+    utts = [("utt%03d" % i, H.features(i, 7 + 5 * i, 6)) for i in range(5)]
+    utts.append(("empty", np.zeros((0, 0), np.float32)))
+    return d, utts
+
+
+@pytest.mark.parametrize("form", ["binary", "text", "CM", "CM2", "CM3", "double"])
+def test_cpp_reader_all_matrix_formats(feats, form):
+    d, utts = feats
+    utts = [u for u in utts if u[1].size] if form.startswith("CM") else utts
+    src = str(d / ("in_%s.ark" % form))
+    expect = dict(utts)
+    if form == "binary":
+        kio.write_ark_matrices(src, utts)
+    elif form == "text":
+        kio.write_ark_matrices(src, utts, binary=False)
+    elif form == "double":
+        with open(src, "wb") as f:
+            for k, m in utts:
+                f.write(k.encode() + b" \x00B")
+                kio.write_matrix(f, m, True, double=True)
+    else:
+        with open(src, "wb") as f:
+            for k, m in utts:
+                f.write(k.encode() + b" \x00B")
+                expect[k] = kio.write_compressed_matrix(f, m, form)
+    dst = str(d / ("out_%s.ark" % form))
+    r = _run("copy-feats", "ark:" + src, "ark:" + dst)
+    assert r.returncode == 0, r.stderr
+    got = dict(kio.read_ark(dst))
+    assert list(got) == [k for k, _ in utts]
+    for k, m in expect.items():
+        assert got[k].shape == m.shape or (m.size == 0 and got[k].size == 0)
+        if m.size:
+            assert np.allclose(got[k], m, rtol=0, atol=2e-6 * max(1.0, np.abs(m).max())), (form, k)
+            if form in ("binary", "text"):
+                assert np.array_equal(got[k], m)
+
+
+def test_cpp_ark_scp_writer_offsets_pipes_and_text(feats):
+    d, utts = feats
+    utts = [u for u in utts if u[1].size]
+    src = str(d / "w_in.ark")
+    kio.write_ark_matrices(src, utts)
+    ark, scp = str(d / "w_out.ark"), str(d / "w_out.scp")
+    # feature rspecifier is a pipe (the form extract_xvectors_new.sh:79 uses), output is ark,scp
+    r = _run("copy-feats", "ark:cat %s |" % src, "ark,scp:%s,%s" % (ark, scp))
+    assert r.returncode == 0, r.stderr
+    lines = open(scp).read().split("\n")[:-1]
+    assert [l.split()[0] for l in lines] == [k for k, _ in utts]
+    raw = open(ark, "rb").read()
+    for line, (k, m) in zip(lines, utts):
+        path, off = line.split()[1].rsplit(":", 1)
+        assert path == ark and raw[int(off):int(off) + 2] == b"\x00B"        # offset points at the binary marker
+        assert raw[int(off) - len(k) - 1:int(off)] == k.encode() + b" "
+    got = dict(kio.read_scp(scp))
+    for k, m in utts:
+        assert np.array_equal(got[k], m)
+    # scp in -> text ark out -> python reader
+    txt = str(d / "w_out.txt")
+    r = _run("copy-feats", "scp:" + scp, "ark,t:" + txt)
+    assert r.returncode == 0, r.stderr
+    got = dict(kio.read_ark(txt))
+    for k, m in utts:
+        assert np.allclose(got[k], m, rtol=2e-7)
+    # vectors: binary -> scp+ark -> text
+    vsrc = str(d / "v.ark")
+    vecs = [("spk%d" % i, H.features(i, 1, 9)[0]) for i in range(4)]
+    kio.write_ark_vectors(vsrc, vecs)
+    r = _run("copy-vector", "ark:" + vsrc, "ark,scp:%s,%s" % (d / "v2.ark", d / "v2.scp"))
+    assert r.returncode == 0, r.stderr
+    got = dict(kio.read_scp(str(d / "v2.scp"), "vector"))
+    for k, v in vecs:
+        assert np.array_equal(got[k], v)
+
+
+def test_cpp_reader_error_behaviour(feats):
+    d, _ = feats
+    r = _run("copy-feats", "ark:/nonexistent/file.ark", "ark:/dev/null")
+    assert r.returncode == 255 and b"cannot open" in r.stderr
+    bad = str(d / "bad.ark")
+    open(bad, "wb").write(b"utt1 \x00BFM \x04\x02\x00\x00\x00\x04\x03\x00\x00\x00abc")     # truncated payload
+    r = _run("copy-feats", "ark:" + bad, "ark:/dev/null")
+    assert r.returncode == 255 and b"unexpected end" in r.stderr
+    r = _run("copy-feats", "foo:" + bad, "ark:/dev/null")
+    assert r.returncode == 255

@@ -1,0 +1,43 @@
+"""CPU test: the plain-C restatement (oracle/xvec_oracle.c) against the numpy graph evaluator - two independent
+formulations of the same published semantics (both test infrastructure; parity with Kaldi itself is unpinned)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle.export_program import export_program
+
+EXE = os.path.join(H.ROOT, "oracle", "_build", "xvec_oracle_c")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "oracle")])
+
+
+@pytest.mark.parametrize("topology,T", [("v2_xvector", 15), ("v2_xvector", 64), ("v5_cvector", 21), ("v5_cvector", 50),
+                                        ("pa_wo_pretrain", 33)])
+def test_c_oracle_matches_numpy_oracle(tmp_path, topology, T):
+    net, line = H.synth_model(topology)
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    export_program(n2, str(tmp_path / "prog.bin"))
+    x = H.features(T, T)
+    x.tofile(str(tmp_path / "x.f32"))
+    subprocess.check_call([EXE, str(tmp_path / "prog.bin"), str(tmp_path / "x.f32"), str(T), str(tmp_path / "o.f32")])
+    got = np.fromfile(str(tmp_path / "o.f32"), np.float32)
+    ref = H.xo.GraphEvaluator(n2, np.float64).compute(x)
+    assert H.rel_err(got[None], ref) < 2e-5
+
+
+def test_c_oracle_refuses_short_chunks(tmp_path):
+    net, line = H.synth_model("v2_xvector")
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    export_program(n2, str(tmp_path / "prog.bin"))
+    H.features(1, 14).tofile(str(tmp_path / "x.f32"))
+    r = subprocess.run([EXE, str(tmp_path / "prog.bin"), str(tmp_path / "x.f32"), "14", str(tmp_path / "o.f32")],
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 2 and b"never pads" in r.stderr

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of `bench.py` into profiles/ (tracked).
+
+Usage: python tools/parse_rocprof.py <gpurun_out/prof dir> <round tag, e.g. r01>
+Expects  <dir>/kt/bench_kernel_stats.csv          (rocprofv3 --kernel-trace --stats)
+         <dir>/pmc_FETCH_SIZE/bench_counter_collection.csv, <dir>/pmc_WRITE_SIZE/...   (separate --pmc passes)
+Writes   profiles/<tag>_kernel_stats.csv          (copy of the stats summary, our kernels + top others)
+         profiles/<tag>_pmc_hbm.md                per-kernel HBM traffic of one step
+         profiles/pmc_traffic.json                {"hbm_bytes_per_launch": ...} for bench.py's roofline.traffic
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+half of a wide coalesced streaming read, so reads are doubled (checked here on prep_input, whose input bytes are
+known); WRITE_SIZE matched the known output bytes of every kernel 1:1.
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def main():
+    d, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    ks = os.path.join(d, "kt", "bench_kernel_stats.csv")
+    if os.path.exists(ks):
+        rows = list(csv.reader(open(ks)))
+        keep = [rows[0]] + [r for r in rows[1:] if "xv::" in r[0]] + [r for r in rows[1:] if "xv::" not in r[0]][:6]
+        with open(os.path.join(prof, tag + "_kernel_stats.csv"), "w", newline="") as f:
+            csv.writer(f, quoting=csv.QUOTE_ALL).writerows(keep)
+    per = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = os.path.join(d, "pmc_" + c, "bench_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
+        rows = [r for r in csv.DictReader(open(p)) if "xv::" in r["Kernel_Name"]]
+        # dispatches of the last complete step: find the last prep_input
+        idx = max(i for i, r in enumerate(rows) if "prep_input" in r["Kernel_Name"])
+        step = rows[idx:]
+        per[c] = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), float(r["Counter_Value"]),
+                   (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in step]
+    if len(per) == 2:
+        lines = ["# HBM traffic per kernel, one bench step (%s)" % tag, "",
+                 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes; reads x2 (gfx950 FETCH_SIZE",
+                 "counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM; prep_input reads a known 9.42 MB and reports 4.7 MB).", "",
+                 "| # | kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes (2*fetch+write) | duration us |", "|---|---|---|---|---|---|"]
+        tot_act, n_act = 0.0, 0
+        for i, ((k, f, us), (_, w, _)) in enumerate(zip(per["FETCH_SIZE"], per["WRITE_SIZE"])):
+            b = (2 * f + w) * 1024
+            lines.append("| %d | %s | %.1f | %.1f | %.3e | %.1f |" % (i, k, f, w, b, us))
+            if "tdnn_gemm_kernel<0, 0>" in k or "tdnn_gemm_kernel<1, 0>" in k or "tdnn_gemm_kernel<2, 0>" in k:
+                tot_act += b
+                n_act += 1
+        open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
+        if n_act:
+            json.dump({"hbm_bytes_per_launch": tot_act / n_act, "kernel": "tdnn_gemm_kernel<prec,act>", "launches": n_act,
+                       "source": tag + "_pmc_hbm.md"}, open(os.path.join(prof, "pmc_traffic.json"), "w"))
+    for name in ("kt_bench.log",):
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            # keep only the JSON line of the profiled run
+            js = [l for l in open(p) if l.startswith("{")]
+            if js:
+                open(os.path.join(prof, tag + "_bench_under_rocprof.json"), "w").write(js[-1])
+    print("wrote", sorted(os.listdir(prof)))
+
+
+if __name__ == "__main__":
+    main()
