@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="batches in flight inside the engine during the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,6 +109,10 @@ def main():
         wt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if world > 1:
         dist.broadcast(wt, 0)       # the ONE collective of this path (weights over xGMI)
+    # The timed region runs the engine with ONE lane (one batch in flight) so that the per-kernel HIP-event durations
+    # used for the roofline are not inflated by kernels of another batch sharing the GPU; the throughput with two
+    # batches in flight (the engine's default, +10-12 %) is measured afterwards and reported as "pipelined".
+    os.environ["XVEC_LANES"] = str(args.lanes)
     ctx = P.Context(blob=wt.cpu().numpy().tobytes(), device=local_rank)
     del wt
 
@@ -116,13 +121,31 @@ def main():
     g = torch.Generator(device=dev).manual_seed(20180101 + rank)
     sigma = (8.0 * 0.9 ** torch.arange(D, dtype=torch.float32)).to(dev)
     feats = torch.randn(B * T, D, generator=g, device=dev, dtype=torch.float32) * sigma
-    out = torch.empty(B, ctx.info.output_dim, dtype=torch.float32, device=dev)
+    outs = [torch.empty(B, ctx.info.output_dim, dtype=torch.float32, device=dev) for _ in range(4)]
+    out = outs[0]
     offs = np.arange(B + 1, dtype=np.int32) * T
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        ctx.forward_batch_device(feats.data_ptr(), offs, out.data_ptr(), out.shape[1], stream)
+    # stream = None -> the engine's own streams: consecutive (independent) batches alternate between its lanes,
+    # each with its own activation buffers, so one batch's tails overlap with the next batch's kernels
+    stream = None
+    step_no = [0]
 
+    def step():
+        o = outs[step_no[0] % len(outs)]
+        step_no[0] += 1
+        ctx.forward_batch_device(feats.data_ptr(), offs, o.data_ptr(), o.shape[1], stream)
+
+    def prewarm(fn, seconds=0.6):
+        """Keep the GPU busy for a moment before a timed region: after an idle gap (model set-up, the CPU oracle) the
+        first ~100 ms of kernels run at a reduced clock, which once halved a measured rate.  Not counted as steps."""
+        t = time.perf_counter()
+        while time.perf_counter() - t < seconds:
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize()
+
+    prewarm(step)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -215,7 +238,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s TDNN, %d chunks x %d frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
                                    % (args.topology, B, T), "topology": args.topology, "batch_chunks_per_gpu": B,
-                       "frames_per_chunk": T, "precision": args.precision,
+                       "frames_per_chunk": T, "precision": args.precision, "lanes": args.lanes,
                        "alg_gflop_per_utt": 2.0 * macs / 1e9},
             "roofline": roofline,
             "parity_rel_err_vs_oracle_fp32": parity,
@@ -224,12 +247,24 @@ def main():
         if world == 1 and not args.no_extra_modes and args.precision == "bf16x3":
             # single-pass modes, reported next to the parity mode with their measured error (never `value`)
             extra = {}
+            os.environ["XVEC_LANES"] = "2"
+            c3 = P.Context(model, device=local_rank, precision=prec)
+            prewarm(lambda: c3.forward_batch_device(feats.data_ptr(), offs, outs[1].data_ptr(), outs[1].shape[1], None))
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                o = outs[i % len(outs)]
+                c3.forward_batch_device(feats.data_ptr(), offs, o.data_ptr(), o.shape[1], None)
+            torch.cuda.synchronize()
+            d3 = time.perf_counter() - t1
+            res["pipelined"] = {"lanes": 2, "value": B * args.steps / d3, "unit": "utt/s", "ms_per_step": d3 / args.steps * 1e3,
+                                "note": "two independent batches in flight on two engine streams (tails of one batch's "
+                                        "kernels overlap the other's); not used for value/roofline"}
+            del c3
+            os.environ["XVEC_LANES"] = str(args.lanes)
             for pname in ("bf16", "fp16"):
                 c2 = P.Context(model, device=local_rank, precision=P.PRECISIONS[pname])
                 o2 = torch.empty_like(out)
-                for _ in range(3):
-                    c2.forward_batch_device(feats.data_ptr(), offs, o2.data_ptr(), o2.shape[1], stream)
-                torch.cuda.synchronize()
+                prewarm(lambda: c2.forward_batch_device(feats.data_ptr(), offs, o2.data_ptr(), o2.shape[1], stream))
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
                     c2.forward_batch_device(feats.data_ptr(), offs, o2.data_ptr(), o2.shape[1], stream)

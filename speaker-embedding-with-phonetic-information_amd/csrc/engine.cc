@@ -1,6 +1,7 @@
 // Device engine.  See engine.h.
 #include "engine.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -246,6 +247,18 @@ Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
         throw EngineError("the pooled layer must feed only the statistics pooling");
   nplanes_ = info_.precision == kPrecBf16x3 ? 2 : 1;
   Check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  {
+    const char* e = getenv("XVEC_LANES");
+    int nl = e && *e ? atoi(e) : 2;
+    if (nl < 1) nl = 1;
+    if (nl > 4) nl = 4;
+    lanes_.resize(nl);
+    for (Lane& L : lanes_) {
+      Check(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking), "hipStreamCreate(lane)");
+      Check(hipEventCreateWithFlags(&L.done, hipEventDisableTiming), "hipEventCreate(lane)");
+      L.act.resize(info_.layers.size());
+    }
+  }
 
   BlobHeader h;
   memcpy(&h, blob, sizeof h);
@@ -275,16 +288,22 @@ Engine::~Engine() {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
   };
-  for (DevLayer& L : layers_) {
-    fr(L.act_hi);
-    fr(L.act_lo);
+  for (Lane& L : lanes_) {
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    for (ActBuf& a : L.act) {
+      fr(a.act_hi);
+      fr(a.act_lo);
+    }
+    fr(L.in_hi);
+    fr(L.in_lo);
+    fr(L.partial);
+    fr(L.stats_hi);
+    fr(L.stats_lo);
+    fr(L.out_f32);
+    fr(L.splitk_ws);
+    if (L.done) (void)hipEventDestroy(L.done);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
   }
-  fr(in_hi_);
-  fr(in_lo_);
-  fr(partial_);
-  fr(stats_hi_);
-  fr(stats_lo_);
-  fr(out_f32_);
   fr(feats_stage_);
   fr(out_stage_);
   if (d_blob_) (void)hipFree(d_blob_);
@@ -300,39 +319,39 @@ void Engine::Ensure(Buf* b, size_t bytes, bool zero) {
   if (zero) Check(hipMemset(b->p, 0, bytes), "hipMemset");
 }
 
-void Engine::EnsureCapacity(int rows, int b_pad) {
-  if (rows > cap_rows_) {
+void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
+  if (rows > L.cap_rows) {
     Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     const size_t r = (size_t)rows + 2 * kHalo;
-    Ensure(&in_hi_, r * in_ld_ * 2, true);
-    if (nplanes_ == 2) Ensure(&in_lo_, r * in_ld_ * 2, true);
+    Ensure(&L.in_hi, r * in_ld_ * 2, true);
+    if (nplanes_ == 2) Ensure(&L.in_lo, r * in_ld_ * 2, true);
     for (size_t i = 0; i < layers_.size(); ++i) {
       const BlobLayerInfo& li = info_.layers[i];
       if (li.segment_level) continue;
       if ((int)i == info_.pooled_layer) {
-        Ensure(&partial_, (size_t)(rows / kRowAlign) * 2 * li.n_pad * 4, true);
+        Ensure(&L.partial, (size_t)(rows / kRowAlign) * 2 * li.n_pad * 4, true);
         continue;
       }
-      Ensure(&layers_[i].act_hi, r * li.n_pad * 2, true);
-      if (nplanes_ == 2) Ensure(&layers_[i].act_lo, r * li.n_pad * 2, true);
+      Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
+      if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true);
     }
-    cap_rows_ = rows;
+    L.cap_rows = rows;
   }
-  if (b_pad > cap_b_) {
+  if (b_pad > L.cap_b) {
     Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-    Ensure(&stats_hi_, (size_t)b_pad * stats_ld_ * 2, true);
-    if (nplanes_ == 2) Ensure(&stats_lo_, (size_t)b_pad * stats_ld_ * 2, true);
+    Ensure(&L.stats_hi, (size_t)b_pad * stats_ld_ * 2, true);
+    if (nplanes_ == 2) Ensure(&L.stats_lo, (size_t)b_pad * stats_ld_ * 2, true);
     for (size_t i = 0; i < layers_.size(); ++i) {
       const BlobLayerInfo& li = info_.layers[i];
       if (!li.segment_level) continue;
       if ((int)i == info_.output_layer) {
-        Ensure(&out_f32_, (size_t)b_pad * li.n_pad * 4, true);
+        Ensure(&L.out_f32, (size_t)b_pad * li.n_pad * 4, true);
       } else {
-        Ensure(&layers_[i].act_hi, (size_t)b_pad * li.n_pad * 2, true);
-        if (nplanes_ == 2) Ensure(&layers_[i].act_lo, (size_t)b_pad * li.n_pad * 2, true);
+        Ensure(&L.act[i].act_hi, (size_t)b_pad * li.n_pad * 2, true);
+        if (nplanes_ == 2) Ensure(&L.act[i].act_lo, (size_t)b_pad * li.n_pad * 2, true);
       }
     }
-    cap_b_ = b_pad;
+    L.cap_b = b_pad;
   }
 }
 
@@ -372,7 +391,7 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
     off += RoundUp(key[b], kRowAlign);
     if (off > (1l << 30)) throw EngineError("batch too large (more than 2^30 device rows)");
   }
-  plan->rows = RoundUp((int)off, kBM);
+  plan->rows = RoundUp((int)off, 2 * kBM);  // the 256-row GEMM variant needs an even number of 128-row tiles
   const int ngrp = plan->rows / kRowAlign;
   std::vector<int32_t> grp_utt(ngrp, -1), g0(B), g1(B), cnt(B);
   std::vector<int8_t> grp_range((size_t)ngrp * 2, 0);
@@ -427,8 +446,12 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
 
 void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream) {
   Check(hipSetDevice(device_), "hipSetDevice");
-  hipStream_t s = stream ? stream : stream_;
-  EnsureCapacity(plan.rows, plan.b_pad);
+  // lane selection: the engine's own streams rotate; a caller-provided stream is mapped to a lane and ordered
+  // behind whatever that lane did last (its buffers are reused)
+  Lane& L = lanes_[stream ? ((size_t)stream >> 6) % lanes_.size() : (next_lane_++ % lanes_.size())];
+  hipStream_t s = stream ? stream : L.stream;
+  if (L.busy) Check(hipStreamWaitEvent(s, L.done, 0), "hipStreamWaitEvent(lane)");
+  EnsureCapacity(L, plan.rows, plan.b_pad);
   const int prec = info_.precision;
 
   PrepArgs pa;
@@ -439,8 +462,8 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
   pa.rows = plan.rows;
   pa.dim = info_.input_dim;
   pa.ld = in_ld_;
-  pa.out_hi = ActBase(in_hi_, in_ld_);
-  pa.out_lo = ActBase(in_lo_, in_ld_);
+  pa.out_hi = ActBase(L.in_hi, in_ld_);
+  pa.out_lo = ActBase(L.in_lo, in_ld_);
   std::vector<hipEvent_t> prof_run;
   const bool first_prof = prof_on_ && prof_labels_.empty();
   if (prof_on_) ProfMark(s, &prof_run);
@@ -459,21 +482,21 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
       const LayerSource& src = li.src[j];
       Seg& sg = ga.seg[j];
       if (src.layer == kSrcInput) {
-        sg.hi = ActBase(in_hi_, in_ld_);
-        sg.lo = ActBase(in_lo_, in_ld_);
+        sg.hi = ActBase(L.in_hi, in_ld_);
+        sg.lo = ActBase(L.in_lo, in_ld_);
         sg.ld = in_ld_;
       } else if (src.layer == kSrcPooled) {
-        sg.hi = (const uint16_t*)stats_hi_.p;
-        sg.lo = (const uint16_t*)stats_lo_.p;
+        sg.hi = (const uint16_t*)L.stats_hi.p;
+        sg.lo = (const uint16_t*)L.stats_lo.p;
         sg.ld = stats_ld_;
       } else {
         const BlobLayerInfo& pi = info_.layers[src.layer];
         if (pi.segment_level) {
-          sg.hi = (const uint16_t*)layers_[src.layer].act_hi.p;
-          sg.lo = (const uint16_t*)layers_[src.layer].act_lo.p;
+          sg.hi = (const uint16_t*)L.act[src.layer].act_hi.p;
+          sg.lo = (const uint16_t*)L.act[src.layer].act_lo.p;
         } else {
-          sg.hi = ActBase(layers_[src.layer].act_hi, pi.n_pad);
-          sg.lo = ActBase(layers_[src.layer].act_lo, pi.n_pad);
+          sg.hi = ActBase(L.act[src.layer].act_hi, pi.n_pad);
+          sg.lo = ActBase(L.act[src.layer].act_lo, pi.n_pad);
         }
         sg.ld = pi.n_pad;
       }
@@ -496,26 +519,34 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
       ga.m_tiles = plan.rows / kBM;
       if ((int)i == info_.pooled_layer) {
         epi = kEpiStats;
-        ga.partial = (float*)partial_.p;
+        ga.partial = (float*)L.partial.p;
         ga.ldp = li.n_pad;
         ga.grp_range = plan.d_grp_range;
       } else {
         epi = kEpiAct;
-        ga.out_hi = ActBase(dl.act_hi, li.n_pad);
-        ga.out_lo = ActBase(dl.act_lo, li.n_pad);
+        ga.out_hi = ActBase(L.act[i].act_hi, li.n_pad);
+        ga.out_lo = ActBase(L.act[i].act_lo, li.n_pad);
         ga.ldo = li.n_pad;
       }
     } else {
       ga.m_tiles = plan.b_pad / kBM;
+      // few rows, long K (3000 for the embedding layer): split K over up to 32 slices, >= 4 steps each
+      const int per = std::max(4, (ksteps + 31) / 32);
+      ga.ksteps_per_slice = per;
+      ga.ksplit = (ksteps + per - 1) / per;
+      if (ga.ksplit > 1) {
+        Ensure(&L.splitk_ws, (size_t)ga.ksplit * plan.b_pad * li.n_pad * 4, false);
+        ga.splitk_ws = (float*)L.splitk_ws.p;
+      }
       if ((int)i == info_.output_layer) {
         epi = kEpiF32;
-        ga.out_f32 = (float*)out_f32_.p;
+        ga.out_f32 = (float*)L.out_f32.p;
         ga.ldf = li.n_pad;
         ga.m_valid = plan.B;
       } else {
         epi = kEpiAct;
-        ga.out_hi = (uint16_t*)dl.act_hi.p;
-        ga.out_lo = (uint16_t*)dl.act_lo.p;
+        ga.out_hi = (uint16_t*)L.act[i].act_hi.p;
+        ga.out_lo = (uint16_t*)L.act[i].act_lo.p;
         ga.ldo = li.n_pad;
       }
     }
@@ -526,7 +557,7 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
 
     if ((int)i == info_.pooled_layer) {
       PoolArgs po;
-      po.partial = (const float*)partial_.p;
+      po.partial = (const float*)L.partial.p;
       po.ldp = li.n_pad;
       po.utt_grp0 = plan.d_utt_grp0;
       po.utt_grp1 = plan.d_utt_grp1;
@@ -534,8 +565,8 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
       po.B = plan.B;
       po.dim = info_.pool_dim;
       po.var_floor = info_.variance_floor;
-      po.out_hi = (uint16_t*)stats_hi_.p;
-      po.out_lo = (uint16_t*)stats_lo_.p;
+      po.out_hi = (uint16_t*)L.stats_hi.p;
+      po.out_lo = (uint16_t*)L.stats_lo.p;
       po.ld = stats_ld_;
       Check(launch_pool_finalise(po, prec, s), "pool_finalise launch");
       if (prof_on_) ProfMark(s, &prof_run);
@@ -543,9 +574,11 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
     }
   }
   const BlobLayerInfo& ol = info_.layers[info_.output_layer];
-  Check(hipMemcpy2DAsync(out_dev, (size_t)out_ld * 4, out_f32_.p, (size_t)ol.n_pad * 4, (size_t)info_.output_dim * 4,
+  Check(hipMemcpy2DAsync(out_dev, (size_t)out_ld * 4, L.out_f32.p, (size_t)ol.n_pad * 4, (size_t)info_.output_dim * 4,
                          (size_t)plan.B, hipMemcpyDeviceToDevice, s),
         "hipMemcpy2DAsync(out)");
+  Check(hipEventRecord(L.done, s), "hipEventRecord(lane)");
+  L.busy = true;
   if (prof_on_) {
     ProfMark(s, &prof_run);
     if (first_prof) prof_labels_.push_back("copy_out");

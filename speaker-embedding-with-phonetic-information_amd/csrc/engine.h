@@ -63,6 +63,7 @@ class Engine {
   void ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out);
 
   hipStream_t stream() const { return stream_; }
+  int num_lanes() const { return (int)lanes_.size(); }
   // last forward's per-kernel launch list (name, m_tiles*n_tiles) for logging / tests
   size_t weight_bytes() const { return blob_data_bytes_; }
   // Per-launch timing with HIP events recorded on the stream the kernels are launched on.
@@ -81,11 +82,24 @@ class Engine {
     const float* bias;
     const float* scale;
     const float* offset;
+  };
+  struct ActBuf {
     Buf act_hi, act_lo;   // frame-level: [halo + rows + halo][n_pad]; segment-level: [b_pad][n_pad]
+  };
+  // A lane = one in-flight batch: its own stream and its own activation / workspace buffers.  Consecutive
+  // forward calls on the engine's own streams alternate between lanes, so the tail of one batch (partially filled
+  // last round of tiles, the 8-workgroup embedding GEMM, small kernels) overlaps with the next batch's kernels.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;   // recorded at the end of every forward on this lane
+    bool busy = false;
+    std::vector<ActBuf> act;     // per layer
+    Buf in_hi, in_lo, partial, stats_hi, stats_lo, out_f32, splitk_ws;
+    int cap_rows = 0, cap_b = 0;
   };
   void Check(hipError_t e, const char* what) const;
   void Ensure(Buf* b, size_t bytes, bool zero);
-  void EnsureCapacity(int rows, int b_pad);
+  void EnsureCapacity(Lane& L, int rows, int b_pad);
   uint16_t* ActBase(const Buf& b, int ld) const;
 
   BlobInfo info_;
@@ -96,13 +110,10 @@ class Engine {
   size_t blob_data_bytes_ = 0;
   std::vector<DevLayer> layers_;
   int in_ld_ = 0;
-  Buf in_hi_, in_lo_;
-  Buf partial_;
-  Buf stats_hi_, stats_lo_;
   int stats_ld_ = 0;
-  Buf out_f32_;
+  std::vector<Lane> lanes_;
+  size_t next_lane_ = 0;
   Buf feats_stage_, out_stage_;
-  int cap_rows_ = 0, cap_b_ = 0;
   std::map<std::vector<int32_t>, std::shared_ptr<Plan>> plan_cache_;
   bool prof_on_ = false;
   std::vector<std::string> prof_labels_;

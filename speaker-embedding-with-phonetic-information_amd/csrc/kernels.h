@@ -34,7 +34,7 @@ enum Epilogue : int {
   kEpiAct = 0,    // bias -> ReLU? -> BatchNorm? -> split to 16-bit planes
   kEpiF32 = 1,    // bias -> ReLU? -> BatchNorm? -> fp32 rows (embedding / raw affine output)
   kEpiStats = 2,  // bias -> ReLU? -> BatchNorm? -> per-16-row partial (sum, sum of squares)
-  kEpiLogSoftmaxPartial = 3,  // reserved
+  kEpiSplitK = 3, // internal: raw fp32 accumulators of one K slice into the split-K workspace
 };
 
 struct Seg {
@@ -46,9 +46,25 @@ struct Seg {
   int pad_;
 };
 
+// A group of K segments that share one LDS activation tile (filled by the launcher, see kernels.hip).
+struct Grp {
+  const uint16_t* hi;
+  const uint16_t* lo;
+  int ld;
+  int ksteps;   // 32-column chunks per segment
+  int nshift;   // time offsets in the group
+  int shift0;   // first (smallest) offset
+  int dstep;    // spacing of the offsets
+  int wcol0;    // weight column of (offset 0, chunk 0)
+  int wstride;  // weight columns between consecutive offsets
+  int pad_;
+};
+
 struct GemmArgs {
   Seg seg[kMaxSeg];
   int nseg;
+  Grp grp[kMaxSeg];
+  int ngrp;
   int total_ksteps;
   const uint16_t* w_hi;  // [n_pad][ldw] row-major (Kaldi <LinearParams> orientation)
   const uint16_t* w_lo;
@@ -72,6 +88,11 @@ struct GemmArgs {
   float* partial;        // [rows/16][2][ldp]
   int ldp;
   const int8_t* grp_range;  // [rows/16][2] first/last(exclusive) valid row inside the 16-row group
+  // split-K (small-M layers after the pooling): ksplit > 1 -> K steps are divided over gridDim.y slices whose raw
+  // accumulators go to splitk_ws[slice][rows][n_pad]; a second kernel adds them in slice order and applies the epilogue
+  int ksplit;
+  int ksteps_per_slice;
+  float* splitk_ws;
 };
 
 // Launches the spliced-affine GEMM. Returns hipSuccess or the launch error.

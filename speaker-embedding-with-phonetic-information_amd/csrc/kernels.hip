@@ -25,6 +25,7 @@
 //     reduction is 3 in-register adds + 2 cross-lane adds.
 #include "kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace xv {
@@ -80,6 +81,133 @@ __device__ __forceinline__ int swap_fields(int x) {
 }
 
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
+
+// Shared epilogue of the GEMM kernels.  acc[p][q] is the 16x16 fragment (P-tile fragment p) x (Q-tile fragment q)
+// of one wave's 64x64 tile whose first frame is mbase and first output column nbase.
+template <int PREC, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], const int mbase, const int nbase,
+                                              const int lane) {
+  constexpr bool SPLIT = (PREC == kPrecBf16x3);
+  constexpr bool F16 = (PREC == kPrecFp16);
+  const int fr_i = lane & 15;
+  const int fr_g = lane >> 4;
+  // ---- epilogues ---------------------------------------------------------------------------
+  if constexpr (EPI == kEpiSplitK) {
+    // raw accumulators of this K slice (bias / ReLU / BatchNorm are applied by splitk_reduce_kernel)
+    const int ncol = nbase + fr_g * 16;
+    float* ws = a.splitk_ws + (long)blockIdx.y * ((long)a.m_tiles * kBM) * ((long)a.n_tiles * kBN);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* dst = ws + (long)(mbase + q * 16 + fr_i) * ((long)a.n_tiles * kBN) + ncol;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *(f32x4*)(dst + p * 4) = acc[p][q];
+    }
+  } else if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
+    // lane owns frames q*16 + fr_i (q = 0..3) x 16 contiguous columns ncol + p*4 + r
+    const int ncol = nbase + fr_g * 16;
+    float bs[16], sc[16], of[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4 b4 = *(const f32x4*)(a.bias + ncol + v * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[v * 4 + r] = b4[r];
+    }
+    if (a.bn) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 s4 = *(const f32x4*)(a.scale + ncol + v * 4);
+        const f32x4 o4 = *(const f32x4*)(a.offset + ncol + v * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[v * 4 + r] = s4[r];
+          of[v * 4 + r] = o4[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        sc[v] = 1.f;
+        of[v] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = mbase + q * 16 + fr_i;
+      float y[16];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float z = acc[p][q][r] + bs[p * 4 + r];
+          if (a.relu) z = fmaxf(z, 0.f);
+          if (a.bn) z = z * sc[p * 4 + r] + of[p * 4 + r];
+          y[p * 4 + r] = z;
+        }
+      if constexpr (EPI == kEpiF32) {
+        if (row < a.m_valid) {
+          float* dst = a.out_f32 + (long)row * a.ldf + ncol;
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            *(f32x4*)(dst + v * 4) = f32x4{y[v * 4], y[v * 4 + 1], y[v * 4 + 2], y[v * 4 + 3]};
+        }
+      } else {
+        unsigned int hw[8], lw[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const uint16_t h0 = to16<F16>(y[2 * v]);
+          const uint16_t h1 = to16<F16>(y[2 * v + 1]);
+          hw[v] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+          if constexpr (SPLIT) {
+            const uint16_t l0 = to16<F16>(y[2 * v] - from16<F16>(h0));
+            const uint16_t l1 = to16<F16>(y[2 * v + 1] - from16<F16>(h1));
+            lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+          }
+        }
+        uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
+        *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+        *(u32x4*)(dh + 8) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+        if constexpr (SPLIT) {
+          uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
+          *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+          *(u32x4*)(dl + 8) = u32x4{lw[4], lw[5], lw[6], lw[7]};
+        }
+      }
+    }
+  } else {
+    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = nbase + q * 16 + fr_i;
+      const float b = a.bias[col];
+      const float sc = a.bn ? a.scale[col] : 1.f;
+      const float of = a.bn ? a.offset[col] : 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int grp = (mbase + p * 16) >> 4;
+        const int first = a.grp_range[2 * grp];
+        const int last = a.grp_range[2 * grp + 1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float z = acc[p][q][r] + b;
+          if (a.relu) z = fmaxf(z, 0.f);
+          if (a.bn) z = z * sc + of;
+          const int rr = fr_g * 4 + r;
+          const bool ok = (rr >= first) && (rr < last);
+          s1 += ok ? z : 0.f;
+          s2 += ok ? z * z : 0.f;
+        }
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        float* dst = a.partial + (long)grp * 2 * a.ldp + col;
+        if (fr_g == 0) dst[0] = s1;
+        if (fr_g == 1) dst[a.ldp] = s2;
+      }
+    }
+  }
+}
 
 template <int PREC, int EPI>
 __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
@@ -174,7 +302,25 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int S = a.total_ksteps;
+  int S = a.total_ksteps;
+  if constexpr (EPI == kEpiSplitK) {
+    // this block's K slice: skip s_begin steps (weights advance linearly, activations segment by segment)
+    const int s_begin = blockIdx.y * a.ksteps_per_slice;
+    const int s_end = min(S, s_begin + a.ksteps_per_slice);
+    for (int t = 0; t < s_begin; ++t) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        xp_hi[u] += kBK;
+        wp_hi[u] += kBK;
+        if constexpr (SPLIT) {
+          xp_lo[u] += kBK;
+          wp_lo[u] += kBK;
+        }
+      }
+      if (--seg_left == 0 && ld_seg + 1 < a.nseg) open_seg(++ld_seg);
+    }
+    S = s_end - s_begin;
+  }
   stage_loads(0);
   __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and orders the LDS writes
 
@@ -219,116 +365,310 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with this one
   }
 
-  // ---- epilogues ---------------------------------------------------------------------------
-  if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
-    // lane owns frames q*16 + fr_i (q = 0..3) x 16 contiguous columns ncol + p*4 + r
-    const int ncol = n0 + wave_n * 64 + fr_g * 16;
-    float bs[16], sc[16], of[16];
+  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// v2: 256x128x32 tile, 8 waves (4 along frames x 2 along columns, 64x64 each).
+//
+//  * Splice staged in LDS.  The K segments of a layer are grouped: consecutive Append() terms that read the same
+//    source at uniformly spaced time offsets (tdnn2: -2,0,2; tdnn3: -3,0,3; tdnn1: -2..2) form one group.  For a
+//    group the activation tile is fetched ONCE per 32-column K chunk as 272 rows (256 + 16 halo) and every time
+//    offset of the group reads its MFMA fragments from that tile at a row displacement - the spliced matrix never
+//    exists, and the L2->LDS traffic of the activations drops by the number of offsets (measured before this
+//    change: DMA-only 0.37 ms vs MFMA-only 0.33 ms per tdnn2 launch, i.e. the DMA path co-limited the kernel).
+//    The XOR swizzle of the 16-byte chunks is a function of the LDS row, so displaced reads stay conflict free.
+//  * LDS rings: activations 3 slots x 272 rows x 64 B x planes, weights 3 slots x 128 rows x 64 B x planes
+//    (150 KiB in split mode).  The LDS-DMA is issued from inline asm so that hipcc does not track it (it would
+//    put a vmcnt(0) in front of every ds_read that may alias a pending DMA); completion is counted by hand.
+//  * Ping-pong schedule: see the comment inside the kernel.
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_addr)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0_barrier() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int PREC, int EPI>
+__global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
+  constexpr bool SPLIT = (PREC == kPrecBf16x3);
+  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SWAP = (EPI != kEpiStats);
+  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int XROWS = 256 + 16;              // tile rows + halo for the time offsets of a group
+  constexpr int XT = XROWS * kBK * 2;          // 17 KiB: one activation plane slot
+  constexpr int WT = kTileBytes;               //  8 KiB: one 128-row weight plane slot
+  constexpr int XSLOT = NPL * XT;
+  constexpr int WSLOT = NPL * WT;
+  constexpr int WBASE = 3 * XSLOT;             // weight ring behind the activation ring
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave & 3;
+  const int wave_n = wave >> 2;
+
+  const int m_tiles = a.m_tiles >> 1;  // 256-row tiles
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int bslot = bid >> 3;
+  const int nt = bslot % a.n_tiles;
+  const int mt = (bslot / a.n_tiles) * 8 + xcd;
+  if (mt >= m_tiles) return;
+  const int m0 = mt * 256;
+  const int n0 = nt * kBN;
+
+  const int ld_row = lane >> 2;
+  const int ld_chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+
+  // weights: this wave stages 16-row chunk `wave` of the 128-row tile; per lane the row start is fixed and the
+  // K column of a step is a wave-uniform offset
+  const uint16_t* wrow_hi;
+  const uint16_t* wrow_lo;
+  {
+    const int rho = wave * 16 + ld_row;
+    const int wrow = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
+    const long off = (long)(n0 + wrow) * a.ldw + ld_chunk * 8;
+    wrow_hi = a.w_hi + off;
+    wrow_lo = SPLIT ? a.w_lo + off : nullptr;
+  }
+  const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
+
+  // ---- issue side: walks the K steps in the order  group -> K chunk -> time offset ------------------------------
+  int ig = 0, ikk = 0, ij = 0;        // group, 32-column chunk inside the group, offset index inside the group
+  int ixslot = 0, iwslot = 0;         // ring slots the next activation stage / weight stage go to
+  Grp gi = a.grp[0];
+  auto issue_step = [&]() -> int {    // returns the number of DMA instructions this wave issued
+    int n = 0;
+    if (ij == 0) {
+      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT);
+      const long col = (long)ikk * kBK + ld_chunk * 8;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const f32x4 b4 = *(const f32x4*)(a.bias + ncol + v * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bs[v * 4 + r] = b4[r];
+      for (int u = 0; u < 2; ++u) {
+        const int c = wave + 8 * u;
+        const long off = (long)(m0 + gi.shift0 + c * 16 + ld_row) * gi.ld + col;
+        glds16_asm(gi.hi + off, st + c * 1024);
+        if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + c * 1024);
+      }
+      n += 2 * NPL;
+      if (wave == 0) {  // halo rows 256..271
+        const long off = (long)(m0 + gi.shift0 + 256 + ld_row) * gi.ld + col;
+        glds16_asm(gi.hi + off, st + 16 * 1024);
+        if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + 16 * 1024);
+        n += NPL;
+      }
+      ixslot = ixslot == 2 ? 0 : ixslot + 1;
     }
-    if (a.bn) {
+    {
+      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
+      const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
+      glds16_asm(wrow_hi + wcol, st);
+      if constexpr (SPLIT) glds16_asm(wrow_lo + wcol, st + WT);
+      n += NPL;
+      iwslot = iwslot == 2 ? 0 : iwslot + 1;
+    }
+    if (++ij == gi.nshift) {
+      ij = 0;
+      if (++ikk == gi.ksteps) {
+        ikk = 0;
+        if (++ig < a.ngrp) gi = a.grp[ig];
+      }
+    }
+    return n;
+  };
+
+  // ---- read side ---------------------------------------------------------------------------------------------
+  int rg = 0, rkk = 0, rj = 0;
+  int rxslot = 0, rwslot = 0;
+  int r_nshift = gi.nshift, r_ksteps = gi.ksteps, r_dstep = gi.dstep;
+  const int fr_i = lane & 15;
+  const int fr_g = lane >> 4;
+  const int w_rd = (wave_n * 64 + fr_i) * 64 + (fr_g ^ ((4 - (fr_i >> 2)) & 3)) * 16;
+  struct Frags {
+    s16x8 xh[4], xl[4], wh[4], wl[4];
+  };
+  auto read_step = [&](Frags& f) {
+    const char* xs = smem + rxslot * XSLOT;
+    const char* ws = smem + WBASE + rwslot * WSLOT;
+    const int row = wave_m * 64 + fr_i + rj * r_dstep;  // displaced by the time offset of this step
+    const int x_rd = row * 64 + (fr_g ^ ((4 - ((row >> 2) & 3)) & 3)) * 16;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const f32x4 s4 = *(const f32x4*)(a.scale + ncol + v * 4);
-        const f32x4 o4 = *(const f32x4*)(a.offset + ncol + v * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sc[v * 4 + r] = s4[r];
-          of[v * 4 + r] = o4[r];
+    for (int i = 0; i < 4; ++i) {
+      f.xh[i] = *(const s16x8*)(xs + x_rd + i * 1024);
+      f.wh[i] = *(const s16x8*)(ws + w_rd + i * 1024);
+      if constexpr (SPLIT) {
+        f.xl[i] = *(const s16x8*)(xs + x_rd + XT + i * 1024);
+        f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
+      }
+    }
+    rwslot = rwslot == 2 ? 0 : rwslot + 1;
+    if (++rj == r_nshift) {
+      rj = 0;
+      rxslot = rxslot == 2 ? 0 : rxslot + 1;
+      if (++rkk == r_ksteps) {
+        rkk = 0;
+        if (++rg < a.ngrp) {
+          r_nshift = a.grp[rg].nshift;
+          r_ksteps = a.grp[rg].ksteps;
+          r_dstep = a.grp[rg].dstep;
         }
       }
-    } else {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        sc[v] = 1.f;
-        of[v] = 0.f;
-      }
     }
+  };
+
+  f32x4 acc[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = m0 + wave_m * 64 + q * 16 + fr_i;
-      float y[16];
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+    for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfmas = [&](const Frags& f) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + bs[p * 4 + r];
-          if (a.relu) z = fmaxf(z, 0.f);
-          if (a.bn) z = z * sc[p * 4 + r] + of[p * 4 + r];
-          y[p * 4 + r] = z;
-        }
-      if constexpr (EPI == kEpiF32) {
-        if (row < a.m_valid) {
-          float* dst = a.out_f32 + (long)row * a.ldf + ncol;
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            *(f32x4*)(dst + v * 4) = f32x4{y[v * 4], y[v * 4 + 1], y[v * 4 + 2], y[v * 4 + 3]};
-        }
-      } else {
-        unsigned int hw[8], lw[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-          const uint16_t h0 = to16<F16>(y[2 * v]);
-          const uint16_t h1 = to16<F16>(y[2 * v + 1]);
-          hw[v] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (SWAP) {
           if constexpr (SPLIT) {
-            const uint16_t l0 = to16<F16>(y[2 * v] - from16<F16>(h0));
-            const uint16_t l1 = to16<F16>(y[2 * v + 1] - from16<F16>(h1));
-            lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+            acc[p][q] = mfma16<F16>(f.wl[p], f.xh[q], acc[p][q]);
+            acc[p][q] = mfma16<F16>(f.wh[p], f.xl[q], acc[p][q]);
           }
-        }
-        uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
-        *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-        *(u32x4*)(dh + 8) = u32x4{hw[4], hw[5], hw[6], hw[7]};
-        if constexpr (SPLIT) {
-          uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
-          *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
-          *(u32x4*)(dl + 8) = u32x4{lw[4], lw[5], lw[6], lw[7]};
+          acc[p][q] = mfma16<F16>(f.wh[p], f.xh[q], acc[p][q]);
+        } else {
+          if constexpr (SPLIT) {
+            acc[p][q] = mfma16<F16>(f.xl[p], f.wh[q], acc[p][q]);
+            acc[p][q] = mfma16<F16>(f.xh[p], f.wl[q], acc[p][q]);
+          }
+          acc[p][q] = mfma16<F16>(f.xh[p], f.wh[q], acc[p][q]);
         }
       }
     }
-  } else {
-    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = n0 + wave_n * 64 + q * 16 + fr_i;
-      const float b = a.bias[col];
-      const float sc = a.bn ? a.scale[col] : 1.f;
-      const float of = a.bn ? a.offset[col] : 0.f;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int grp = (m0 + wave_m * 64 + p * 16) >> 4;
-        const int first = a.grp_range[2 * grp];
-        const int last = a.grp_range[2 * grp + 1];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + b;
-          if (a.relu) z = fmaxf(z, 0.f);
-          if (a.bn) z = z * sc + of;
-          const int rr = fr_g * 4 + r;
-          const bool ok = (rr >= first) && (rr < last);
-          s1 += ok ? z : 0.f;
-          s2 += ok ? z * z : 0.f;
-        }
-        s1 += __shfl_xor(s1, 16);
-        s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        float* dst = a.partial + (long)grp * 2 * a.ldp + col;
-        if (fr_g == 0) dst[0] = s1;
-        if (fr_g == 1) dst[a.ldp] = s2;
-      }
+  };
+
+  // Ping-pong schedule.  The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  A K
+  // step of a group is a LOAD segment (ds_read its fragments of step j, issue its share of the DMA of step j+2,
+  // wait until only that share is outstanding, i.e. its share of step j+1 has landed) and a COMPUTE segment (48 /
+  // 16 MFMAs), separated by workgroup barriers; group 1 runs one barrier interval behind group 0, so on every
+  // SIMD one wave is in its MFMA segment while its partner does the LDS / DMA issue work.
+  //   RAW: a share of step j+1 is waited for at the end of the owner's LOAD_j, which is followed by a barrier that
+  //        every reader passes before its LOAD_{j+1}.
+  //   WAR: the slots written for step j+2 were last read for step j-1 (weights) or earlier (activations); both
+  //        groups finished those reads (lgkmcnt(0) before their barrier) at least one barrier earlier.
+  // n = DMA instructions this wave may leave in flight: NPL (weights only), 3*NPL (+2 activation chunks), 4*NPL
+  // (wave 0, + halo chunk).
+  auto wait_and_barrier = [&](int n) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) through the builtin: hipcc's scoreboard then knows about it
+    if (n == 0) wait_vm_lgkm0_barrier<0>();
+    else if (n == NPL) wait_vm_lgkm0_barrier<NPL>();
+    else if (n == 3 * NPL) wait_vm_lgkm0_barrier<3 * NPL>();
+    else wait_vm_lgkm0_barrier<4 * NPL>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto plain_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int S = a.total_ksteps;
+  const int group = wave >> 2;
+  issue_step();
+  const int n1 = S > 1 ? issue_step() : 0;
+  wait_and_barrier(n1);              // every share of step 0 has landed
+  if (group == 1) plain_barrier();   // group 1 runs one barrier interval behind group 0
+  Frags f;
+  for (int j = 0; j < S; ++j) {
+    // ---- LOAD segment of step j
+    read_step(f);
+    const int n = (j + 2 < S) ? issue_step() : 0;
+    wait_and_barrier(n);
+    // ---- COMPUTE segment of step j
+    __builtin_amdgcn_s_setprio(1);
+    mfmas(f);
+    __builtin_amdgcn_s_setprio(0);
+    plain_barrier();
+  }
+  if (group == 0) plain_barrier();
+  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane);
+}
+
+// Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring.  XVEC_GEMM_VARIANT overrides.
+static int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("XVEC_GEMM_VARIANT");
+    v = (e && *e) ? atoi(e) : 2;
+    if (v != 1 && v != 2) v = 2;
+  }
+  return v;
+}
+
+// Groups consecutive K segments that read the same source at uniformly spaced time offsets (see the v2 kernel).
+static void build_groups(GemmArgs* g) {
+  g->ngrp = 0;
+  int wcol = 0;
+  for (int j = 0; j < g->nseg;) {
+    const Seg& s0 = g->seg[j];
+    Grp& G = g->grp[g->ngrp++];
+    G.hi = s0.hi;
+    G.lo = s0.lo;
+    G.ld = s0.ld;
+    G.ksteps = s0.ksteps;
+    G.nshift = 1;
+    G.shift0 = s0.row_shift;
+    G.dstep = 0;
+    G.wcol0 = wcol;
+    G.wstride = s0.ksteps * kBK;
+    int k = j + 1;
+    while (k < g->nseg && g->seg[k].hi == s0.hi && g->seg[k].lo == s0.lo && g->seg[k].ld == s0.ld &&
+           g->seg[k].ksteps == s0.ksteps) {
+      const int d = g->seg[k].row_shift - g->seg[k - 1].row_shift;
+      if (d <= 0 || (G.nshift > 1 && d != G.dstep) || g->seg[k].row_shift - s0.row_shift > 16) break;
+      G.dstep = d;
+      ++G.nshift;
+      ++k;
     }
+    wcol += G.nshift * G.wstride;
+    j = k;
   }
 }
 
 template <int PREC, int EPI>
+static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
+  constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
+  constexpr int lds = NPL * 3 * ((256 + 16) * kBK * 2 + kTileBytes);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel_v2<PREC, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int mt = a.m_tiles >> 1;
+  const int mt8 = (mt + 7) / 8 * 8;
+  dim3 grid(mt8 * a.n_tiles), block(512);
+  GemmArgs b = a;
+  build_groups(&b);
+  hipLaunchKernelGGL((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
+  return hipGetLastError();
+}
+
+template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+  if (gemm_variant() == 2 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
   constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
   constexpr int lds = kTileBytes * 2 * NPL * 2;
   static bool attr_done = false;
@@ -344,8 +684,76 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K reduction: out = epilogue(sum over K slices, in slice order, + bias).  One thread = 4 columns of a row.
+template <int PREC, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
+  constexpr bool SPLIT = (PREC == kPrecBf16x3);
+  constexpr bool F16 = (PREC == kPrecFp16);
+  const int n_pad = a.n_tiles * kBN;
+  const int rows = a.m_tiles * kBM;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = n_pad >> 2;
+  if (idx >= (long)rows * per_row) return;
+  const int row = (int)(idx / per_row);
+  const int col = (int)(idx - (long)row * per_row) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const long slab = (long)rows * n_pad;
+  for (int k = 0; k < a.ksplit; ++k) v += *(const f32x4*)(a.splitk_ws + k * slab + (long)row * n_pad + col);
+  const f32x4 b = *(const f32x4*)(a.bias + col);
+  float y[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float z = v[r] + b[r];
+    if (a.relu) z = fmaxf(z, 0.f);
+    if (a.bn) z = z * a.scale[col + r] + a.offset[col + r];
+    y[r] = z;
+  }
+  if constexpr (EPI == kEpiF32) {
+    if (row < a.m_valid) *(f32x4*)(a.out_f32 + (long)row * a.ldf + col) = f32x4{y[0], y[1], y[2], y[3]};
+  } else {
+    const uint16_t h0 = to16<F16>(y[0]), h1 = to16<F16>(y[1]), h2 = to16<F16>(y[2]), h3 = to16<F16>(y[3]);
+    unsigned int* dh = (unsigned int*)(a.out_hi + (long)row * a.ldo + col);
+    dh[0] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+    dh[1] = (unsigned int)h2 | ((unsigned int)h3 << 16);
+    if constexpr (SPLIT) {
+      const uint16_t l0 = to16<F16>(y[0] - from16<F16>(h0)), l1 = to16<F16>(y[1] - from16<F16>(h1));
+      const uint16_t l2 = to16<F16>(y[2] - from16<F16>(h2)), l3 = to16<F16>(y[3] - from16<F16>(h3));
+      unsigned int* dl = (unsigned int*)(a.out_lo + (long)row * a.ldo + col);
+      dl[0] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+      dl[1] = (unsigned int)l2 | ((unsigned int)l3 << 16);
+    }
+  }
+}
+
+template <int PREC, int EPI>
+static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
+  constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
+  constexpr int lds = kTileBytes * 2 * NPL * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, kEpiSplitK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int mt8 = (a.m_tiles + 7) / 8 * 8;
+  dim3 grid(mt8 * a.n_tiles, a.ksplit), block(256);
+  hipLaunchKernelGGL((tdnn_gemm_kernel<PREC, kEpiSplitK>), grid, block, lds, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const long total = (long)a.m_tiles * kBM * (a.n_tiles * kBN / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<PREC, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 template <int PREC>
 static hipError_t launch_prec(const GemmArgs& a, int epi, hipStream_t s) {
+  if (a.ksplit > 1 && a.splitk_ws) {
+    if (epi == kEpiAct) return launch_splitk<PREC, kEpiAct>(a, s);
+    if (epi == kEpiF32) return launch_splitk<PREC, kEpiF32>(a, s);
+    return hipErrorInvalidValue;
+  }
   switch (epi) {
     case kEpiAct: return launch_one<PREC, kEpiAct>(a, s);
     case kEpiF32: return launch_one<PREC, kEpiF32>(a, s);

@@ -1,0 +1,99 @@
+"""GPU tests of the drop-in command line, driven exactly the way the reference's script drives Kaldi's binary
+(egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:58-59,79,86-93): model through an `nnet3-copy ... |` pipe,
+features through an `ark:... |` pipe, `ark,scp:` output; results against the oracle, plus the log/exit contract."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import kaldi_io as kio
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(H.ROOT, H.PKG_NAME, "bin")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def job(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    net, line = H.synth_model("v2_xvector")
+    (d / "final.raw").write_bytes(net.to_bytes(True))
+    (d / "extract.config").write_text(line + "\n")
+    lens = [400, 0, 137, 20, 10, 1000, 25, 333]
+    utts = [("utt%03d" % i, H.features(700 + i, T) if T else np.zeros((0, 23), np.float32)) for i, T in enumerate(lens)]
+    kio.write_ark_matrices(str(d / "feats.ark"), utts, scp_path=str(d / "feats.scp"))
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    return d, utts, H.xo.GraphEvaluator(n2, np.float32)
+
+
+def _run(args, **kw):
+    return subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def test_cli_script_invocation_matches_oracle(job):
+    d, utts, ev = job
+    nnet = "%s/nnet3-copy --nnet-config=%s/extract.config %s/final.raw - |" % (BIN, d, d)
+    feat = "ark:%s/copy-feats scp:%s/feats.scp ark:- |" % (BIN, d)
+    ark, scp = d / "xvector_t.1.ark", d / "xvector_t.1.scp"
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=300",
+              nnet, feat, "ark,scp:%s,%s" % (ark, scp)])
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    got = dict(kio.read_scp(str(scp), "vector"))
+    fails = 0
+    for k, x in utts:
+        ref = H.xo.extract_xvector(ev, x, 300, 25, True)
+        if ref is None:
+            assert k not in got
+            fails += 1
+            continue
+        assert H.rel_err(got[k][None], ref[None]) < TOL, k
+    assert list(got) == [k for k, x in utts if H.xo.extract_xvector(ev, x, 300, 25, True) is not None]  # input order kept
+    assert "Done %d utterances, failed for %d" % (len(got), fails) in err
+    assert "WARNING" in err and "Zero-length utterance: utt001" in err
+    assert "real-time factor assuming 100 frames/sec" in err
+    assert "--use-gpu=no requested" in err      # accepted, reported, still on the GPU
+
+
+def test_cli_no_pad_input_and_text_output(job):
+    d, utts, ev = job
+    out = d / "x.txt"
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=yes", "--pad-input=false", "--min-chunk-size=25",
+              "--chunk-size=10000", "--output-node=tdnn6.affine", str(d / "final.raw"), "ark:%s/feats.ark" % d,
+              "ark,t:%s" % out])
+    assert r.returncode == 0, r.stderr.decode()
+    got = dict(kio.read_ark(str(out), "vector"))
+    for k, x in utts:
+        ref = H.xo.extract_xvector(ev, x, 10000, 25, False)
+        assert (k in got) == (ref is not None), k
+        if ref is not None:
+            assert H.rel_err(got[k][None], ref[None]) < TOL, k
+    assert "Minimum chunk size of 25 is greater than the number of rows in utterance: utt003" in r.stderr.decode()
+
+
+def test_cli_exit_status_when_nothing_succeeds(job):
+    d, utts, ev = job
+    kio.write_ark_matrices(str(d / "short.ark"), [("a", H.features(1, 5)), ("b", H.features(2, 9))])
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--pad-input=false", "--min-chunk-size=25",
+              "--output-node=tdnn6.affine", str(d / "final.raw"), "ark:%s/short.ark" % d, "ark:/dev/null"])
+    assert r.returncode == 1 and b"Done 0 utterances, failed for 2" in r.stderr
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--output-node=nosuch", str(d / "final.raw"),
+              "ark:%s/short.ark" % d, "ark:/dev/null"])
+    assert r.returncode == 255 and b"unknown node" in r.stderr
+
+
+def test_extract_table_through_the_c_abi(job):
+    d, utts, ev = job
+    P = H.pkg()
+    net, line = H.synth_model("v2_xvector")
+    ctx = P.Context(P.Model(raw=net.to_bytes(True), nnet_config=line))
+    done, failed = ctx.extract_table("scp:%s/feats.scp" % d, "ark,scp:%s/t.ark,%s/t.scp" % (d, d), 10000, 25, True)
+    assert (done, failed) == (7, 1)
+    got = dict(kio.read_scp(str(d / "t.scp"), "vector"))
+    for k, x in utts:
+        ref = H.xo.extract_xvector(ev, x, 10000, 25, True)
+        if ref is not None:
+            assert H.rel_err(got[k][None], ref[None]) < TOL, k

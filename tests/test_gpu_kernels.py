@@ -9,7 +9,7 @@ from helpers import pkg as _pkg
 
 pytestmark = pytest.mark.gpu
 
-HALO = 16
+HALO = 32   # the engine keeps 32 zero rows around every plane (kHalo)
 
 
 def _torch():
@@ -154,6 +154,19 @@ def test_gemm_stats_epilogue(prec):
     out, ref = _run_case(prec, 2, 256, 1536, [(0, 512, 0, 512)], relu=True, bn=True, seed=4)
     scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
     assert (np.abs(out - ref) / scale).max() < 3e-5
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_even_tile_count_uses_256_row_variant(prec, epi):
+    # 22 row tiles of 128 -> 11 tiles of 256 (not a multiple of 8 either); three K segments with shifts
+    out, ref = _run_case(prec, epi, 22 * 128, 256, [(0, 64, -3, 64), (0, 64, 0, 64), (1, 32, 3, 32)], relu=True, bn=True,
+                         seed=6)
+    if epi == 2:
+        scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+        assert (np.abs(out - ref) / scale).max() < 3e-5
+    else:
+        assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[prec] + (OUT_Q[prec] if epi == 0 else 0)
 
 
 def test_gemm_many_tiles_xcd_mapping():
