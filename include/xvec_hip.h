@@ -88,7 +88,13 @@ xv_status xv_ctx_info(const xv_ctx* c, xv_model_info_t* info, int32_t* precision
 /* One forward pass over a batch of B chunks (replaces RunNnetComputation for B chunks at once).
  * feats: packed rows [row_offsets[B]][input_dim] fp32; chunk b = rows row_offsets[b] .. row_offsets[b+1]-1;
  * out: [B][output_dim] fp32.  Every chunk must have >= min_frames rows (XV_ERR_ARG otherwise; nnet3
- * would refuse to compile the same request).  Host-buffer flavour: blocking. */
+ * would refuse to compile the same request).  Host-buffer flavour: blocking.
+ * Frame-level models (xv_model_info_t.output_is_segment == 0: the output node does not follow the statistics pooling,
+ * e.g. senone log-posteriors `output.log-softmax` or bottleneck features `tdnn5.batchnorm`; what the reference gets
+ * from `nnet3-compute`, sid/nnet3_cvector/cvector/extract_log_post.sh:77-84, sid/nnet3_cvector/am/extract_bn.sh:68):
+ * the output has ONE ROW PER INPUT FRAME - chunk b occupies rows row_offsets[b]..row_offsets[b+1]-1 of out, exactly
+ * like its features - the chunk being extended by replicating its first / last frame over the network's left / right
+ * context (nnet3-compute's edge behaviour); any chunk length >= 1 is accepted. */
 xv_status xv_forward_batch(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float* out);
 /* Device-buffer flavour: feats/out are device pointers on the context's GPU, row_offsets is a HOST array;
  * asynchronous on hip_stream (a hipStream_t, NULL = the context's own stream). out rows are out_ld apart. */

@@ -282,6 +282,18 @@ def extract_xvector(ev: GraphEvaluator, feats, chunk_size=-1, min_chunk_size=100
     return (avg / ev.dtype(tot)).astype(ev.dtype)
 
 
+def compute_all_frames(ev: GraphEvaluator, feats):
+    """Frame-level output for EVERY input frame, the way `nnet3-compute` produces it (reference call sites:
+    sid/nnet3_cvector/cvector/extract_log_post.sh:77-84, sid/nnet3_cvector/am/extract_bn.sh:68): frames the network
+    needs outside [0, T) are the first / last frame repeated [UPSTREAM Kaldi DecodableNnetSimple, recalled]."""
+    feats = np.asarray(feats)
+    left, right = ev.context()
+    padded = np.concatenate([np.repeat(feats[:1], left, axis=0), feats, np.repeat(feats[-1:], right, axis=0)], axis=0)
+    out = ev.compute(padded)
+    assert out.shape[0] == feats.shape[0]
+    return out
+
+
 # ------------------------------------------------------------------ synthetic data (SURVEY.md §8(d))
 def synthetic_features(i, T, dim=23):
     """Utterance i: N(0,1)*sigma_d, sigma_d = 8*0.9^d, seeded 20180101+i."""

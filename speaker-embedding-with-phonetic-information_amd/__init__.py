@@ -201,7 +201,9 @@ class Context:
         feats = np.ascontiguousarray(feats, dtype=np.float32)
         offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
         B = len(offs) - 1
-        out = np.empty((B, self.info.output_dim), dtype=np.float32)
+        # segment-level models: one row per chunk; frame-level models: one row per input frame
+        n_out = B if self.info.output_is_segment else int(offs[-1] - offs[0])
+        out = np.empty((n_out, self.info.output_dim), dtype=np.float32)
         _check(lib().xv_forward_batch(self._h, feats.ctypes.data, offs.ctypes.data, B, out.ctypes.data))
         return out
 

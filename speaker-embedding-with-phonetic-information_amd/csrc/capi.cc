@@ -174,7 +174,7 @@ xv_status xv_forward_batch(xv_ctx* c, const float* feats, const int32_t* row_off
   if (!c || !feats || !row_offsets || !out) return Fail(XV_ERR_ARG, "xv_forward_batch: null argument");
   return Guard([&] {
     for (int b = 0; b < B; ++b)
-      if (row_offsets[b + 1] - row_offsets[b] < c->eng->info().min_frames)
+      if (row_offsets[b + 1] - row_offsets[b] < (c->eng->frame_mode() ? 1 : c->eng->info().min_frames))
         return Fail(XV_ERR_ARG, "xv_forward_batch: chunk " + std::to_string(b) + " has fewer than min_frames rows");
     c->eng->ForwardHost(feats, row_offsets, B, out);
     return XV_OK;
@@ -186,7 +186,7 @@ xv_status xv_forward_batch_device(xv_ctx* c, const float* feats_dev, const int32
   if (!c || !feats_dev || !row_offsets || !out_dev) return Fail(XV_ERR_ARG, "xv_forward_batch_device: null argument");
   return Guard([&] {
     for (int b = 0; b < B; ++b)
-      if (row_offsets[b + 1] - row_offsets[b] < c->eng->info().min_frames)
+      if (row_offsets[b + 1] - row_offsets[b] < (c->eng->frame_mode() ? 1 : c->eng->info().min_frames))
         return Fail(XV_ERR_ARG, "xv_forward_batch_device: chunk " + std::to_string(b) + " has fewer than min_frames rows");
     if (out_ld < c->eng->info().output_dim) return Fail(XV_ERR_ARG, "xv_forward_batch_device: out_ld < output_dim");
     std::shared_ptr<xv::Engine::Plan> plan = c->eng->MakePlan(row_offsets, B);

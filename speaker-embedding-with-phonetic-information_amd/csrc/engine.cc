@@ -238,13 +238,19 @@ Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
   Check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     throw EngineError(std::string("kernels are built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
-  if (!info_.output_is_segment)
-    throw EngineError("frame-level outputs are not supported by this engine build (output must follow the pooling)");
-  if (info_.pooled_layer < 0) throw EngineError("model has no statistics pooling");
-  for (size_t i = 0; i < info_.layers.size(); ++i)
-    for (const LayerSource& s : info_.layers[i].src)
-      if (s.layer == info_.pooled_layer)
-        throw EngineError("the pooled layer must feed only the statistics pooling");
+  frame_mode_ = !info_.output_is_segment;
+  if (frame_mode_) {
+    // nnet3-compute semantics: every input frame gets an output row; the chunk is extended by edge replication
+    if (info_.pooled_layer >= 0) throw EngineError("a frame-level output that depends on statistics pooling is not supported");
+    pad_left_ = info_.left_context;
+    pad_right_ = info_.right_context;
+  } else {
+    if (info_.pooled_layer < 0) throw EngineError("model has no statistics pooling");
+    for (size_t i = 0; i < info_.layers.size(); ++i)
+      for (const LayerSource& s : info_.layers[i].src)
+        if (s.layer == info_.pooled_layer)
+          throw EngineError("the pooled layer must feed only the statistics pooling");
+  }
   nplanes_ = info_.precision == kPrecBf16x3 ? 2 : 1;
   Check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   {
@@ -301,6 +307,7 @@ Engine::~Engine() {
     fr(L.stats_lo);
     fr(L.out_f32);
     fr(L.splitk_ws);
+    fr(L.frame_f32);
     if (L.done) (void)hipEventDestroy(L.done);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
@@ -332,12 +339,16 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
         Ensure(&L.partial, (size_t)(rows / kRowAlign) * 2 * li.n_pad * 4, true);
         continue;
       }
+      if (frame_mode_ && (int)i == info_.output_layer) {
+        Ensure(&L.frame_f32, (size_t)rows * li.n_pad * 4, false);
+        continue;
+      }
       Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
       if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true);
     }
     L.cap_rows = rows;
   }
-  if (b_pad > L.cap_b) {
+  if (!frame_mode_ && b_pad > L.cap_b) {
     Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     Ensure(&L.stats_hi, (size_t)b_pad * stats_ld_ * 2, true);
     if (nplanes_ == 2) Ensure(&L.stats_lo, (size_t)b_pad * stats_ld_ * 2, true);
@@ -368,7 +379,7 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
   std::vector<int32_t> key(B);
   for (int b = 0; b < B; ++b) {
     key[b] = row_offsets[b + 1] - row_offsets[b];
-    if (key[b] < info_.min_frames) {
+    if (frame_mode_ ? key[b] < 1 : key[b] < info_.min_frames) {
       std::ostringstream m;
       m << "chunk " << b << " has " << key[b] << " frames; the network needs at least " << info_.min_frames;
       throw EngineError(m.str());
@@ -388,15 +399,28 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
   long off = 0;
   for (int b = 0; b < B; ++b) {
     dev_off[b] = (int32_t)off;
-    off += RoundUp(key[b], kRowAlign);
+    off += RoundUp(key[b] + pad_left_ + pad_right_, kRowAlign);
     if (off > (1l << 30)) throw EngineError("batch too large (more than 2^30 device rows)");
   }
   plan->rows = RoundUp((int)off, 2 * kBM);  // the 256-row GEMM variant needs an even number of 128-row tiles
   const int ngrp = plan->rows / kRowAlign;
   std::vector<int32_t> grp_utt(ngrp, -1), g0(B), g1(B), cnt(B);
   std::vector<int8_t> grp_range((size_t)ngrp * 2, 0);
-  const BlobLayerInfo& pl = info_.layers[info_.pooled_layer];
-  for (int b = 0; b < B; ++b) {
+  std::vector<int32_t> out_row;
+  if (frame_mode_) {
+    plan->out_off.assign(1, 0);
+    for (int b = 0; b < B; ++b) {
+      const int Td = key[b] + pad_left_ + pad_right_;
+      const int ga = dev_off[b] / kRowAlign, gb = (dev_off[b] + RoundUp(Td, kRowAlign)) / kRowAlign;
+      for (int g = ga; g < gb; ++g) grp_utt[g] = b;
+      // output frame i of the chunk is frame pad_left + i of the padded chunk
+      for (int i = 0; i < key[b]; ++i) out_row.push_back(dev_off[b] + pad_left_ + i);
+      plan->out_off.push_back((int32_t)out_row.size());
+    }
+    plan->n_out = (int)out_row.size();
+  }
+  const BlobLayerInfo& pl = info_.layers[frame_mode_ ? 0 : info_.pooled_layer];
+  for (int b = 0; b < B && !frame_mode_; ++b) {
     const int T = key[b];
     // frames of the pooled layer that exist, intersected with the pooling window of output index t=0
     const int first = std::max(pl.left, -info_.pool_left);
@@ -420,8 +444,10 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
   size_t o_g0 = Align256(o_gr + (size_t)ngrp * 2);
   size_t o_g1 = Align256(o_g0 + (size_t)B * 4);
   size_t o_cn = Align256(o_g1 + (size_t)B * 4);
-  size_t total = Align256(o_cn + (size_t)B * 4);
+  size_t o_or = Align256(o_cn + (size_t)B * 4);
+  size_t total = Align256(o_or + out_row.size() * 4);
   std::vector<uint8_t> host(total, 0);
+  if (!out_row.empty()) memcpy(host.data() + o_or, out_row.data(), out_row.size() * 4);
   memcpy(host.data() + o_src, plan->src_off.data(), (size_t)(B + 1) * 4);
   memcpy(host.data() + o_dev, dev_off.data(), (size_t)B * 4);
   memcpy(host.data() + o_gu, grp_utt.data(), (size_t)ngrp * 4);
@@ -439,6 +465,7 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
   plan->d_utt_grp0 = (const int32_t*)(d + o_g0);
   plan->d_utt_grp1 = (const int32_t*)(d + o_g1);
   plan->d_utt_count = (const int32_t*)(d + o_cn);
+  plan->d_out_row = (const int32_t*)(d + o_or);
   if (plan_cache_.size() >= 64) plan_cache_.clear();
   plan_cache_[key] = plan;
   return plan;
@@ -464,6 +491,8 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
   pa.ld = in_ld_;
   pa.out_hi = ActBase(L.in_hi, in_ld_);
   pa.out_lo = ActBase(L.in_lo, in_ld_);
+  pa.pad_left = pad_left_;
+  pa.pad_right = pad_right_;
   std::vector<hipEvent_t> prof_run;
   const bool first_prof = prof_on_ && prof_labels_.empty();
   if (prof_on_) ProfMark(s, &prof_run);
@@ -522,6 +551,11 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
         ga.partial = (float*)L.partial.p;
         ga.ldp = li.n_pad;
         ga.grp_range = plan.d_grp_range;
+      } else if (frame_mode_ && (int)i == info_.output_layer) {
+        epi = kEpiF32;
+        ga.out_f32 = (float*)L.frame_f32.p;
+        ga.ldf = li.n_pad;
+        ga.m_valid = plan.rows;
       } else {
         epi = kEpiAct;
         ga.out_hi = ActBase(L.act[i].act_hi, li.n_pad);
@@ -574,6 +608,30 @@ void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, i
     }
   }
   const BlobLayerInfo& ol = info_.layers[info_.output_layer];
+  if (frame_mode_) {
+    FrameOutArgs fo;
+    fo.src = (const float*)L.frame_f32.p;
+    fo.ld = ol.n_pad;
+    fo.out_row = plan.d_out_row;
+    fo.n_out = plan.n_out;
+    fo.dim = info_.output_dim;
+    fo.log_softmax = ol.log_softmax;
+    fo.out = out_dev;
+    fo.out_ld = out_ld;
+    Check(launch_frame_output(fo, s), "frame_output launch");
+  } else if (ol.log_softmax) {
+    // pooled output taken after a LogSoftmaxComponent (e.g. the speaker posteriors of the unedited x-vector net)
+    FrameOutArgs fo;
+    fo.src = (const float*)L.out_f32.p;
+    fo.ld = ol.n_pad;
+    fo.out_row = nullptr;
+    fo.n_out = plan.B;
+    fo.dim = info_.output_dim;
+    fo.log_softmax = 1;
+    fo.out = out_dev;
+    fo.out_ld = out_ld;
+    Check(launch_frame_output(fo, s), "frame_output launch");
+  } else
   Check(hipMemcpy2DAsync(out_dev, (size_t)out_ld * 4, L.out_f32.p, (size_t)ol.n_pad * 4, (size_t)info_.output_dim * 4,
                          (size_t)plan.B, hipMemcpyDeviceToDevice, s),
         "hipMemcpy2DAsync(out)");
@@ -616,7 +674,7 @@ void Engine::ForwardHost(const float* feats, const int32_t* row_offsets, int B, 
   Check(hipSetDevice(device_), "hipSetDevice");
   std::shared_ptr<Plan> plan = MakePlan(row_offsets, B);
   const size_t fbytes = (size_t)(row_offsets[B] - row_offsets[0]) * info_.input_dim * 4;
-  const size_t obytes = (size_t)B * info_.output_dim * 4;
+  const size_t obytes = (size_t)(frame_mode_ ? plan->n_out : B) * info_.output_dim * 4;
   if (feats_stage_.bytes < fbytes || out_stage_.bytes < obytes) Check(hipStreamSynchronize(stream_), "sync");
   Ensure(&feats_stage_, std::max(fbytes, (size_t)4), false);
   Ensure(&out_stage_, obytes, false);

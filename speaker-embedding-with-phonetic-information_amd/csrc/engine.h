@@ -59,8 +59,10 @@ class Engine {
   // feats_dev: packed fp32 rows [row_offsets[B]][input_dim] in device memory;
   // out_dev: [B][out_ld] fp32 (device).  Asynchronous on `stream` (nullptr = the engine's stream).
   void Forward(const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream);
-  // Host convenience: H2D, forward, D2H, synchronise.
+  // Host convenience: H2D, forward, D2H, synchronise.  Segment-level output: out is [B][output_dim]; frame-level
+  // output: out is [sum of chunk lengths][output_dim] (one row per input frame), chunk b starting at OutRowOffset.
   void ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out);
+  bool frame_mode() const { return frame_mode_; }
 
   hipStream_t stream() const { return stream_; }
   int num_lanes() const { return (int)lanes_.size(); }
@@ -94,7 +96,7 @@ class Engine {
     hipEvent_t done = nullptr;   // recorded at the end of every forward on this lane
     bool busy = false;
     std::vector<ActBuf> act;     // per layer
-    Buf in_hi, in_lo, partial, stats_hi, stats_lo, out_f32, splitk_ws;
+    Buf in_hi, in_lo, partial, stats_hi, stats_lo, out_f32, splitk_ws, frame_f32;
     int cap_rows = 0, cap_b = 0;
   };
   void Check(hipError_t e, const char* what) const;
@@ -104,6 +106,8 @@ class Engine {
 
   BlobInfo info_;
   int device_ = 0;
+  bool frame_mode_ = false;   // output is one row per input frame (nnet3-compute semantics), no pooling
+  int pad_left_ = 0, pad_right_ = 0;
   int nplanes_ = 1;
   hipStream_t stream_ = nullptr;
   void* d_blob_ = nullptr;
@@ -132,6 +136,10 @@ struct Engine::Plan {
   const int32_t* d_utt_grp0 = nullptr;
   const int32_t* d_utt_grp1 = nullptr;
   const int32_t* d_utt_count = nullptr;
+  // frame-level output mode: output row -> device row, and where each chunk's rows start in the packed output
+  const int32_t* d_out_row = nullptr;
+  std::vector<int32_t> out_off;  // [B+1]
+  int n_out = 0;
   ~Plan();
 };
 

@@ -110,6 +110,9 @@ struct PrepArgs {
   int ld;                   // plane leading dimension (multiple of kBK)
   uint16_t* out_hi;
   uint16_t* out_lo;
+  // frame-level outputs (nnet3-compute semantics): the chunk is extended by pad_left copies of its first frame and
+  // pad_right copies of its last one, so that every input frame gets an output row (0/0 for x-vector extraction)
+  int pad_left, pad_right;
 };
 hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s);
 
@@ -129,6 +132,20 @@ struct PoolArgs {
   int ld;
 };
 hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s);
+
+// Frame-level output: gathers the rows that correspond to input frames out of the [rows][ld] fp32 result of the last
+// GEMM into the caller's packed matrix, optionally applying LogSoftmaxComponent row-wise.
+struct FrameOutArgs {
+  const float* src;         // [device rows][ld]
+  int ld;
+  const int32_t* out_row;   // [n_out] device row of every output row
+  int n_out;
+  int dim;                  // output dimension (unpadded)
+  int log_softmax;
+  float* out;               // [n_out][out_ld]
+  int out_ld;
+};
+hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s);
 
 // 16-bit helpers shared by host packing code (round-to-nearest-even, like v_cvt_pk_bf16_f32).
 uint16_t host_f32_to_bf16(float x);

@@ -75,9 +75,14 @@ __device__ __forceinline__ float from16(uint16_t u) {
   }
 }
 
-// swap bit fields [5:4] and [3:2] of a 6-bit index (an involution)
-__device__ __forceinline__ int swap_fields(int x) {
-  return ((x & 0x30) >> 2) | ((x & 0x0c) << 2) | (x & 3);
+// Weight-row permutation of the "weights as MFMA A operand" orientation.  LDS row rho = p*16 + g*4 + r of a wave's
+// 64-row slice (p = 16-row fragment, g = lane>>4, r = accumulator register) holds weight row
+//   n = (p>>1)*32 + g*8 + (p&1)*4 + r,
+// so the lane with lane>>4 == g ends up with output columns g*8..g*8+7 of each 32-column half: 16 contiguous bytes
+// per plane per store, and the four lane groups of a store instruction cover 64 contiguous bytes of a row.
+__device__ __forceinline__ int swap_fields(int rho) {
+  const int p = (rho >> 4) & 3, g = (rho >> 2) & 3, r = rho & 3;
+  return ((p >> 1) << 5) | (g << 3) | ((p & 1) << 2) | r;
 }
 
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
@@ -94,40 +99,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
   // ---- epilogues ---------------------------------------------------------------------------
   if constexpr (EPI == kEpiSplitK) {
     // raw accumulators of this K slice (bias / ReLU / BatchNorm are applied by splitk_reduce_kernel)
-    const int ncol = nbase + fr_g * 16;
     float* ws = a.splitk_ws + (long)blockIdx.y * ((long)a.m_tiles * kBM) * ((long)a.n_tiles * kBN);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float* dst = ws + (long)(mbase + q * 16 + fr_i) * ((long)a.n_tiles * kBN) + ncol;
+      float* dst = ws + (long)(mbase + q * 16 + fr_i) * ((long)a.n_tiles * kBN) + nbase + fr_g * 8;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) *(f32x4*)(dst + p * 4) = acc[p][q];
+      for (int p = 0; p < 4; ++p) *(f32x4*)(dst + (p >> 1) * 32 + (p & 1) * 4) = acc[p][q];
     }
   } else if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
-    // lane owns frames q*16 + fr_i (q = 0..3) x 16 contiguous columns ncol + p*4 + r
-    const int ncol = nbase + fr_g * 16;
+    // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
+    // h = p>>1, position inside the group (p&1)*4 + r
+    const int ncol = nbase + fr_g * 8;
     float bs[16], sc[16], of[16];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const f32x4 b4 = *(const f32x4*)(a.bias + ncol + v * 4);
+    for (int p = 0; p < 4; ++p) {
+      const int c = ncol + (p >> 1) * 32 + (p & 1) * 4;
+      const f32x4 b4 = *(const f32x4*)(a.bias + c);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[v * 4 + r] = b4[r];
-    }
-    if (a.bn) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const f32x4 s4 = *(const f32x4*)(a.scale + ncol + v * 4);
-        const f32x4 o4 = *(const f32x4*)(a.offset + ncol + v * 4);
+      for (int r = 0; r < 4; ++r) bs[p * 4 + r] = b4[r];
+      if (a.bn) {
+        const f32x4 s4 = *(const f32x4*)(a.scale + c);
+        const f32x4 o4 = *(const f32x4*)(a.offset + c);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sc[v * 4 + r] = s4[r];
-          of[v * 4 + r] = o4[r];
+          sc[p * 4 + r] = s4[r];
+          of[p * 4 + r] = o4[r];
         }
-      }
-    } else {
+      } else {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        sc[v] = 1.f;
-        of[v] = 0.f;
+        for (int r = 0; r < 4; ++r) {
+          sc[p * 4 + r] = 1.f;
+          of[p * 4 + r] = 0.f;
+        }
       }
     }
 #pragma unroll
@@ -147,8 +150,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         if (row < a.m_valid) {
           float* dst = a.out_f32 + (long)row * a.ldf + ncol;
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            *(f32x4*)(dst + v * 4) = f32x4{y[v * 4], y[v * 4 + 1], y[v * 4 + 2], y[v * 4 + 3]};
+          for (int p = 0; p < 4; ++p)
+            *(f32x4*)(dst + (p >> 1) * 32 + (p & 1) * 4) = f32x4{y[p * 4], y[p * 4 + 1], y[p * 4 + 2], y[p * 4 + 3]};
         }
       } else {
         unsigned int hw[8], lw[8];
@@ -163,13 +166,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
           }
         }
+        // y[0..7] = columns ncol..ncol+7, y[8..15] = columns ncol+32..ncol+39
         uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
         *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-        *(u32x4*)(dh + 8) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+        *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
         if constexpr (SPLIT) {
           uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
           *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
-          *(u32x4*)(dl + 8) = u32x4{lw[4], lw[5], lw[6], lw[7]};
+          *(u32x4*)(dl + 32) = u32x4{lw[4], lw[5], lw[6], lw[7]};
         }
       }
     }
@@ -789,7 +793,11 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
   if (u >= 0) {
     const int t = row - a.dev_off[u];
     const int len = a.src_off[u + 1] - a.src_off[u];
-    if (t < len) src = a.feats + (long)(a.src_off[u] + t) * a.dim;
+    if (t < len + a.pad_left + a.pad_right) {
+      // edge replication (frame-level outputs): device frame t is source frame clamp(t - pad_left, 0, len-1)
+      const int ts = min(max(t - a.pad_left, 0), len - 1);
+      src = a.feats + (long)(a.src_off[u] + ts) * a.dim;
+    }
   }
   unsigned int hw[4], lw[4];
 #pragma unroll
@@ -821,6 +829,42 @@ hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s) {
     case kPrecFp16: hipLaunchKernelGGL(prep_input_kernel<kPrecFp16>, grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame_output: one workgroup per output row.  LogSoftmaxComponent: y = x - max - log(sum exp(x - max)).
+__global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a) {
+  const int o = blockIdx.x;
+  const float* src = a.src + (long)(a.out_row ? a.out_row[o] : o) * a.ld;
+  float* dst = a.out + (long)o * a.out_ld;
+  const int tid = threadIdx.x;
+  if (!a.log_softmax) {
+    for (int c = tid; c < a.dim; c += 256) dst[c] = src[c];
+    return;
+  }
+  __shared__ float red[4];
+  float m = -INFINITY;
+  for (int c = tid; c < a.dim; c += 256) m = fmaxf(m, src[c]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < a.dim; c += 256) sum += expf(src[c] - m);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+  for (int c = tid; c < a.dim; c += 256) dst[c] = src[c] - lse;
+}
+
+hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s) {
+  if (a.n_out <= 0) return hipSuccess;
+  hipLaunchKernelGGL(frame_output_kernel, dim3(a.n_out), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

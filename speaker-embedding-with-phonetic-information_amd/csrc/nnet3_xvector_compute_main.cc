@@ -32,7 +32,9 @@
 
 namespace {
 
-const char* kProg = "nnet3-xvector-compute";
+const char* kProg = "nnet3-xvector-compute";  // or "nnet3-compute" (same source, frame-level job), see main()
+bool g_frame_job = false;
+bool g_apply_exp = false;
 int g_verbose = 0;
 
 void LogLine(const char* level, int line, const std::string& msg) {
@@ -155,6 +157,11 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
       *err = "invalid boolean for --print-args: " + value;
       return false;
     }
+  } else if (name == "apply-exp") {
+    if (!ParseBool(value, &g_apply_exp)) {
+      *err = "invalid boolean for --apply-exp: " + value;
+      return false;
+    }
   } else if (name == "output-node") o->output_node = value;
   else if (name == "nnet-config") o->nnet_config = value;
   else if (name == "precision") o->precision = value;
@@ -180,6 +187,14 @@ int JobIndexFromWspecifier(const std::string& w) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  {
+    // one source, two drop-ins: invoked as `nnet3-compute` it does the frame-level job (a matrix per utterance)
+    const char* base = strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0];
+    if (strcmp(base, "nnet3-compute") == 0) {
+      g_frame_job = true;
+      kProg = "nnet3-compute";
+    }
+  }
   try {
     Options opt;
     std::vector<std::string> pos;
@@ -242,8 +257,10 @@ int main(int argc, char** argv) {
     if (!opt.output_node.empty()) net.ApplyNnetConfig("output-node name=output input=" + opt.output_node);
     xv::TdnnProgram prog = xv::LowerToProgram(net, "output");
     if (g_verbose >= 1) XLOG("lowered model:\n" << prog.Describe());
-    if (!prog.output_is_segment)
+    if (!g_frame_job && !prog.output_is_segment)
       throw xv::KioError("the output node is frame-level; nnet3-xvector-compute expects a pooled (x-vector) output");
+    if (g_frame_job && prog.output_is_segment)
+      throw xv::KioError("the output node follows the statistics pooling; nnet3-compute expects a frame-level output");
 
     // ---- device --------------------------------------------------------------------------------
     int ndev = 0;
@@ -262,6 +279,15 @@ int main(int argc, char** argv) {
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
                    << opt.precision << ", " << (engine.weight_bytes() >> 20) << " MiB of packed weights");
 
+    if (g_frame_job) {
+      xv::TableExtractResult fr = xv::RunTableCompute(
+          &engine, opt.batch_frames, g_apply_exp, feat_rspec, vec_wspec,
+          [](const char* level, const std::string& m) { LogLine(level, 0, m); });
+      XLOG("Time taken " << fr.seconds << "s: real-time factor assuming 100 frames/sec is "
+                         << (fr.seconds * 100.0 / std::max(fr.frames, 1.0)));
+      XLOG("Done " << fr.num_success << " utterances, failed for " << fr.num_fail);
+      return fr.num_success != 0 ? 0 : 1;
+    }
     // ---- the utterance loop (reader thread -> batches -> device -> ark,scp writer) ---------------------------
     xv::ExtractOptions eo;
     eo.chunk_size = opt.chunk_size;

@@ -1,6 +1,7 @@
 // Table-driven extraction loop.  See table_extract.h.
 #include "table_extract.h"
 
+#include <math.h>
 #include <string.h>
 
 #include <chrono>
@@ -141,6 +142,78 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   if (!fatal.empty()) throw std::runtime_error(fatal);
   if (!reader_error.empty()) throw KioError(reader_error);
   res.num_fail += num_fail_read;
+  res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return res;
+}
+
+TableExtractResult RunTableCompute(Engine* engine, int max_batch_rows, bool apply_exp, const std::string& feat_rspec,
+                                   const std::string& mat_wspec, const LogFn& log) {
+  TableExtractResult res;
+  if (!engine->frame_mode()) throw EngineError("nnet3-compute needs a frame-level output node (this one follows the pooling)");
+  const int D = engine->info().input_dim, E = engine->info().output_dim;
+  TableWriter writer(mat_wspec);
+  SequentialMatrixReader rd(feat_rspec);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<Utt> batch;
+  std::vector<float> packed, out;
+  std::vector<int32_t> offs;
+  long rows = 0;
+  auto flush = [&]() {
+    if (batch.empty()) return;
+    packed.resize((size_t)rows * D);
+    offs.assign(1, 0);
+    size_t r = 0;
+    for (const Utt& u : batch) {
+      memcpy(&packed[r * D], u.feats.data.data(), (size_t)u.feats.rows * D * 4);
+      r += u.feats.rows;
+      offs.push_back((int32_t)r);
+    }
+    out.resize((size_t)rows * E);
+    engine->ForwardHost(packed.data(), offs.data(), (int)batch.size(), out.data());
+    for (size_t i = 0; i < batch.size(); ++i) {
+      Matrix m;
+      m.rows = batch[i].feats.rows;
+      m.cols = E;
+      m.data.assign(out.begin() + (size_t)offs[i] * E, out.begin() + (size_t)offs[i + 1] * E);
+      if (apply_exp)
+        for (float& v : m.data) v = expf(v);
+      writer.WriteMat(batch[i].key, m);
+      res.frames += m.rows;
+      ++res.num_success;
+    }
+    batch.clear();
+    rows = 0;
+  };
+  std::string key, e;
+  Matrix m;
+  while (rd.Next(&key, &m, &e)) {
+    if (!e.empty()) {
+      log("WARNING", "failed to read features for " + key + ": " + e);
+      ++res.num_fail;
+      continue;
+    }
+    if (m.rows == 0) {
+      log("WARNING", "Zero-length utterance: " + key);
+      ++res.num_fail;
+      continue;
+    }
+    if (m.cols != D) {
+      std::ostringstream s;
+      s << "feature dimension " << m.cols << " of utterance " << key << " does not match the model's " << D;
+      log("WARNING", s.str());
+      ++res.num_fail;
+      continue;
+    }
+    Utt u;
+    u.key = key;
+    u.feats = std::move(m);
+    rows += u.feats.rows;
+    batch.push_back(std::move(u));
+    if (rows >= max_batch_rows) flush();
+  }
+  flush();
+  res.reader_status = rd.Close();
+  writer.Close();
   res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return res;
 }

@@ -25,4 +25,10 @@ typedef std::function<void(const char* level, const std::string& msg)> LogFn;
 TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
                                       const std::string& vector_wspecifier, const LogFn& log);
 
+// nnet3-compute style job: one output MATRIX per utterance (a row per input frame) from a frame-level model
+// (reference call sites: sid/nnet3_cvector/cvector/extract_log_post.sh:77-84, sid/nnet3_cvector/am/extract_bn.sh:68,
+// steps/nnet3/make_bottleneck_features_new.sh:109).  apply_exp turns log-posteriors into posteriors (--apply-exp).
+TableExtractResult RunTableCompute(Engine* engine, int max_batch_rows, bool apply_exp, const std::string& feature_rspecifier,
+                                   const std::string& matrix_wspecifier, const LogFn& log);
+
 }  // namespace xv

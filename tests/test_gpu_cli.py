@@ -97,3 +97,27 @@ def test_extract_table_through_the_c_abi(job):
         ref = H.xo.extract_xvector(ev, x, 10000, 25, True)
         if ref is not None:
             assert H.rel_err(got[k][None], ref[None]) < TOL, k
+
+
+def test_nnet3_compute_cli_frame_level(tmp_path):
+    """`nnet3-compute` drop-in (sid/nnet3_cvector/am/extract_bn.sh:68 style): bottleneck features of the AM net."""
+    net = H.nm.synthesize([H.config_text("am")], seed=21, head_stddev=1.0)
+    (tmp_path / "am.raw").write_bytes(net.to_bytes(True))
+    utts = [("u%d" % i, H.features(800 + i, T)) for i, T in enumerate([120, 7, 333])]
+    kio.write_ark_matrices(str(tmp_path / "f.ark"), utts)
+    r = _run([os.path.join(BIN, "nnet3-compute"), "--use-gpu=no", "--output-node=tdnn5.batchnorm", str(tmp_path / "am.raw"),
+              "ark:%s/f.ark" % tmp_path, "ark,scp:%s/bn.ark,%s/bn.scp" % (tmp_path, tmp_path)])
+    assert r.returncode == 0, r.stderr.decode()
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config("output-node name=output input=tdnn5.batchnorm")
+    ev = H.xo.GraphEvaluator(n2, np.float32)
+    got = dict(kio.read_scp(str(tmp_path / "bn.scp")))
+    for k, x in utts:
+        ref = H.xo.compute_all_frames(ev, x)
+        assert got[k].shape == ref.shape == (x.shape[0], 128)
+        assert H.rel_err(got[k], ref) < TOL, k
+    assert b"Done 3 utterances, failed for 0" in r.stderr
+    # an x-vector (pooled) output is refused by nnet3-compute, and a frame-level one by nnet3-xvector-compute
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--output-node=tdnn5.batchnorm", str(tmp_path / "am.raw"),
+              "ark:%s/f.ark" % tmp_path, "ark:/dev/null"])
+    assert r.returncode == 255 and b"frame-level" in r.stderr

@@ -1,0 +1,78 @@
+"""GPU parity tests of frame-level outputs (what the reference obtains from `nnet3-compute`): senone log-posteriors of
+the AM / multitask heads and bottleneck features, one output row per input frame with edge-frame replication."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _case(cfgs, out_node, head_stddev=1.0, seed=11):
+    P = H.pkg()
+    net = H.nm.synthesize([H.config_text(c) for c in cfgs], seed=seed, head_stddev=head_stddev)
+    line = "output-node name=output input=%s" % out_node
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    assert model.info.output_is_segment == 0
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    return P, model, H.xo.GraphEvaluator(n2, np.float32)
+
+
+@pytest.mark.parametrize("cfgs,node,dim", [
+    (["am"], "output.log-softmax", 5139),                 # train_am.sh:31-37 senone head (fixture: 5139 targets)
+    (["am"], "tdnn5.batchnorm", 128),                     # extract_bn.sh: 128-d phonetic bottleneck features
+    (["v3_multitask"], "output_am.log-softmax", 3856),    # config 5: multitask senone head
+    (["v3_multitask"], "tdnn4_xvec.batchnorm", 512),      # an inner frame-level node
+])
+def test_frame_level_parity(cfgs, node, dim):
+    P, model, ev = _case(cfgs, node)
+    assert model.info.output_dim == dim
+    ctx = P.Context(model, precision=P.PREC_BF16X3)
+    lens = [200, 1, 37, 600, 16]
+    utts = [H.features(40 + i, T) for i, T in enumerate(lens)]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    assert out.shape == (sum(lens), dim)
+    for i, u in enumerate(utts):
+        ref = H.xo.compute_all_frames(ev, u)
+        got = out[offs[i]:offs[i + 1]]
+        if node.endswith("log-softmax"):
+            # log-posteriors (values of order -100 with these synthetic heads): relative to the row's largest magnitude,
+            # and each row must still be a normalised distribution
+            assert H.rel_err(got, ref) < TOL, (i, H.rel_err(got, ref))
+            assert np.abs(np.exp(got.astype(np.float64)).sum(axis=1) - 1).max() < 1e-3
+        else:
+            assert H.rel_err(got, ref) < TOL, (i, H.rel_err(got, ref))
+
+
+def test_frame_level_fp16_mode_config5():
+    # BASELINE config 5: multitask net incl. senone head, fp16 MFMA, variable-length 200-600 frame chunks
+    P, model, ev = _case(["v3_multitask"], "output_am.log-softmax")
+    ctx = P.Context(model, precision=P.PREC_FP16)
+    rng = np.random.default_rng(5)
+    lens = [int(t) for t in rng.integers(200, 601, 6)]
+    utts = [H.features(90 + i, T) for i, T in enumerate(lens)]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    ref = np.concatenate([H.xo.compute_all_frames(ev, u) for u in utts])
+    # single-pass fp16: not the parity mode; bound loosely, the measured value is what bench reports
+    assert H.rel_err(out, ref) < 5e-3
+    assert (out.argmax(1) == ref.argmax(1)).mean() > 0.97
+
+
+def test_pooled_log_softmax_output():
+    # the unedited x-vector net: speaker log-posteriors after tdnn7 (pooled, LogSoftmax over 5139 classes)
+    P = H.pkg()
+    net = H.nm.synthesize(H.config_text("v2_xvector"), seed=3, head_stddev=1.0)
+    model = P.Model(raw=net.to_bytes(True))
+    assert model.info.output_is_segment == 1 and model.info.output_dim == 5139
+    ctx = P.Context(model)
+    ev = H.xo.GraphEvaluator(net, np.float32)
+    utts = [H.features(70 + i, T) for i, T in enumerate([300, 150])]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    ref = np.stack([ev.compute(u)[0] for u in utts])
+    assert H.rel_err(out, ref) < TOL
+    assert np.abs(np.exp(out.astype(np.float64)).sum(axis=1) - 1).max() < 1e-3
