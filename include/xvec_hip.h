@@ -126,6 +126,14 @@ xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char
                            int32_t min_chunk_size, int32_t pad_input, int32_t batch_frames, int64_t* num_done,
                            int64_t* num_failed);
 
+/* Feature front-end on the device (the two pipe stages of extract_xvectors_new.sh:79): sliding-window cepstral mean
+ * subtraction (`apply-cmvn-sliding --norm-vars=false --center=<center> --cmn-window=<cmn_window>`; cmn_window <= 0: none)
+ * over each whole utterance, then `select-voiced-frames` with vad[r] != 0 (vad: one float per raw row, NULL = keep
+ * all).  raw: packed rows, utterance u = rows raw_off[u]..raw_off[u+1]-1; out receives the kept rows (capacity >= the
+ * number of raw rows), out_off[n_utts+1] their offsets.  Host buffers, blocking. */
+xv_status xv_frontend_cmvn_select(xv_ctx* c, const float* raw, const int32_t* raw_off, int32_t n_utts, const float* vad,
+                                  int32_t cmn_window, int32_t center, float* out, int32_t* out_off);
+
 /* Host-only: the chunk list nnet3-xvector-compute would build for one utterance of num_rows frames
  * (SURVEY.md App. B.5).  Arrays of capacity `cap` receive per chunk: first source row, frames taken (= averaging
  * weight), copies of the first / last frame added by --pad-input.  *n_chunks = number of chunks; returns XV_ERR_ARG

@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "xv_model_macs", "xv_model_describe", "xv_model_pack", "xv_ctx_create", "xv_ctx_create_from_blob", "xv_ctx_free",
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances",
-    "xv_extract_table", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
+    "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
 ]
 
 _lib = None
@@ -229,6 +229,22 @@ class Context:
             label, calls, ms = line.split("\t")
             rows.append((label, int(calls), float(ms)))
         return rows
+
+    def frontend(self, raw, raw_offsets, vad=None, cmn_window=300, center=True):
+        """apply-cmvn-sliding (norm-vars=false) + select-voiced-frames on the device.  Returns (feats, offsets)."""
+        import numpy as np
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        offs = np.ascontiguousarray(raw_offsets, dtype=np.int32)
+        n = len(offs) - 1
+        out = np.empty_like(raw)
+        out_off = np.zeros(n + 1, dtype=np.int32)
+        v = None if vad is None else np.ascontiguousarray(vad, dtype=np.float32)
+        L = lib()
+        L.xv_frontend_cmvn_select.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        _check(L.xv_frontend_cmvn_select(self._h, raw.ctypes.data, offs.ctypes.data, n, None if v is None else v.ctypes.data,
+                                         cmn_window, 1 if center else 0, out.ctypes.data, out_off.ctypes.data))
+        return out[:out_off[-1]], out_off
 
     def extract_table(self, feature_rspecifier, vector_wspecifier, chunk_size=-1, min_chunk_size=100, pad_input=True,
                       batch_frames=0):

@@ -1,5 +1,6 @@
 // extern "C" boundary of libxvec_hip.so - see include/xvec_hip.h.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -249,12 +250,34 @@ xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char
     opt.min_chunk_size = min_chunk_size;
     opt.pad_input = pad_input != 0;
     if (batch_frames > 0) opt.max_batch_rows = batch_frames;
+    if (getenv("XVEC_CMN_WINDOW")) opt.cmn_window = atoi(getenv("XVEC_CMN_WINDOW"));
+    if (getenv("XVEC_VAD_RSPECIFIER")) opt.vad_rspecifier = getenv("XVEC_VAD_RSPECIFIER");
     xv::TableExtractResult r = xv::RunTableExtraction(
         c->eng.get(), opt, feature_rspecifier, vector_wspecifier, [](const char* level, const std::string& m) {
           fprintf(stderr, "%s (xvec_hip:xv_extract_table) %s\n", level, m.c_str());
         });
     if (num_done) *num_done = r.num_success;
     if (num_failed) *num_failed = r.num_fail;
+    return XV_OK;
+  });
+}
+
+xv_status xv_frontend_cmvn_select(xv_ctx* c, const float* raw, const int32_t* raw_off, int32_t n_utts, const float* vad,
+                                  int32_t cmn_window, int32_t center, float* out, int32_t* out_off) {
+  if (!c || !raw || !raw_off || !out || !out_off || n_utts < 0) return Fail(XV_ERR_ARG, "xv_frontend_cmvn_select: bad argument");
+  return Guard([&] {
+    std::vector<int32_t> sel_row, sel_utt;
+    out_off[0] = 0;
+    for (int u = 0; u < n_utts; ++u) {
+      for (int32_t r = raw_off[u]; r < raw_off[u + 1]; ++r)
+        if (!vad || vad[r] != 0.f) {
+          sel_row.push_back(r);
+          sel_utt.push_back(u);
+        }
+      out_off[u + 1] = (int32_t)sel_row.size();
+    }
+    c->eng->FrontEndHost(raw, raw_off, n_utts, sel_row.data(), sel_utt.data(), (int)sel_row.size(), cmn_window, center != 0,
+                         100, out);
     return XV_OK;
   });
 }

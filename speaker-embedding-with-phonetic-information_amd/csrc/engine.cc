@@ -312,6 +312,10 @@ Engine::~Engine() {
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   fr(feats_stage_);
+  fr(fe_raw_);
+  fr(fe_tab_);
+  fr(fe_prefix_);
+  fr(fe_out_);
   fr(out_stage_);
   if (d_blob_) (void)hipFree(d_blob_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -668,6 +672,43 @@ std::string Engine::ProfileReport() {
   for (size_t i = 0; i < tot.size(); ++i) o << prof_labels_[i] << "\t" << prof_runs_.size() << "\t" << tot[i] << "\n";
   prof_runs_.clear();
   return o.str();
+}
+
+void Engine::FrontEndHost(const float* raw, const int32_t* raw_off, int n_utts, const int32_t* sel_row,
+                          const int32_t* sel_utt, int n_out, int cmn_window, bool center, int min_window, float* out) {
+  Check(hipSetDevice(device_), "hipSetDevice");
+  if (n_out <= 0) return;
+  const int D = info_.input_dim;
+  const long raw_rows = raw_off[n_utts];
+  Check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  Ensure(&fe_raw_, (size_t)raw_rows * D * 4, false);
+  Ensure(&fe_prefix_, (size_t)(raw_rows + n_utts) * D * 8, false);
+  Ensure(&fe_out_, (size_t)n_out * D * 4, false);
+  const size_t o_off = 0, o_row = Align256((size_t)(n_utts + 1) * 4), o_utt = Align256(o_row + (size_t)n_out * 4);
+  const size_t tab = Align256(o_utt + (size_t)n_out * 4);
+  Ensure(&fe_tab_, tab, false);
+  std::vector<uint8_t> host(tab, 0);
+  memcpy(host.data() + o_off, raw_off, (size_t)(n_utts + 1) * 4);
+  memcpy(host.data() + o_row, sel_row, (size_t)n_out * 4);
+  memcpy(host.data() + o_utt, sel_utt, (size_t)n_out * 4);
+  Check(hipMemcpyAsync(fe_tab_.p, host.data(), tab, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(front-end tables)");
+  Check(hipMemcpyAsync(fe_raw_.p, raw, (size_t)raw_rows * D * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(raw feats)");
+  FrontEndArgs fa;
+  fa.raw = (const float*)fe_raw_.p;
+  fa.raw_off = (const int32_t*)((const uint8_t*)fe_tab_.p + o_off);
+  fa.prefix = (double*)fe_prefix_.p;
+  fa.n_utts = n_utts;
+  fa.dim = D;
+  fa.sel_row = (const int32_t*)((const uint8_t*)fe_tab_.p + o_row);
+  fa.sel_utt = (const int32_t*)((const uint8_t*)fe_tab_.p + o_utt);
+  fa.n_out = n_out;
+  fa.cmn_window = cmn_window;
+  fa.center = center ? 1 : 0;
+  fa.min_window = min_window;
+  fa.out = (float*)fe_out_.p;
+  Check(launch_frontend(fa, stream_), "front-end launch");
+  Check(hipMemcpyAsync(out, fe_out_.p, (size_t)n_out * D * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(front-end out)");
+  Check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
 void Engine::ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out) {

@@ -63,6 +63,10 @@ class Engine {
   // output: out is [sum of chunk lengths][output_dim] (one row per input frame), chunk b starting at OutRowOffset.
   void ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out);
   bool frame_mode() const { return frame_mode_; }
+  // Feature front-end on the device: sliding-window CMN (cmn_window <= 0: none) + selection of the rows listed in
+  // sel_row (absolute raw rows, ascending; sel_utt = their utterance).  Host buffers in / out, blocking.
+  void FrontEndHost(const float* raw, const int32_t* raw_off, int n_utts, const int32_t* sel_row, const int32_t* sel_utt,
+                    int n_out, int cmn_window, bool center, int min_window, float* out);
 
   hipStream_t stream() const { return stream_; }
   int num_lanes() const { return (int)lanes_.size(); }
@@ -118,6 +122,7 @@ class Engine {
   std::vector<Lane> lanes_;
   size_t next_lane_ = 0;
   Buf feats_stage_, out_stage_;
+  Buf fe_raw_, fe_tab_, fe_prefix_, fe_out_;
   std::map<std::vector<int32_t>, std::shared_ptr<Plan>> plan_cache_;
   bool prof_on_ = false;
   std::vector<std::string> prof_labels_;

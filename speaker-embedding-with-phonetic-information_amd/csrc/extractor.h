@@ -30,6 +30,12 @@ struct ExtractOptions {
   bool pad_input = true;
   int max_batch_rows = 1 << 17;   // rows of (padded) chunks per forward pass
   int max_batch_chunks = 4096;
+  // optional device front-end in front of the extractor (replaces the apply-cmvn-sliding | select-voiced-frames pipes
+  // of extract_xvectors_new.sh:79): sliding CMN when cmn_window > 0, voiced-frame selection when a VAD table is given
+  int cmn_window = 0;
+  bool cmn_center = true;
+  int cmn_min_window = 100;
+  std::string vad_rspecifier;
 };
 
 // feats: packed host rows; utterance u = rows row_offsets[u] .. row_offsets[u+1]-1.

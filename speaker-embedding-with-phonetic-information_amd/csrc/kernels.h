@@ -147,6 +147,25 @@ struct FrameOutArgs {
 };
 hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s);
 
+// Feature front-end on the device: sliding-window cepstral mean subtraction
+// (apply-cmvn-sliding --norm-vars=false, centred or not) followed by the selection of voiced frames
+// (select-voiced-frames), the pipeline of egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:79.
+struct FrontEndArgs {
+  const float* raw;         // packed raw feature rows [raw rows][dim]
+  const int32_t* raw_off;   // [n_utts + 1] row offsets of the utterances
+  double* prefix;           // [raw rows + n_utts][dim] per-utterance exclusive prefix sums (workspace)
+  int n_utts;
+  int dim;
+  const int32_t* sel_row;   // [n_out] absolute raw row of every kept frame
+  const int32_t* sel_utt;   // [n_out] its utterance
+  int n_out;
+  int cmn_window;           // <= 0: no mean subtraction
+  int center;
+  int min_window;
+  float* out;               // [n_out][dim]
+};
+hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s);
+
 // 16-bit helpers shared by host packing code (round-to-nearest-even, like v_cvt_pk_bf16_f32).
 uint16_t host_f32_to_bf16(float x);
 float host_bf16_to_f32(uint16_t h);

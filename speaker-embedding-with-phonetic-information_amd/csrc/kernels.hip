@@ -833,6 +833,69 @@ hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Front-end.  cmn_prefix: one workgroup per utterance, thread d keeps a double running sum of column d (the tool
+// this replaces also accumulates in double).  cmn_select: one thread per (kept frame, column): window bounds as in
+// Kaldi's SlidingWindowCmn, mean from two prefix rows, out = (float)(x - mean).
+__global__ __launch_bounds__(64) void cmn_prefix_kernel(const FrontEndArgs a) {
+  const int u = blockIdx.x, d = threadIdx.x;
+  if (d >= a.dim) return;
+  const int r0 = a.raw_off[u], len = a.raw_off[u + 1] - r0;
+  double* p = a.prefix + ((long)r0 + u) * a.dim + d;
+  const float* x = a.raw + (long)r0 * a.dim + d;
+  double acc = 0.0;
+  p[0] = 0.0;
+  for (int t = 0; t < len; ++t) {
+    acc += (double)x[(long)t * a.dim];
+    p[(long)(t + 1) * a.dim] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void cmn_select_kernel(const FrontEndArgs a) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.n_out * a.dim) return;
+  const int i = (int)(idx / a.dim), d = (int)(idx - (long)i * a.dim);
+  const int u = a.sel_utt[i];
+  const int r0 = a.raw_off[u], T = a.raw_off[u + 1] - r0;
+  const int t = a.sel_row[i] - r0;
+  const float x = a.raw[(long)a.sel_row[i] * a.dim + d];
+  if (a.cmn_window <= 0) {
+    a.out[idx] = x;
+    return;
+  }
+  int ws, we;
+  if (a.center) {
+    ws = t - a.cmn_window / 2;
+    we = ws + a.cmn_window;
+  } else {
+    ws = t - a.cmn_window;
+    we = t + 1;
+  }
+  if (ws < 0) {
+    we -= ws;
+    ws = 0;
+  }
+  if (!a.center && we > t) we = max(t + 1, a.min_window);
+  if (we > T) {
+    ws -= (we - T);
+    we = T;
+    if (ws < 0) ws = 0;
+  }
+  const double* p = a.prefix + ((long)r0 + u) * a.dim + d;
+  const double mean = (p[(long)we * a.dim] - p[(long)ws * a.dim]) / (double)(we - ws);
+  a.out[idx] = (float)((double)x - mean);
+}
+
+hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s) {
+  if (a.dim > 64) return hipErrorInvalidValue;
+  if (a.cmn_window > 0 && a.n_utts > 0) hipLaunchKernelGGL(cmn_prefix_kernel, dim3(a.n_utts), dim3(64), 0, s, a);
+  if (a.n_out > 0) {
+    const long total = (long)a.n_out * a.dim;
+    hipLaunchKernelGGL(cmn_select_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // frame_output: one workgroup per output row.  LogSoftmaxComponent: y = x - max - log(sum exp(x - max)).
 __global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a) {
   const int o = blockIdx.x;

@@ -71,6 +71,9 @@ const char* kUsage =
     "  --precision=bf16x3|bf16|fp16     arithmetic of the MFMA GEMMs (default bf16x3: fp32-grade)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
+    "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
+    "                                   run apply-cmvn-sliding (--norm-vars=false) and select-voiced-frames on the device\n"
+    "                                   in front of the network; the features rspecifier is then the raw feats.scp\n"
     "  --config=<file>  --verbose=<int>  --print-args=true|false  --help\n";
 
 struct Options {
@@ -84,6 +87,9 @@ struct Options {
   int batch_frames = 1 << 17;
   int device = -1;
   bool print_args = true;
+  int cmn_window = 0;
+  bool cmn_center = true;
+  std::string vad_rspecifier;
 };
 
 bool ParseBool(const std::string& v, bool* out) {
@@ -146,6 +152,14 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   else if (name == "min-chunk-size") return need_int(&o->min_chunk_size);
   else if (name == "batch-frames") return need_int(&o->batch_frames);
   else if (name == "device") return need_int(&o->device);
+  else if (name == "cmn-window") return need_int(&o->cmn_window);
+  else if (name == "vad-rspecifier") o->vad_rspecifier = value;
+  else if (name == "cmn-center") {
+    if (!ParseBool(value, &o->cmn_center)) {
+      *err = "invalid boolean for --cmn-center: " + value;
+      return false;
+    }
+  }
   else if (name == "verbose") return need_int(&g_verbose);
   else if (name == "pad-input") {
     if (!ParseBool(value, &o->pad_input)) {
@@ -294,6 +308,9 @@ int main(int argc, char** argv) {
     eo.min_chunk_size = opt.min_chunk_size;
     eo.pad_input = opt.pad_input;
     eo.max_batch_rows = opt.batch_frames;
+    eo.cmn_window = opt.cmn_window;
+    eo.cmn_center = opt.cmn_center;
+    eo.vad_rspecifier = opt.vad_rspecifier;
     xv::TableExtractResult res = xv::RunTableExtraction(
         &engine, eo, feat_rspec, vec_wspec, [](const char* level, const std::string& m) { LogLine(level, 0, m); });
     if (res.reader_status != 0) XWARN("feature input command exited with status " << res.reader_status);

@@ -2,6 +2,7 @@
 #include "table_extract.h"
 
 #include <math.h>
+#include <memory>
 #include <string.h>
 
 #include <chrono>
@@ -81,10 +82,13 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   });
 
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<float> packed, emb;
-  std::vector<int32_t> offs, ok;
+  std::vector<float> packed, emb, processed;
+  std::vector<int32_t> offs, ok, sel_row, sel_utt, poffs;
   std::vector<std::string> why;
   std::string fatal;
+  const bool use_frontend = opt.cmn_window > 0 || !opt.vad_rspecifier.empty();
+  std::unique_ptr<RandomAccessVectorReader> vad;
+  if (!opt.vad_rspecifier.empty()) vad.reset(new RandomAccessVectorReader(opt.vad_rspecifier));
   for (;;) {
     Batch b;
     {
@@ -116,7 +120,60 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
           offs.push_back((int32_t)r);
           idx.push_back((int)i);
         }
-        const int n = (int)idx.size();
+        int n = (int)idx.size();
+        if (use_frontend && n) {
+          // sliding CMN over the WHOLE utterance first, then keep the voiced frames (order of the two pipe stages)
+          sel_row.clear();
+          sel_utt.clear();
+          poffs.assign(1, 0);
+          std::vector<int> keep_idx;
+          std::vector<int32_t> raw_off2(1, 0);
+          std::vector<float> raw2;
+          for (int k = 0; k < n; ++k) {
+            const Utt& u = b.utts[idx[k]];
+            const int T = u.feats.rows;
+            const std::vector<float>* v = nullptr;
+            if (vad) {
+              if (!vad->HasKey(u.key)) {
+                warn("No VAD input found for utterance " + u.key);
+                ++res.num_fail;
+                continue;
+              }
+              v = &vad->Value(u.key);
+              if ((int)v->size() != T) {
+                std::ostringstream m;
+                m << "Mismatch in number of frames " << T << " for features and VAD " << v->size() << ", for utterance " << u.key;
+                warn(m.str());
+                ++res.num_fail;
+                continue;
+              }
+            }
+            const int32_t base = raw_off2.back();
+            const size_t before = sel_row.size();
+            for (int t = 0; t < T; ++t)
+              if (!v || (*v)[t] != 0.f) {
+                sel_row.push_back(base + t);
+                sel_utt.push_back((int32_t)keep_idx.size());
+              }
+            if (T > 0 && sel_row.size() == before) {
+              warn("No features were judged as voiced for utterance " + u.key);
+              ++res.num_fail;
+              continue;
+            }
+            raw2.insert(raw2.end(), u.feats.data.begin(), u.feats.data.end());
+            raw_off2.push_back(base + T);
+            keep_idx.push_back(idx[k]);
+            poffs.push_back((int32_t)sel_row.size());
+          }
+          idx.swap(keep_idx);
+          n = (int)idx.size();
+          processed.resize(sel_row.size() * (size_t)D);
+          if (n)
+            engine->FrontEndHost(raw2.data(), raw_off2.data(), n, sel_row.data(), sel_utt.data(), (int)sel_row.size(),
+                                 opt.cmn_window, opt.cmn_center, opt.cmn_min_window, processed.data());
+          packed.swap(processed);
+          offs = poffs;
+        }
         emb.resize((size_t)n * E);
         ok.assign(n, 0);
         if (n) ExtractUtterances(engine, opt, packed.data(), offs.data(), n, emb.data(), ok.data(), &why);

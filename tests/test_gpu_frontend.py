@@ -1,0 +1,74 @@
+"""GPU parity tests of the device front-end (sliding CMN + voiced-frame selection) against oracle/frontend.py, and
+of the extractor CLI with the front-end fused in (replacing the two pipe stages of extract_xvectors_new.sh:79)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import frontend as fe
+from oracle import kaldi_io as kio
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(H.ROOT, H.PKG_NAME, "bin")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    P = H.pkg()
+    net, line = H.synth_model("v2_xvector")
+    return P.Context(P.Model(raw=net.to_bytes(True), nnet_config=line))
+
+
+@pytest.mark.parametrize("center", [True, False])
+def test_sliding_cmn_and_vad_selection(ctx, center):
+    lens = [1000, 299, 300, 301, 50, 1, 640]
+    utts = [H.features(60 + i, T) + 3.0 for i, T in enumerate(lens)]       # non-zero mean so CMN matters
+    vads = [fe.synthetic_vad(i, T) for i, T in enumerate(lens)]
+    vads[5][:] = 1.0
+    raw, offs = H.pack(utts)
+    out, out_off = ctx.frontend(raw, offs, np.concatenate(vads), cmn_window=300, center=center)
+    for i, (u, v) in enumerate(zip(utts, vads)):
+        ref = fe.select_voiced(fe.sliding_cmn(u, 300, center), v)
+        got = out[out_off[i]:out_off[i + 1]]
+        if ref is None:
+            assert got.shape[0] == 0
+            continue
+        assert got.shape == ref.shape, i
+        # fp32 features of magnitude ~10: the subtraction is done in double on both sides
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(u).max()), (i, np.abs(got - ref).max())
+    # no VAD, no CMN: identity
+    out2, off2 = ctx.frontend(raw, offs, None, cmn_window=0)
+    assert np.array_equal(out2, raw) and np.array_equal(off2, offs)
+
+
+def test_cli_with_fused_front_end(tmp_path):
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    lens = [500, 120, 64, 900]
+    utts = [("utt%d" % i, H.features(900 + i, T) + 1.5) for i, T in enumerate(lens)]
+    vads = [("utt%d" % i, fe.synthetic_vad(30 + i, T)) for i, T in enumerate(lens)]
+    vads[2] = ("utt2", np.zeros(64, np.float32))                          # nothing voiced -> skipped with a warning
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"))
+    kio.write_ark_vectors(str(tmp_path / "vad.ark"), vads, scp_path=str(tmp_path / "vad.scp"))
+    r = subprocess.run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000",
+                        "--output-node=tdnn6.affine", "--cmn-window=300", "--cmn-center=true",
+                        "--vad-rspecifier=scp,s,cs:%s/vad.scp" % tmp_path, str(tmp_path / "final.raw"),
+                        "scp:%s/feats.scp" % tmp_path, "ark,scp:%s/x.ark,%s/x.scp" % (tmp_path, tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    got = dict(kio.read_scp(str(tmp_path / "x.scp"), "vector"))
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    ev = H.xo.GraphEvaluator(n2, np.float32)
+    for (k, x), (_, v) in zip(utts, vads):
+        f = fe.select_voiced(fe.sliding_cmn(x, 300, True), v)
+        if f is None:
+            assert k not in got
+            continue
+        ref = H.xo.extract_xvector(ev, f, 10000, 25, True)
+        assert H.rel_err(got[k][None], ref[None]) < 1e-4, k
+    assert "No features were judged as voiced for utterance utt2" in err
+    assert "Done 3 utterances, failed for 1" in err
