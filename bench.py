@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--output-node", default=None,
+                    help="compute this node instead of the topology's embedding node (e.g. output_am.log-softmax: the "
+                         "senone head of BASELINE config 5 -> frame-level output, one row per frame)")
+    ap.add_argument("--ragged", default=None, help="LO-HI: chunk lengths drawn uniformly from {LO..HI} (seed 5) instead of --frames")
     ap.add_argument("--lanes", type=int, default=1, help="batches in flight inside the engine during the timed region")
     args = ap.parse_args()
 
@@ -94,9 +98,20 @@ def main():
     net = cfg_line = None
     if rank == 0:
         net, cfg_line = H.synth_model(args.topology)
+        if args.output_node:
+            cfgs, _ = H.TOPOLOGIES[args.topology]
+            net = H.nm.synthesize([H.config_text(c) for c in cfgs], seed=123, head_stddev=1.0)   # non-zero senone head
+            cfg_line = "output-node name=output input=%s" % args.output_node
         model = P.Model(raw=net.to_bytes(True), nnet_config=cfg_line)
         blob = model.pack(prec)
-        macs = model.macs(args.frames)
+        if args.ragged:
+            lo_, hi_ = [int(v) for v in args.ragged.split("-")]
+            lens_ = np.random.default_rng(5).integers(lo_, hi_ + 1, args.batch)
+        else:
+            lens_ = np.full(args.batch, args.frames)
+        mi_ = model.info
+        ctx_pad = 0 if mi_.output_is_segment else mi_.left_context + mi_.right_context
+        macs = float(np.mean([model.macs(int(t) + ctx_pad) for t in lens_]))      # average per chunk
         meta = torch.tensor([len(blob), int(macs)], dtype=torch.int64, device=dev)
     else:
         meta = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -118,12 +133,20 @@ def main():
 
     # ---- synthetic inputs resident in HBM (N(0,1)*sigma_d, sigma_d = 8*0.9^d) ---------------
     B, T, D = args.batch, args.frames, ctx.info.input_dim
+    if args.ragged:
+        lo_, hi_ = [int(v) for v in args.ragged.split("-")]
+        lens = np.random.default_rng(5 + rank).integers(lo_, hi_ + 1, B).astype(np.int64)
+    else:
+        lens = np.full(B, T, dtype=np.int64)
+    total_rows = int(lens.sum())
+    frame_level = not ctx.info.output_is_segment
     g = torch.Generator(device=dev).manual_seed(20180101 + rank)
     sigma = (8.0 * 0.9 ** torch.arange(D, dtype=torch.float32)).to(dev)
-    feats = torch.randn(B * T, D, generator=g, device=dev, dtype=torch.float32) * sigma
-    outs = [torch.empty(B, ctx.info.output_dim, dtype=torch.float32, device=dev) for _ in range(4)]
+    feats = torch.randn(total_rows, D, generator=g, device=dev, dtype=torch.float32) * sigma
+    out_rows = total_rows if frame_level else B
+    outs = [torch.empty(out_rows, ctx.info.output_dim, dtype=torch.float32, device=dev) for _ in range(2 if frame_level else 4)]
     out = outs[0]
-    offs = np.arange(B + 1, dtype=np.int32) * T
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     stream = torch.cuda.current_stream().cuda_stream
 
     # stream = None -> the engine's own streams: consecutive (independent) batches alternate between its lanes,
@@ -197,7 +220,7 @@ def main():
         # segment-level layers, which run in other instantiations
         stats_names = [l.split(":", 1)[1] for (l, c, ms) in prof if l.startswith("tdnn_gemm<stats>")]
         f32_names = [l.split(":", 1)[1] for (l, c, ms) in prof if l.startswith("tdnn_gemm<f32>")]
-        pool_frames = T - ctx.info.left_context - ctx.info.right_context
+        pool_frames = float(np.mean(lens)) - ctx.info.left_context - ctx.info.right_context
         other_macs = 0.0
         for nme in stats_names:
             k, n = per_layer.get(nme, (0, 0))
@@ -228,9 +251,13 @@ def main():
         n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
         n2.apply_nnet_config(cfg_line)
         ev = H.xo.GraphEvaluator(n2, np.float32)
-        f_host = feats[:2 * T].cpu().numpy()
-        ref = np.stack([ev.compute(f_host[i * T:(i + 1) * T])[0] for i in range(2)])
-        parity = H.rel_err(out[:2].cpu().numpy(), ref)
+        f_host = feats[:int(offs[2])].cpu().numpy()
+        if frame_level:
+            ref = np.concatenate([H.xo.compute_all_frames(ev, f_host[offs[i]:offs[i + 1]]) for i in range(2)])
+            parity = H.rel_err(outs[0][:int(offs[2])].cpu().numpy(), ref)
+        else:
+            ref = np.stack([ev.compute(f_host[offs[i]:offs[i + 1]])[0] for i in range(2)])
+            parity = H.rel_err(out[:2].cpu().numpy(), ref)
         res = {
             "metric": "utterance-embeddings/sec (400-frame chunks)", "value": value, "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -239,12 +266,14 @@ def main():
             "config": {"workload": "%s TDNN, %d chunks x %d frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
                                    % (args.topology, B, T), "topology": args.topology, "batch_chunks_per_gpu": B,
                        "frames_per_chunk": T, "precision": args.precision, "lanes": args.lanes,
-                       "alg_gflop_per_utt": 2.0 * macs / 1e9},
+                       "alg_gflop_per_utt": 2.0 * macs / 1e9, "output_node": args.output_node or "embedding",
+                       "chunk_lengths": args.ragged or str(T), "frames_per_step": total_rows},
+            "frames_per_sec": world * total_rows * args.steps / dt,
             "roofline": roofline,
             "parity_rel_err_vs_oracle_fp32": parity,
             "kernels_ms_per_step": {l: ms / max(1, c) for (l, c, ms) in prof},
         }
-        if world == 1 and not args.no_extra_modes and args.precision == "bf16x3":
+        if world == 1 and not args.no_extra_modes and args.precision == "bf16x3" and not frame_level and not args.ragged:
             # single-pass modes, reported next to the parity mode with their measured error (never `value`)
             extra = {}
             os.environ["XVEC_LANES"] = "2"
@@ -276,7 +305,7 @@ def main():
                 del c2
             res["single_pass_modes"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(net, cfg_line, T, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(net, cfg_line, int(np.mean(lens)), args.cpu_seconds)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

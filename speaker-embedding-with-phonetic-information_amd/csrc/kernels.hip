@@ -14,9 +14,10 @@
 //   * both operands are K-contiguous ([rows][K] activations, [N][K] weights), staged with
 //     global_load_lds_dwordx4 straight into LDS (no VGPR round trip), double buffered, one
 //     workgroup barrier per K step;
-//   * LDS rows are 64 B; the 16-byte chunk index is XOR-swizzled with the row so that every
-//     ds_read_b128 lane group touches 16 distinct 16-B slots.  Because LDS-DMA writes are
-//     lane-linear the swizzle is applied to the per-lane *global source* address;
+//   * LDS rows are 64 B; the 16-byte chunk index is XOR-swizzled with the row (phys = chunk ^ ((row>>1)&3)) so
+//     that every ds_read_b128 lane group touches 16 distinct 16-B slots for ANY starting row (the spliced layers
+//     read the activation tile displaced by their time offsets; brute-forced over all 16 displacements).  Because
+//     LDS-DMA writes are lane-linear the swizzle is applied to the per-lane *global source* address;
 //   * the splice (Append of time offsets) is a row shift of the activation tile per K segment;
 //   * split-bf16 (hi, lo planes) gives fp32-grade products from three bf16 MFMAs;
 //   * kEpiAct / kEpiF32 feed the weight tile as the MFMA *A* operand, with the weight rows of a
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   // ---- per-lane staging geometry -------------------------------------------------------
   // one global_load_lds_dwordx4 per wave = 16 LDS rows x 64 B; lane l -> row l>>2, phys chunk l&3
   const int ld_row = lane >> 2;
-  const int ld_chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);  // logical 16-B chunk fetched
+  const int ld_chunk = (lane & 3) ^ ((lane >> 3) & 3);  // logical 16-B chunk fetched
   const int c0 = wave * 2;                                           // this wave's two 16-row chunks
 
   const uint16_t* wp_hi[2];
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   // ---- per-lane fragment read geometry ---------------------------------------------------
   const int fr_i = lane & 15;
   const int fr_g = lane >> 4;
-  const int fr_chunk = fr_g ^ ((4 - (fr_i >> 2)) & 3);
+  const int fr_chunk = fr_g ^ ((fr_i >> 1) & 3);
   const int x_rd = (wave_m * 64 + fr_i) * 64 + fr_chunk * 16;                     // + f*1024
   const int w_rd = NPL * kTileBytes + (wave_n * 64 + fr_i) * 64 + fr_chunk * 16;  // + f*1024
 
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   const int n0 = nt * kBN;
 
   const int ld_row = lane >> 2;
-  const int ld_chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+  const int ld_chunk = (lane & 3) ^ ((lane >> 3) & 3);
 
   // weights: this wave stages 16-row chunk `wave` of the 128-row tile; per lane the row start is fixed and the
   // K column of a step is a wave-uniform offset
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
         if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + c * 1024);
       }
       n += 2 * NPL;
-      if (wave == 0) {  // halo rows 256..271
+      if (wave == 0 && gi.nshift > 1) {  // halo rows 256..271 (only read by displaced offsets)
         const long off = (long)(m0 + gi.shift0 + 256 + ld_row) * gi.ld + col;
         glds16_asm(gi.hi + off, st + 16 * 1024);
         if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + 16 * 1024);
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   int r_nshift = gi.nshift, r_ksteps = gi.ksteps, r_dstep = gi.dstep;
   const int fr_i = lane & 15;
   const int fr_g = lane >> 4;
-  const int w_rd = (wave_n * 64 + fr_i) * 64 + (fr_g ^ ((4 - (fr_i >> 2)) & 3)) * 16;
+  const int w_rd = (wave_n * 64 + fr_i) * 64 + (fr_g ^ ((fr_i >> 1) & 3)) * 16;
   struct Frags {
     s16x8 xh[4], xl[4], wh[4], wl[4];
   };
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     const char* xs = smem + rxslot * XSLOT;
     const char* ws = smem + WBASE + rwslot * WSLOT;
     const int row = wave_m * 64 + fr_i + rj * r_dstep;  // displaced by the time offset of this step
-    const int x_rd = row * 64 + (fr_g ^ ((4 - ((row >> 2) & 3)) & 3)) * 16;
+    const int x_rd = row * 64 + (fr_g ^ ((row >> 1) & 3)) * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f.xh[i] = *(const s16x8*)(xs + x_rd + i * 1024);

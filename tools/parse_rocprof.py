@@ -49,13 +49,44 @@ def main():
         for i, ((k, f, us), (_, w, _)) in enumerate(zip(per["FETCH_SIZE"], per["WRITE_SIZE"])):
             b = (2 * f + w) * 1024
             lines.append("| %d | %s | %.1f | %.1f | %.3e | %.1f |" % (i, k, f, w, b, us))
-            if "tdnn_gemm_kernel<0, 0>" in k or "tdnn_gemm_kernel<1, 0>" in k or "tdnn_gemm_kernel<2, 0>" in k:
+            if ("tdnn_gemm_kernel" in k) and (", 0>" in k):
                 tot_act += b
                 n_act += 1
         open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
         if n_act:
             json.dump({"hbm_bytes_per_launch": tot_act / n_act, "kernel": "tdnn_gemm_kernel<prec,act>", "launches": n_act,
                        "source": tag + "_pmc_hbm.md"}, open(os.path.join(prof, "pmc_traffic.json"), "w"))
+    sq = os.path.join(d, "pmc_sq", "bench_counter_collection.csv")
+    if os.path.exists(sq):
+        import collections
+        rows = [r for r in csv.DictReader(open(sq)) if "xv::" in r["Kernel_Name"]]
+        disp = collections.OrderedDict()
+        for r in rows:
+            e = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"].split("(")[0].replace("void ", ""),
+                                                  "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                                  "vgpr": r["VGPR_Count"], "lds": r["LDS_Block_Size"], "grid": r["Grid_Size"]})
+            e[r["Counter_Name"]] = float(r["Counter_Value"])
+        last = list(disp.values())
+        idx = max(i for i, e in enumerate(last) if "prep_input" in e["name"])
+        lines = ["# SQ counters per kernel, one bench step (%s)" % tag, "",
+                 "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES",
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, no tracing).",
+                 "clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles).", "",
+                 "| kernel | us | VGPR | LDS B | clock GHz | MFMA pipe busy | wait_any | wait_inst | active | LDS bank conflict cycles |",
+                 "|---|---|---|---|---|---|---|---|---|---|"]
+        for e in last[idx:]:
+            cyc = e.get("GRBM_GUI_ACTIVE", 0) / 8.0
+            wc = max(e.get("SQ_WAVE_CYCLES", 1), 1)
+            lines.append("| %s | %.1f | %s | %s | %.2f | %.1f %% | %.2f | %.2f | %.2f | %.3g |" % (
+                e["name"], e["us"], e["vgpr"], e["lds"], cyc / e["us"] / 1e3 if e["us"] else 0,
+                100 * e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc if cyc else 0, e.get("SQ_WAIT_ANY", 0) / wc,
+                e.get("SQ_WAIT_INST_ANY", 0) / wc, e.get("SQ_ACTIVE_INST_ANY", 0) / wc, e.get("SQ_LDS_BANK_CONFLICT", 0)))
+        open(os.path.join(prof, tag + "_pmc_sq.md"), "w").write("\n".join(lines) + "\n")
+    bd = os.path.join(d, "bench_default.json")
+    if os.path.exists(bd):
+        js = [l for l in open(bd) if l.startswith("{")]
+        if js:
+            open(os.path.join(prof, tag + "_bench_default.json"), "w").write(js[-1])
     for name in ("kt_bench.log",):
         p = os.path.join(d, name)
         if os.path.exists(p):
