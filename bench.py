@@ -147,8 +147,6 @@ def main():
     outs = [torch.empty(out_rows, ctx.info.output_dim, dtype=torch.float32, device=dev) for _ in range(2 if frame_level else 4)]
     out = outs[0]
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    stream = torch.cuda.current_stream().cuda_stream
-
     # stream = None -> the engine's own streams: consecutive (independent) batches alternate between its lanes,
     # each with its own activation buffers, so one batch's tails overlap with the next batch's kernels
     stream = None
@@ -196,22 +194,13 @@ def main():
         # ---- roofline of the dominant kernel (activation-producing spliced GEMM) -----------------------------
         act = [(l, c, ms) for (l, c, ms) in prof if l.startswith("tdnn_gemm<act>")]
         allg = [(l, c, ms) for (l, c, ms) in prof if l.startswith("tdnn_gemm<")]
-        info_layers = None
+        # K x N of every layer from the library's layer table ("[i] name  K->N ..."), to attribute the algorithmic
+        # MACs (unpadded dims x frames nnet3 would compute, xv_model_macs) to the kernel instantiations
         per_layer = {}
-        try:
-            desc = model.describe()
-            for line in desc.splitlines()[1:]:
-                parts = line.split()
-                name, dims = parts[1], parts[2]
-                k, n = dims.split("->")
-                per_layer[name] = (int(k), int(n))
-        except Exception:
-            pass
-        # algorithmic MACs per layer per chunk: unpadded dims x frames nnet3 would compute; computed by the library
-        # for the whole net (macs); per layer we apportion by K*N*(needed frames) using the same rule
-        def layer_macs(name):
-            # needed frames: library reports total only; recompute from the describe() table context columns
-            return None
+        for line in model.describe().splitlines()[1:]:
+            parts = line.split()
+            k, n = parts[2].split("->")
+            per_layer[parts[1]] = (int(k), int(n))
         act_ms = sum(ms for _, _, ms in act)
         act_launches = sum(c for _, c, _ in act)
         gemm_ms = sum(ms for _, _, ms in allg)
