@@ -16,7 +16,8 @@ Rank 0 prints ONE JSON line.
            duration measured with HIP events on the launch stream inside the timed region; peak = 2.5 PFLOP/s
            dense bf16 MFMA (MI355X_MICROARCH.md).  Note the split mode executes 3 MFMAs per algorithmic MAC.
   cpu_baseline  the numpy/OpenBLAS fp32 oracle ("port": this repo's restatement of Kaldi's semantics, NOT Kaldi,
-           which is neither vendored by the reference nor installed) timed on the host cores, rank 0, N=1 only.
+           which is neither vendored by the reference nor installed) run the way the recipes run Kaldi on CPU - one
+           single-threaded process per host core, an utterance at a time - rank 0, N=1 only, ~12 s.
 """
 import argparse
 import importlib
@@ -32,28 +33,25 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def cpu_baseline(net, cfg_line, frames, seconds):
-    """Oracle (numpy fp32 sgemm formulation = how Kaldi's CPU path spends its time) on a bounded sample."""
-    import numpy as np
-    import helpers as H
-    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
-    n2.apply_nnet_config(cfg_line)
-    ev = H.xo.GraphEvaluator(n2, np.float32)
-    x = [H.features(i, frames) for i in range(4)]
-    ev.compute(x[0])  # warm
-    n, t0 = 0, time.time()
-    while time.time() - t0 < seconds:
-        ev.compute(x[n % 4])
-        n += 1
-    dt = time.time() - t0
-    threads = os.cpu_count()
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [threads])
-    except Exception:
-        pass
-    return {"value": n / dt, "unit": "utt/s", "cores": int(threads), "kind": "port",
-            "sample": "%d x %d-frame utterances in %.1f s, numpy/OpenBLAS fp32 oracle, one utterance at a time" % (n, frames, dt)}
+def cpu_baseline(topology, frames, seconds):
+    """CPU oracle ("port" = this repo's numpy/OpenBLAS fp32 restatement of Kaldi's semantics, NOT Kaldi) the way the
+    reference runs extraction on CPU: independent single-threaded processes, one utterance at a time
+    (egs/sre/v2/run_sre10.sh:24,200 uses --nj 32).  One worker per host core, started as child processes."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    worker = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, worker, topology, str(frames), str(seconds), str(i)], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, env=env) for i in range(cores)]
+    n_tot, rate = 0, 0.0
+    for p in procs:
+        out = p.communicate()[0].decode().split()
+        if len(out) == 2:
+            n_tot += int(out[0])
+            rate += int(out[0]) / float(out[1])
+    return {"value": rate, "unit": "utt/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d-frame utterances in ~%.0f s by %d single-threaded numpy/OpenBLAS fp32 oracle processes "
+                      "(one per host core, one utterance at a time)" % (n_tot, frames, seconds, cores)}
 
 
 def main():
@@ -85,13 +83,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a visible MI355X; there is no CPU path to measure")
+    # BENCH_DIST_BACKEND=gloo + BENCH_FORCE_DEVICE=0 exist only to exercise the multi-rank code path on a 1-GPU box
+    # (ranks then share one GPU, so the throughput of such a run means nothing)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_FORCE_DEVICE"):
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")    # where collective payloads live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- model: read/packed ONCE on rank 0, broadcast over RCCL -------------------------------------------
     prec = P.PRECISIONS[args.precision]
@@ -112,16 +119,16 @@ def main():
         mi_ = model.info
         ctx_pad = 0 if mi_.output_is_segment else mi_.left_context + mi_.right_context
         macs = float(np.mean([model.macs(int(t) + ctx_pad) for t in lens_]))      # average per chunk
-        meta = torch.tensor([len(blob), int(macs)], dtype=torch.int64, device=dev)
+        meta = torch.tensor([len(blob), int(macs)], dtype=torch.int64, device=cdev)
     else:
-        meta = torch.zeros(2, dtype=torch.int64, device=dev)
+        meta = torch.zeros(2, dtype=torch.int64, device=cdev)
     if world > 1:
         dist.broadcast(meta, 0)
     nbytes, macs = int(meta[0].item()), float(meta[1].item())
     if rank == 0:
-        wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(cdev)
     else:
-        wt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        wt = torch.empty(nbytes, dtype=torch.uint8, device=cdev)
     if world > 1:
         dist.broadcast(wt, 0)       # the ONE collective of this path (weights over xGMI)
     # The timed region runs the engine with ONE lane (one batch in flight) so that the per-kernel HIP-event durations
@@ -184,7 +191,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
     prof = ctx.profile_report()
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -294,7 +301,7 @@ def main():
                 del c2
             res["single_pass_modes"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(net, cfg_line, int(np.mean(lens)), args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(args.topology, int(np.mean(lens)), args.cpu_seconds)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
