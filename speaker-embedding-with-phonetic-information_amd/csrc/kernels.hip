@@ -143,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float z = acc[p][q][r] + bs[p * 4 + r];
-          if (a.relu) z = fmaxf(z, 0.f);
+          if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
           if (a.bn) z = z * sc[p * 4 + r] + of[p * 4 + r];
           y[p * 4 + r] = z;
         }
@@ -195,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float z = acc[p][q][r] + b;
-          if (a.relu) z = fmaxf(z, 0.f);
+          if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
           if (a.bn) z = z * sc + of;
           const int rr = fr_g * 4 + r;
           const bool ok = (rr >= first) && (rr < last);
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float z = v[r] + b[r];
-    if (a.relu) z = fmaxf(z, 0.f);
+    if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
     if (a.bn) z = z * a.scale[col + r] + a.offset[col + r];
     y[r] = z;
   }

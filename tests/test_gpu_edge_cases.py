@@ -1,0 +1,96 @@
+"""GPU tests of the edge cases of the path: maximum chunk size, multi-chunk utterances, many tiny utterances per tile,
+non-finite features (must not leak into neighbours), determinism, compressed feature archives through the CLI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import kaldi_io as kio
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(H.ROOT, H.PKG_NAME, "bin")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def v2():
+    P = H.pkg()
+    net, line = H.synth_model("v2_xvector")
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    return P, net, line, model, P.Context(model), H.xo.GraphEvaluator(n2, np.float32)
+
+
+def test_maximum_chunk_size_and_long_utterance(v2):
+    # max_chunk_size=10000 (run_xvector_new.sh:83): a 10000-frame chunk is one pooling window; 25000 frames -> 3 chunks
+    P, net, line, model, ctx, ev = v2
+    x = H.features(4242, 25000)
+    out, ok = ctx.extract_utterances(x, [0, 25000], 10000, 25, True)
+    assert ok[0]
+    ref = H.xo.extract_xvector(ev, x, 10000, 25, True)
+    assert H.rel_err(out, ref[None]) < TOL
+    one = ctx.forward_batch(x[:10000], [0, 10000])
+    assert H.rel_err(one, ev.compute(x[:10000])) < TOL
+
+
+def test_many_tiny_utterances_share_tiles(v2):
+    # 300 utterances of 15..40 frames: up to 16 utterances per 256-row tile, several per 16-row... no: each starts a
+    # new 16-row group; checks the per-group masks and per-utterance reductions
+    P, net, line, model, ctx, ev = v2
+    rng = np.random.default_rng(8)
+    lens = [int(t) for t in rng.integers(15, 41, 300)]
+    utts = [H.features(2000 + i, T) for i, T in enumerate(lens)]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    idx = list(range(0, 300, 13))
+    ref = np.stack([ev.compute(utts[i])[0] for i in idx])
+    assert H.rel_err(out[idx], ref) < TOL
+    assert np.all(np.isfinite(out))
+
+
+def test_non_finite_features_stay_in_their_utterance(v2):
+    P, net, line, model, ctx, ev = v2
+    utts = [H.features(3000 + i, T) for i, T in enumerate([100, 64, 100, 37])]
+    clean, offs = H.pack(utts)
+    base = ctx.forward_batch(clean, offs)
+    bad = [u.copy() for u in utts]
+    bad[1][0, 3] = np.nan           # first frame of utterance 1 (adjacent to the last frames of utterance 0)
+    bad[1][-1, 0] = np.inf          # and its last frame (adjacent to utterance 2)
+    f2, _ = H.pack(bad)
+    out = ctx.forward_batch(f2, offs)
+    assert not np.all(np.isfinite(out[1]))
+    for i in (0, 2, 3):
+        assert np.array_equal(out[i], base[i]), i      # neighbours are bit-identical: no cross-utterance arithmetic
+
+
+def test_repeatability_and_single_utterance_batch(v2):
+    P, net, line, model, ctx, ev = v2
+    x = H.features(77, 400)
+    a = ctx.forward_batch(x, [0, 400])
+    b = ctx.forward_batch(x, [0, 400])
+    assert np.array_equal(a, b)
+    with pytest.raises(P.XvError):
+        ctx.forward_batch(x[:0], [0])               # empty batch is an argument error, not a crash
+
+
+def test_compressed_feature_archive_through_the_cli(tmp_path, v2):
+    # steps/make_mfcc.sh writes compress=true archives (make_mfcc.sh:12); the extractor must read CM/CM2 directly
+    P, net, line, model, ctx, ev = v2
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    utts = [("c%d" % i, H.features(5000 + i, T)) for i, T in enumerate([300, 45])]
+    expect = {}
+    with open(tmp_path / "feats.ark", "wb") as f:
+        for (k, m), method in zip(utts, ("CM", "CM2")):
+            f.write(k.encode() + b" \x00B")
+            expect[k] = kio.write_compressed_matrix(f, m, method)      # what a conforming reader reconstructs
+    r = subprocess.run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--chunk-size=10000",
+                        "--output-node=tdnn6.affine", str(tmp_path / "final.raw"), "ark:%s/feats.ark" % tmp_path,
+                        "ark:%s/x.ark" % tmp_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    got = dict(kio.read_ark(str(tmp_path / "x.ark"), "vector"))
+    for k, m in expect.items():
+        ref = H.xo.extract_xvector(ev, m, 10000, 25, True)
+        assert H.rel_err(got[k][None], ref[None]) < TOL, k
