@@ -150,6 +150,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(20180101 + rank)
     sigma = (8.0 * 0.9 ** torch.arange(D, dtype=torch.float32)).to(dev)
     feats = torch.randn(total_rows, D, generator=g, device=dev, dtype=torch.float32) * sigma
+    if os.environ.get("BENCH_ZERO_FEATS") == "1":   # diagnostic only (DVFS study): constant activations
+        feats.zero_()
     out_rows = total_rows if frame_level else B
     outs = [torch.empty(out_rows, ctx.info.output_dim, dtype=torch.float32, device=dev) for _ in range(2 if frame_level else 4)]
     out = outs[0]
