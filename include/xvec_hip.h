@@ -147,6 +147,23 @@ xv_status xv_plan_chunks(int32_t num_rows, int32_t chunk_size, int32_t min_chunk
  * on the host, uploading to devices[0] and broadcasting device-to-device with one ncclBroadcast. */
 xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, int precision, xv_ctx** out);
 
+/* ---- speaker-level back-end ----------------------------------------------
+ * What the reference does to the vectors right after extraction, as device kernels behind host buffers
+ * (no Kaldi FFI exists for these either; they replace the processes of egs/sre/v2/run_sre10.sh:238-241 and
+ * egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:106-107):
+ *   xv_backend_apply   ivector-subtract-global-mean (mean != NULL) -> transform-vec (transform != NULL; t_cols == dim
+ *                      linear, dim + 1 affine, anything else XV_ERR_ARG "Dimension mismatch") ->
+ *                      ivector-normalize-length (normalize != 0; scaleup as Kaldi's --scaleup).
+ *                      out[n][out_dim], out_dim = transform ? t_rows : dim; ratio[n] (optional) = |y|/sqrt(out_dim)
+ *                      (|y| without scaleup) before normalisation; a zero vector is left unchanged (ratio 0).
+ *   xv_segment_mean    ivector-mean: out[s] = mean of rows idx[seg_off[s] .. seg_off[s+1]) of x, added in list order,
+ *                      fp32 accumulator (speaker means) or fp64 (acc64 != 0, the global mean); empty segment -> zeros.
+ * Both fail with XV_ERR_DEVICE when no gfx950 device is usable. */
+xv_status xv_backend_apply(int device, const float* x, int32_t n, int32_t dim, const float* mean, const float* transform,
+                           int32_t t_rows, int32_t t_cols, int32_t normalize, int32_t scaleup, float* out, float* ratio);
+xv_status xv_segment_mean(int device, const float* x, int32_t n, int32_t dim, const int32_t* seg_off, const int32_t* idx,
+                          int32_t n_seg, int32_t acc64, float* out);
+
 /* ---- kernel-level entry (unit tests of the HIP GEMM against a plain fp32 reference) ------------------- */
 typedef struct {
   const void* hi;   /* device plane (bf16 / fp16) at logical row 0 */

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libxvec_hip.so")
 BIN_DIR = os.path.join(_HERE, "bin")
 
 XV_OK = 0
+XV_ERR_IO, XV_ERR_MODEL, XV_ERR_DEVICE, XV_ERR_ARG, XV_ERR_INTERNAL = 1, 2, 3, 4, 5
 PREC_BF16X3, PREC_BF16, PREC_FP16 = 0, 1, 2
 PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16}
 EPI_ACT, EPI_F32, EPI_STATS = 0, 1, 2
@@ -57,6 +58,7 @@ ABI_SYMBOLS = [
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
+    "xv_backend_apply", "xv_segment_mean",
 ]
 
 _lib = None
@@ -282,6 +284,53 @@ def plan_chunks(num_rows, chunk_size, min_chunk_size, pad_input, min_net_frames,
     if st != XV_OK:
         return None
     return [(arr[0][i], arr[1][i], arr[2][i], arr[3][i]) for i in range(n.value)]
+
+
+def backend_apply(x, mean=None, transform=None, normalize=False, scaleup=True, device=0, return_ratio=False):
+    """Speaker-level back-end on the device: ivector-subtract-global-mean -> transform-vec -> ivector-normalize-length
+    (egs/sre/v2/run_sre10.sh:238-241), each stage optional.  x: [n, dim] float32.  Returns [n, out_dim] (and the length
+    ratios when asked)."""
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, dim = x.shape
+    mean_p = tr_p = None
+    t_rows = t_cols = 0
+    if mean is not None:
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+        if mean.shape != (dim,):
+            raise XvError(XV_ERR_ARG, "mean has shape %s, vectors have dimension %d" % (mean.shape, dim))
+        mean_p = mean.ctypes.data
+    if transform is not None:
+        transform = np.ascontiguousarray(transform, dtype=np.float32)
+        t_rows, t_cols = transform.shape
+        tr_p = transform.ctypes.data
+    out = np.empty((n, t_rows if transform is not None else dim), dtype=np.float32)
+    ratio = np.empty(n, dtype=np.float32)
+    L = lib()
+    L.xv_backend_apply.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    _check(L.xv_backend_apply(device, x.ctypes.data, n, dim, mean_p, tr_p, t_rows, t_cols, 1 if normalize else 0,
+                              1 if scaleup else 0, out.ctypes.data, ratio.ctypes.data))
+    return (out, ratio) if return_ratio else out
+
+
+def segment_mean(x, segments, acc64=False, device=0):
+    """ivector-mean on the device: row s of the result is the mean of x[segments[s]] (rows added in list order;
+    fp32 accumulator like the per-speaker loop, fp64 with acc64=True like the global mean)."""
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, dim = x.shape
+    off = np.zeros(len(segments) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(s) for s in segments])
+    idx = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.int32) for s in segments]) if len(segments) else
+                               np.zeros(0, np.int32), dtype=np.int32)
+    out = np.empty((len(segments), dim), dtype=np.float32)
+    L = lib()
+    L.xv_segment_mean.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    _check(L.xv_segment_mean(device, x.ctypes.data, n, dim, off.ctypes.data, idx.ctypes.data if idx.size else None,
+                             len(segments), 1 if acc64 else 0, out.ctypes.data))
+    return out
 
 
 def kernel_tdnn_gemm(desc):

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/xvec_hip.h"
+#include "backend.h"
 #include "engine.h"
 #include "extractor.h"
 #include "kernels.h"
@@ -299,6 +300,39 @@ xv_status xv_plan_chunks(int32_t num_rows, int32_t chunk_size, int32_t min_chunk
       if (left_pad) left_pad[i] = ch[i].left_pad;
       if (right_pad) right_pad[i] = ch[i].right_pad;
     }
+    return XV_OK;
+  });
+}
+
+xv_status xv_backend_apply(int device, const float* x, int32_t n, int32_t dim, const float* mean, const float* transform,
+                           int32_t t_rows, int32_t t_cols, int32_t normalize, int32_t scaleup, float* out, float* ratio) {
+  if (n < 0 || dim < 1 || (n > 0 && (!x || !out)) || (transform && t_rows < 1))
+    return Fail(XV_ERR_ARG, "xv_backend_apply: bad argument");
+  if (transform && t_cols != dim && t_cols != dim + 1)
+    return Fail(XV_ERR_ARG, "Dimension mismatch: input vector has dimension " + std::to_string(dim) + " and transform has " +
+                                std::to_string(t_cols) + " columns");
+  return Guard([&] {
+    xv::BackendOptions o;
+    o.mean = mean;
+    o.transform = transform;
+    o.t_rows = t_rows;
+    o.t_cols = t_cols;
+    o.normalize = normalize != 0;
+    o.scaleup = scaleup != 0;
+    xv::BackendApply(device, x, n, dim, o, out, ratio);
+    return XV_OK;
+  });
+}
+
+xv_status xv_segment_mean(int device, const float* x, int32_t n, int32_t dim, const int32_t* seg_off, const int32_t* idx,
+                          int32_t n_seg, int32_t acc64, float* out) {
+  if (n < 0 || dim < 1 || n_seg < 0 || (n_seg > 0 && (!x || !seg_off || !out)))
+    return Fail(XV_ERR_ARG, "xv_segment_mean: bad argument");
+  for (int s = 0; s < n_seg; ++s)
+    if (seg_off[s + 1] < seg_off[s] || seg_off[s] < 0) return Fail(XV_ERR_ARG, "xv_segment_mean: segment offsets must not decrease");
+  if (n_seg > 0 && seg_off[n_seg] > 0 && !idx) return Fail(XV_ERR_ARG, "xv_segment_mean: null index list");
+  return Guard([&] {
+    xv::SegmentMean(device, x, n, dim, seg_off, idx, n_seg, acc64 != 0, out);
     return XV_OK;
   });
 }

@@ -36,6 +36,14 @@ struct ExtractOptions {
   bool cmn_center = true;
   int cmn_min_window = 100;
   std::string vad_rspecifier;
+  // optional device back-end behind the extractor (replaces the ivector-subtract-global-mean | transform-vec |
+  // ivector-normalize-length pipes of egs/sre/v2/run_sre10.sh:240 for the test-side vectors): applied to every
+  // embedding before it is written.  Table jobs only (table_extract.cc).
+  std::vector<float> backend_mean;        // empty: no mean subtraction
+  std::vector<float> backend_transform;   // [rows][cols] row-major, empty: none
+  int backend_t_rows = 0, backend_t_cols = 0;
+  bool backend_normalize = false;
+  bool backend_scaleup = true;
 };
 
 // feats: packed host rows; utterance u = rows row_offsets[u] .. row_offsets[u+1]-1.

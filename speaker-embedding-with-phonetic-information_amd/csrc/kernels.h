@@ -166,6 +166,36 @@ struct FrontEndArgs {
 };
 hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s);
 
+// Speaker-level back-end on the device (the chain of egs/sre/v2/run_sre10.sh:238-241:
+// ivector-subtract-global-mean | transform-vec | ivector-normalize-length):
+//   y = T (x - mean)   [T linear (cols == dim) or affine (cols == dim + 1), each stage optional]
+//   y *= sqrt(out_dim) / |y|   (normalize; scaleup = 0: y /= |y|; a zero vector is left alone)
+struct BackendArgs {
+  const float* x;        // [n][ldx]
+  int n, dim, ldx;
+  const float* mean;     // [dim] or null
+  const float* t;        // [t_rows][t_cols] row-major or null
+  int t_rows, t_cols;
+  int normalize, scaleup;
+  float* out;            // [n][ldo], out_dim = t ? t_rows : dim
+  int ldo;
+  float* ratio;          // [n] length ratio |y| / sqrt(out_dim) (or |y|) before normalisation, or null
+};
+hipError_t launch_backend(const BackendArgs& a, hipStream_t s);
+
+// Segment means (ivector-mean, extract_xvectors_new.sh:106-107): out[s] = mean of the rows idx[seg_off[s] ..
+// seg_off[s+1]) of x, accumulated in list order in fp32 (acc64 = 0) or fp64 (acc64 = 1).  Empty segments give zeros.
+struct SegMeanArgs {
+  const float* x;        // [n][ldx]
+  int dim, ldx;
+  const int32_t* seg_off;  // [n_seg + 1]
+  const int32_t* idx;      // [seg_off[n_seg]] row numbers
+  int n_seg;
+  int acc64;
+  float* out;            // [n_seg][dim]
+};
+hipError_t launch_segment_mean(const SegMeanArgs& a, hipStream_t s);
+
 // 16-bit helpers shared by host packing code (round-to-nearest-even, like v_cvt_pk_bf16_f32).
 uint16_t host_f32_to_bf16(float x);
 float host_bf16_to_f32(uint16_t h);

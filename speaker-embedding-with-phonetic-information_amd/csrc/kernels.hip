@@ -983,6 +983,211 @@ hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Speaker-level back-end.  y = T (x - mean) is a small fp32 GEMM ([n x dim] . [dim x rows], 58 FLOP per byte of its
+// own traffic: bound by the fp32 matrix rate, not by HBM), done with v_mfma_f32_16x16x4_f32 - exact fp32 products,
+// fp32 accumulation in a fixed order.  One workgroup = 64 vectors (one wave = 16 of them) x up to 256 output rows;
+// the transform tile [rows x 32] and the mean-subtracted vector tile [64 x 32] go through LDS (row pitch 36 floats:
+// the 64 lanes of a fragment read hit 64 different banks).  The length normalisation is fused: a lane owns 4 rows of
+// every 16-row fragment of one vector, so |y|^2 is an in-register sum plus two cross-lane adds.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+constexpr int kBkVB = 64, kBkKT = 32, kBkLD = 36, kBkMaxRF = 16;
+
+template <int RF>   // 16-row fragments of the transform handled per workgroup (rows beyond t_rows are zero)
+__global__ __launch_bounds__(256) void backend_gemm_kernel(const BackendArgs a) {
+  __shared__ float ts[RF * 16 * kBkLD];
+  __shared__ float xs[kBkVB * kBkLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v0 = blockIdx.x * kBkVB;
+  const int fi = lane & 15, fk = lane >> 4;
+  f32x4_t acc[RF];
+#pragma unroll
+  for (int r = 0; r < RF; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // register staging of the next K tile (global loads in flight while the current tile is multiplied)
+  constexpr int NT = RF * 16 / 8, NX = kBkVB / 8;
+  float tr[NT], xr[NX];
+  const int kk = tid & 31, r8 = tid >> 5;
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int r = r8 + 8 * i;
+      tr[i] = (r < a.t_rows && k0 + kk < a.dim) ? a.t[(long)r * a.t_cols + k0 + kk] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int v = r8 + 8 * i;
+      float x = 0.f;
+      if (v0 + v < a.n && k0 + kk < a.dim) {
+        x = a.x[(long)(v0 + v) * a.ldx + k0 + kk];
+        if (a.mean) x -= a.mean[k0 + kk];
+      }
+      xr[i] = x;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < a.dim; k0 += kBkKT) {
+    __syncthreads();
+    // thread -> (row = tid / 32 + 8 * i, k = tid % 32): 128 contiguous bytes per row
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ts[(r8 + 8 * i) * kBkLD + kk] = tr[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[(r8 + 8 * i) * kBkLD + kk] = xr[i];
+    __syncthreads();
+    if (k0 + kBkKT < a.dim) fetch(k0 + kBkKT);
+#pragma unroll
+    for (int k4 = 0; k4 < kBkKT / 4; ++k4) {
+      const float b = xs[(wave * 16 + fi) * kBkLD + k4 * 4 + fk];
+#pragma unroll
+      for (int r = 0; r < RF; ++r) {
+        const float w = ts[(r * 16 + fi) * kBkLD + k4 * 4 + fk];
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, acc[r], 0, 0, 0);
+      }
+    }
+  }
+  // lane: vector v0 + wave*16 + fi, rows r*16 + fk*4 + (0..3)
+  const int v = v0 + wave * 16 + fi;
+  const int out_dim = a.t_rows;
+  float ss = 0.f;
+#pragma unroll
+  for (int r = 0; r < RF; ++r) {
+    {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = r * 16 + fk * 4 + q;
+        float y = acc[r][q];
+        if (row < out_dim) {
+          if (a.t_cols == a.dim + 1) y += a.t[(long)row * a.t_cols + a.dim];
+        } else {
+          y = 0.f;
+        }
+        acc[r][q] = y;
+        ss = fmaf(y, y, ss);
+      }
+    }
+  }
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  float scale = 1.f;
+  if (a.normalize || a.ratio) {
+    const float norm = sqrtf(ss);
+    const float ratio = a.scaleup ? norm / sqrtf((float)out_dim) : norm;
+    if (a.ratio && fk == 0 && v < a.n) a.ratio[v] = ratio;
+    if (a.normalize && ratio != 0.f) scale = 1.f / ratio;
+  }
+  if (v < a.n) {
+    float* dst = a.out + (long)v * a.ldo;
+#pragma unroll
+    for (int r = 0; r < RF; ++r) {
+      {
+        const int row = r * 16 + fk * 4;
+        if (row + 3 < out_dim && (a.ldo & 3) == 0 && (out_dim & 3) == 0) {
+          *(f32x4_t*)(dst + row) = acc[r] * scale;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (row + q < out_dim) dst[row + q] = acc[r][q] * scale;
+        }
+      }
+    }
+  }
+}
+
+// No transform (or normalisation of an already transformed table): one wave per vector, streaming.
+__global__ __launch_bounds__(256) void backend_rowwise_kernel(const BackendArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= a.n) return;
+  const float* src = a.x + (long)v * a.ldx;
+  float ss = 0.f;
+  for (int k = lane; k < a.dim; k += 64) {
+    float x = src[k];
+    if (a.mean) x -= a.mean[k];
+    ss = fmaf(x, x, ss);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+  float scale = 1.f;
+  if (a.normalize || a.ratio) {
+    const float norm = sqrtf(ss);
+    const float ratio = a.scaleup ? norm / sqrtf((float)a.dim) : norm;
+    if (a.ratio && lane == 0) a.ratio[v] = ratio;
+    if (a.normalize && ratio != 0.f) scale = 1.f / ratio;
+  }
+  float* dst = a.out + (long)v * a.ldo;
+  for (int k = lane; k < a.dim; k += 64) {
+    float x = src[k];
+    if (a.mean) x -= a.mean[k];
+    dst[k] = x * scale;
+  }
+}
+
+static hipError_t launch_backend_gemm(const BackendArgs& a, hipStream_t s) {
+  const dim3 grid((a.n + kBkVB - 1) / kBkVB), block(256);
+  const int rf = (a.t_rows + 15) / 16;
+  if (rf <= 2) hipLaunchKernelGGL(backend_gemm_kernel<2>, grid, block, 0, s, a);
+  else if (rf <= 4) hipLaunchKernelGGL(backend_gemm_kernel<4>, grid, block, 0, s, a);
+  else if (rf <= 7) hipLaunchKernelGGL(backend_gemm_kernel<7>, grid, block, 0, s, a);
+  else if (rf <= 10) hipLaunchKernelGGL(backend_gemm_kernel<10>, grid, block, 0, s, a);
+  else if (rf <= 13) hipLaunchKernelGGL(backend_gemm_kernel<13>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(backend_gemm_kernel<16>, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_backend(const BackendArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  if (a.dim < 1 || (a.t && a.t_cols != a.dim && a.t_cols != a.dim + 1)) return hipErrorInvalidValue;
+  if (!a.t) {
+    hipLaunchKernelGGL(backend_rowwise_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
+  if (a.t_rows <= kBkMaxRF * 16) return launch_backend_gemm(a, s);
+  // more than 256 output rows: blocks of 256 rows without normalisation, then the row-wise pass on the result
+  for (int r0 = 0; r0 < a.t_rows; r0 += kBkMaxRF * 16) {
+    BackendArgs b = a;
+    b.t = a.t + (long)r0 * a.t_cols;
+    b.t_rows = min(kBkMaxRF * 16, a.t_rows - r0);
+    b.out = a.out + r0;
+    b.normalize = 0;
+    b.ratio = nullptr;
+    hipError_t e = launch_backend_gemm(b, s);
+    if (e != hipSuccess) return e;
+  }
+  if (a.normalize || a.ratio) {
+    BackendArgs c = a;
+    c.x = a.out;
+    c.ldx = a.ldo;
+    c.dim = a.t_rows;
+    c.mean = nullptr;
+    c.t = nullptr;
+    hipLaunchKernelGGL(backend_rowwise_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, c);
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+
+template <typename ACC>
+__global__ __launch_bounds__(256) void segment_mean_kernel(const SegMeanArgs a) {
+  const int s = blockIdx.x;
+  const int b = a.seg_off[s], e = a.seg_off[s + 1];
+  for (int k = threadIdx.x; k < a.dim; k += 256) {
+    ACC acc = 0;
+    for (int i = b; i < e; ++i) acc += (ACC)a.x[(long)a.idx[i] * a.ldx + k];   // list order, like the AddVec loop
+    float m = 0.f;
+    if (e > b) {
+      if constexpr (sizeof(ACC) == 8) m = (float)(acc * (1.0 / (double)(e - b)));
+      else m = acc * (float)(1.0 / (double)(e - b));
+    }
+    a.out[(long)s * a.dim + k] = m;
+  }
+}
+
+hipError_t launch_segment_mean(const SegMeanArgs& a, hipStream_t s) {
+  if (a.n_seg <= 0) return hipSuccess;
+  if (a.acc64) hipLaunchKernelGGL(segment_mean_kernel<double>, dim3(a.n_seg), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(segment_mean_kernel<float>, dim3(a.n_seg), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 uint16_t host_f32_to_bf16(float x) {
   uint32_t u;
   memcpy(&u, &x, 4);

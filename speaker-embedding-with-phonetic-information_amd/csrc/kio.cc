@@ -662,9 +662,102 @@ RandomAccessVectorReader::RandomAccessVectorReader(const std::string& rspecifier
 }
 
 int RandomAccessVectorReader::Find(const std::string& key) {
-  for (size_t i = 0; i < entries_.size(); ++i)
-    if (entries_[i].key == key) return (int)i;
-  return -1;
+  if (index_.size() != entries_.size()) {
+    index_.clear();
+    for (size_t i = 0; i < entries_.size(); ++i) index_.emplace(entries_[i].key, (int)i);   // first entry of a key wins
+  }
+  auto it = index_.find(key);
+  return it == index_.end() ? -1 : it->second;
+}
+
+SequentialVectorReader::SequentialVectorReader(const std::string& rspecifier) {
+  opts_ = ParseRspecifier(rspecifier);
+  in_.Open(opts_.rxfilename);
+}
+
+bool SequentialVectorReader::Next(std::string* key, std::vector<float>* v, std::string* error) {
+  error->clear();
+  if (!ReadKey(in_, key)) return false;
+  if (!opts_.is_scp) {
+    bool binary = ReadBinaryHeader(in_);
+    ReadVector(in_, binary, v);
+    return true;
+  }
+  std::string rx;
+  int c;
+  while ((c = in_.Get()) >= 0 && c != '\n') rx.push_back((char)c);
+  rx = Trim(rx);
+  try {
+    if (rx.empty()) throw KioError("empty rxfilename for key " + *key);
+    Input data;
+    data.Open(rx);
+    bool binary = ReadBinaryHeader(data);
+    ReadVector(data, binary, v);
+  } catch (const KioError& e) {
+    *error = e.what();
+  }
+  return true;
+}
+
+int SequentialVectorReader::Close() { return in_.Close(); }
+
+std::vector<TokenList> ReadTokenVectorTable(const std::string& rspecifier) {
+  RspecifierOptions o = ParseRspecifier(rspecifier);
+  if (o.is_scp) throw KioError("token-vector tables are read from archives (ark:...), not scp: " + rspecifier);
+  Input in;
+  in.Open(o.rxfilename);
+  std::vector<TokenList> out;
+  std::string line;
+  auto flush = [&]() {
+    std::string t = Trim(line);
+    line.clear();
+    if (t.empty()) return;
+    TokenList e;
+    size_t i = 0;
+    while (i < t.size()) {
+      while (i < t.size() && isspace((unsigned char)t[i])) ++i;
+      size_t j = i;
+      while (j < t.size() && !isspace((unsigned char)t[j])) ++j;
+      if (j > i) {
+        if (e.key.empty()) e.key = t.substr(i, j - i);
+        else e.tokens.push_back(t.substr(i, j - i));
+      }
+      i = j;
+    }
+    out.push_back(std::move(e));
+  };
+  int c;
+  while ((c = in.Get()) >= 0) {
+    if (c == '\n') flush();
+    else line.push_back((char)c);
+  }
+  flush();
+  in.Close();
+  return out;
+}
+
+void ReadVectorObject(const std::string& rxfilename, std::vector<float>* v) {
+  Input in;
+  in.Open(rxfilename);
+  bool binary = ReadBinaryHeader(in);
+  ReadVector(in, binary, v);
+  in.Close();
+}
+
+void ReadMatrixObject(const std::string& rxfilename, Matrix* m) {
+  Input in;
+  in.Open(rxfilename);
+  bool binary = ReadBinaryHeader(in);
+  ReadMatrix(in, binary, m);
+  in.Close();
+}
+
+void WriteVectorObject(const std::string& wxfilename, bool binary, const float* v, int n) {
+  Output out;
+  out.Open(wxfilename);
+  if (binary) out.Write("\0B", 2);
+  WriteVector(out, binary, v, n);
+  out.Close();
 }
 
 bool RandomAccessVectorReader::HasKey(const std::string& key) { return Find(key) >= 0; }
@@ -729,6 +822,13 @@ void TableWriter::WriteVec(const std::string& key, const float* v, int n) {
 void TableWriter::WriteMat(const std::string& key, const Matrix& m) {
   Begin(key);
   WriteMatrix(ark_, opts_.binary, m);
+  End();
+}
+
+void TableWriter::WriteInt32(const std::string& key, int32_t v) {
+  Begin(key);
+  xv::WriteInt32(ark_, opts_.binary, v);
+  if (!opts_.binary) ark_.Put('\n');
   End();
 }
 

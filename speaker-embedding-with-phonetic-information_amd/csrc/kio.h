@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace xv {
@@ -142,6 +143,19 @@ class SequentialMatrixReader {
   std::string data_path_;
 };
 
+// Sequential reader of a table of float vectors ("ark:..." or "scp:...").  A corrupt archive is fatal (KioError),
+// an unreadable scp entry is reported through `error` and reading continues.
+class SequentialVectorReader {
+ public:
+  explicit SequentialVectorReader(const std::string& rspecifier);
+  bool Next(std::string* key, std::vector<float>* v, std::string* error);
+  int Close();
+
+ private:
+  RspecifierOptions opts_;
+  Input in_;
+};
+
 // Random-access reader over an scp (used by the front-end for vad.scp: "scp,s,cs:...").
 // Also accepts "ark:" by loading the whole archive.
 class RandomAccessVectorReader {
@@ -153,8 +167,21 @@ class RandomAccessVectorReader {
  private:
   struct Entry { std::string key, rx; std::vector<float> v; bool loaded = false; };
   std::vector<Entry> entries_;
+  std::unordered_map<std::string, int> index_;
   int Find(const std::string& key);
 };
+
+// A text table of token lists, "key tok1 tok2 ...\n" per entry (spk2utt, "ark:$data/spk2utt").
+struct TokenList {
+  std::string key;
+  std::vector<std::string> tokens;
+};
+std::vector<TokenList> ReadTokenVectorTable(const std::string& rspecifier);
+
+// Whole-file Kaldi objects (with the optional binary header): mean.vec, transform.mat.
+void ReadVectorObject(const std::string& rxfilename, std::vector<float>* v);
+void ReadMatrixObject(const std::string& rxfilename, Matrix* m);
+void WriteVectorObject(const std::string& wxfilename, bool binary, const float* v, int n);
 
 // Writer of a table of float vectors / matrices: "ark:", "ark,t:", "ark,scp:a,b", "scp,ark:b,a".
 class TableWriter {
@@ -163,6 +190,7 @@ class TableWriter {
   ~TableWriter();
   void WriteVec(const std::string& key, const float* v, int n);
   void WriteMat(const std::string& key, const Matrix& m);
+  void WriteInt32(const std::string& key, int32_t v);   // Int32Writer (num_utts.ark)
   void Close();
 
  private:

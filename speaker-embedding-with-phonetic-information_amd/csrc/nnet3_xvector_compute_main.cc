@@ -74,6 +74,9 @@ const char* kUsage =
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
     "                                   run apply-cmvn-sliding (--norm-vars=false) and select-voiced-frames on the device\n"
     "                                   in front of the network; the features rspecifier is then the raw feats.scp\n"
+    "  --backend-mean=<vec> --backend-transform=<mat> --backend-normalize-length=true|false [--backend-scaleup=true]\n"
+    "                                   apply ivector-subtract-global-mean | transform-vec | ivector-normalize-length\n"
+    "                                   on the device to every embedding before it is written\n"
     "  --config=<file>  --verbose=<int>  --print-args=true|false  --help\n";
 
 struct Options {
@@ -90,6 +93,8 @@ struct Options {
   int cmn_window = 0;
   bool cmn_center = true;
   std::string vad_rspecifier;
+  std::string backend_mean, backend_transform;
+  bool backend_normalize = false, backend_scaleup = true;
 };
 
 bool ParseBool(const std::string& v, bool* out) {
@@ -154,6 +159,19 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   else if (name == "device") return need_int(&o->device);
   else if (name == "cmn-window") return need_int(&o->cmn_window);
   else if (name == "vad-rspecifier") o->vad_rspecifier = value;
+  else if (name == "backend-mean") o->backend_mean = value;
+  else if (name == "backend-transform") o->backend_transform = value;
+  else if (name == "backend-normalize-length") {
+    if (!ParseBool(value, &o->backend_normalize)) {
+      *err = "invalid boolean for --backend-normalize-length: " + value;
+      return false;
+    }
+  } else if (name == "backend-scaleup") {
+    if (!ParseBool(value, &o->backend_scaleup)) {
+      *err = "invalid boolean for --backend-scaleup: " + value;
+      return false;
+    }
+  }
   else if (name == "cmn-center") {
     if (!ParseBool(value, &o->cmn_center)) {
       *err = "invalid boolean for --cmn-center: " + value;
@@ -311,6 +329,16 @@ int main(int argc, char** argv) {
     eo.cmn_window = opt.cmn_window;
     eo.cmn_center = opt.cmn_center;
     eo.vad_rspecifier = opt.vad_rspecifier;
+    if (!opt.backend_mean.empty()) xv::ReadVectorObject(opt.backend_mean, &eo.backend_mean);
+    if (!opt.backend_transform.empty()) {
+      xv::Matrix t;
+      xv::ReadMatrixObject(opt.backend_transform, &t);
+      eo.backend_transform = t.data;
+      eo.backend_t_rows = t.rows;
+      eo.backend_t_cols = t.cols;
+    }
+    eo.backend_normalize = opt.backend_normalize;
+    eo.backend_scaleup = opt.backend_scaleup;
     xv::TableExtractResult res = xv::RunTableExtraction(
         &engine, eo, feat_rspec, vec_wspec, [](const char* level, const std::string& m) { LogLine(level, 0, m); });
     if (res.reader_status != 0) XWARN("feature input command exited with status " << res.reader_status);

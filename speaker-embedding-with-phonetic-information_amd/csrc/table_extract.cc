@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 
+#include "backend.h"
 #include "kio.h"
 
 namespace xv {
@@ -32,6 +33,13 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
                                       const std::string& vec_wspec, const LogFn& log) {
   TableExtractResult res;
   const int D = engine->info().input_dim, E = engine->info().output_dim;
+  // option errors are raised before the reader thread and the output files exist
+  if (!opt.backend_mean.empty() && (int)opt.backend_mean.size() != E)
+    throw KioError("--backend-mean has dimension " + std::to_string(opt.backend_mean.size()) + ", the embedding has " +
+                   std::to_string(E));
+  if (!opt.backend_transform.empty() && opt.backend_t_cols != E && opt.backend_t_cols != E + 1)
+    throw KioError("Dimension mismatch: the embedding has dimension " + std::to_string(E) + " and --backend-transform has " +
+                   std::to_string(opt.backend_t_cols) + " columns");
   TableWriter writer(vec_wspec);
   std::mutex mu;
   std::condition_variable cv;
@@ -82,7 +90,8 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   });
 
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<float> packed, emb, processed;
+  std::vector<float> packed, emb, processed, post;
+  const bool has_backend = !opt.backend_mean.empty() || !opt.backend_transform.empty() || opt.backend_normalize;
   std::vector<int32_t> offs, ok, sel_row, sel_utt, poffs;
   std::vector<std::string> why;
   std::string fatal;
@@ -177,6 +186,23 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
         emb.resize((size_t)n * E);
         ok.assign(n, 0);
         if (n) ExtractUtterances(engine, opt, packed.data(), offs.data(), n, emb.data(), ok.data(), &why);
+        const float* vec = emb.data();
+        int VE = E;
+        if (n && has_backend) {
+          BackendOptions bo;
+          bo.mean = opt.backend_mean.empty() ? nullptr : opt.backend_mean.data();
+          bo.transform = opt.backend_transform.empty() ? nullptr : opt.backend_transform.data();
+          bo.t_rows = opt.backend_t_rows;
+          bo.t_cols = opt.backend_t_cols;
+          bo.normalize = opt.backend_normalize;
+          bo.scaleup = opt.backend_scaleup;
+          VE = bo.transform ? bo.t_rows : E;
+          post.resize((size_t)n * VE);
+          for (int k = 0; k < n; ++k)
+            if (!ok[k]) std::fill(emb.begin() + (size_t)k * E, emb.begin() + (size_t)(k + 1) * E, 0.f);
+          BackendApply(engine->device(), emb.data(), n, E, bo, post.data(), nullptr);
+          vec = post.data();
+        }
         for (int k = 0; k < n; ++k) {
           const Utt& u = b.utts[idx[k]];
           if (!ok[k]) {
@@ -184,7 +210,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
             ++res.num_fail;
             continue;
           }
-          writer.WriteVec(u.key, &emb[(size_t)k * E], E);
+          writer.WriteVec(u.key, vec + (size_t)k * VE, VE);
           res.frames += u.feats.rows;
           ++res.num_success;
         }
