@@ -311,6 +311,19 @@ Engine::~Engine() {
     if (L.done) (void)hipEventDestroy(L.done);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
+  for (HostSlot& S : host_slots_) {
+    if (S.done) {
+      (void)hipEventSynchronize(S.done);
+      (void)hipEventDestroy(S.done);
+    }
+    S.plan.reset();
+    fr(S.d_feats);
+    fr(S.d_out);
+    fr(S.d_tables);
+    if (S.h_feats) (void)hipHostFree(S.h_feats);
+    if (S.h_out) (void)hipHostFree(S.h_out);
+    if (S.h_tables) (void)hipHostFree(S.h_tables);
+  }
   fr(feats_stage_);
   fr(fe_raw_);
   fr(fe_tab_);
@@ -375,10 +388,10 @@ uint16_t* Engine::ActBase(const Buf& b, int ld) const {
 }
 
 Engine::Plan::~Plan() {
-  if (d_tables) (void)hipFree(d_tables);
+  if (d_tables && !borrowed_tables) (void)hipFree(d_tables);
 }
 
-std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B) {
+void Engine::FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector<uint8_t>* tables) const {
   if (B <= 0) throw EngineError("empty batch");
   std::vector<int32_t> key(B);
   for (int b = 0; b < B; ++b) {
@@ -389,12 +402,6 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
       throw EngineError(m.str());
     }
   }
-  key.push_back(row_offsets[0]);
-  auto hit = plan_cache_.find(key);
-  if (hit != plan_cache_.end()) return hit->second;
-
-  Check(hipSetDevice(device_), "hipSetDevice");
-  auto plan = std::make_shared<Plan>();
   plan->B = B;
   plan->b_pad = RoundUp(B, kBM);
   plan->src_off.assign(row_offsets, row_offsets + B + 1);
@@ -440,46 +447,70 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
       grp_range[2 * g + 1] = (int8_t)std::min(std::max(last + 1 - t0, 0), kRowAlign);
     }
   }
-  // one device allocation, 256-B aligned sections
-  size_t o_src = 0;
-  size_t o_dev = Align256(o_src + (size_t)(B + 1) * 4);
-  size_t o_gu = Align256(o_dev + (size_t)B * 4);
-  size_t o_gr = Align256(o_gu + (size_t)ngrp * 4);
-  size_t o_g0 = Align256(o_gr + (size_t)ngrp * 2);
-  size_t o_g1 = Align256(o_g0 + (size_t)B * 4);
-  size_t o_cn = Align256(o_g1 + (size_t)B * 4);
-  size_t o_or = Align256(o_cn + (size_t)B * 4);
-  size_t total = Align256(o_or + out_row.size() * 4);
-  std::vector<uint8_t> host(total, 0);
-  if (!out_row.empty()) memcpy(host.data() + o_or, out_row.data(), out_row.size() * 4);
-  memcpy(host.data() + o_src, plan->src_off.data(), (size_t)(B + 1) * 4);
-  memcpy(host.data() + o_dev, dev_off.data(), (size_t)B * 4);
-  memcpy(host.data() + o_gu, grp_utt.data(), (size_t)ngrp * 4);
-  memcpy(host.data() + o_gr, grp_range.data(), (size_t)ngrp * 2);
-  memcpy(host.data() + o_g0, g0.data(), (size_t)B * 4);
-  memcpy(host.data() + o_g1, g1.data(), (size_t)B * 4);
-  memcpy(host.data() + o_cn, cnt.data(), (size_t)B * 4);
-  Check(hipMalloc(&plan->d_tables, total), "hipMalloc(plan)");
-  Check(hipMemcpy(plan->d_tables, host.data(), total, hipMemcpyHostToDevice), "hipMemcpy(plan)");
-  const uint8_t* d = (const uint8_t*)plan->d_tables;
-  plan->d_src_off = (const int32_t*)(d + o_src);
-  plan->d_dev_off = (const int32_t*)(d + o_dev);
-  plan->d_grp_utt = (const int32_t*)(d + o_gu);
-  plan->d_grp_range = (const int8_t*)(d + o_gr);
-  plan->d_utt_grp0 = (const int32_t*)(d + o_g0);
-  plan->d_utt_grp1 = (const int32_t*)(d + o_g1);
-  plan->d_utt_count = (const int32_t*)(d + o_cn);
-  plan->d_out_row = (const int32_t*)(d + o_or);
+  // one table image, 256-B aligned sections
+  plan->o_src = 0;
+  plan->o_dev = Align256(plan->o_src + (size_t)(B + 1) * 4);
+  plan->o_gu = Align256(plan->o_dev + (size_t)B * 4);
+  plan->o_gr = Align256(plan->o_gu + (size_t)ngrp * 4);
+  plan->o_g0 = Align256(plan->o_gr + (size_t)ngrp * 2);
+  plan->o_g1 = Align256(plan->o_g0 + (size_t)B * 4);
+  plan->o_cn = Align256(plan->o_g1 + (size_t)B * 4);
+  plan->o_or = Align256(plan->o_cn + (size_t)B * 4);
+  const size_t total = Align256(plan->o_or + out_row.size() * 4);
+  std::vector<uint8_t>& host = *tables;
+  host.assign(total, 0);
+  if (!out_row.empty()) memcpy(host.data() + plan->o_or, out_row.data(), out_row.size() * 4);
+  memcpy(host.data() + plan->o_src, plan->src_off.data(), (size_t)(B + 1) * 4);
+  memcpy(host.data() + plan->o_dev, dev_off.data(), (size_t)B * 4);
+  memcpy(host.data() + plan->o_gu, grp_utt.data(), (size_t)ngrp * 4);
+  memcpy(host.data() + plan->o_gr, grp_range.data(), (size_t)ngrp * 2);
+  memcpy(host.data() + plan->o_g0, g0.data(), (size_t)B * 4);
+  memcpy(host.data() + plan->o_g1, g1.data(), (size_t)B * 4);
+  memcpy(host.data() + plan->o_cn, cnt.data(), (size_t)B * 4);
+}
+
+void Engine::BindPlan(Plan* plan, const void* device_tables) {
+  const uint8_t* d = (const uint8_t*)device_tables;
+  plan->d_src_off = (const int32_t*)(d + plan->o_src);
+  plan->d_dev_off = (const int32_t*)(d + plan->o_dev);
+  plan->d_grp_utt = (const int32_t*)(d + plan->o_gu);
+  plan->d_grp_range = (const int8_t*)(d + plan->o_gr);
+  plan->d_utt_grp0 = (const int32_t*)(d + plan->o_g0);
+  plan->d_utt_grp1 = (const int32_t*)(d + plan->o_g1);
+  plan->d_utt_count = (const int32_t*)(d + plan->o_cn);
+  plan->d_out_row = (const int32_t*)(d + plan->o_or);
+}
+
+std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B) {
+  if (B <= 0) throw EngineError("empty batch");
+  std::vector<int32_t> key(B + 1);
+  for (int b = 0; b < B; ++b) key[b] = row_offsets[b + 1] - row_offsets[b];
+  key[B] = row_offsets[0];
+  auto hit = plan_cache_.find(key);
+  if (hit != plan_cache_.end()) return hit->second;
+  Check(hipSetDevice(device_), "hipSetDevice");
+  auto plan = std::make_shared<Plan>();
+  std::vector<uint8_t> host;
+  FillPlan(row_offsets, B, plan.get(), &host);
+  Check(hipMalloc(&plan->d_tables, host.size()), "hipMalloc(plan)");
+  Check(hipMemcpy(plan->d_tables, host.data(), host.size(), hipMemcpyHostToDevice), "hipMemcpy(plan)");
+  BindPlan(plan.get(), plan->d_tables);
   if (plan_cache_.size() >= 64) plan_cache_.clear();
   plan_cache_[key] = plan;
   return plan;
 }
 
 void Engine::Forward(const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream) {
-  Check(hipSetDevice(device_), "hipSetDevice");
   // lane selection: the engine's own streams rotate; a caller-provided stream is mapped to a lane and ordered
   // behind whatever that lane did last (its buffers are reused)
-  Lane& L = lanes_[stream ? ((size_t)stream >> 6) % lanes_.size() : (next_lane_++ % lanes_.size())];
+  ForwardOnLane(stream ? ((size_t)stream >> 6) % lanes_.size() : (next_lane_++ % lanes_.size()), plan, feats_dev, out_dev,
+                out_ld, stream);
+}
+
+void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev, float* out_dev, int out_ld,
+                           hipStream_t stream) {
+  Check(hipSetDevice(device_), "hipSetDevice");
+  Lane& L = lanes_[lane % lanes_.size()];
   hipStream_t s = stream ? stream : L.stream;
   if (L.busy) Check(hipStreamWaitEvent(s, L.done, 0), "hipStreamWaitEvent(lane)");
   EnsureCapacity(L, plan.rows, plan.b_pad);
@@ -709,6 +740,70 @@ void Engine::FrontEndHost(const float* raw, const int32_t* raw_off, int n_utts, 
   Check(launch_frontend(fa, stream_), "front-end launch");
   Check(hipMemcpyAsync(out, fe_out_.p, (size_t)n_out * D * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(front-end out)");
   Check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+void Engine::EnsurePinned(void** p, size_t* have, size_t bytes) {
+  if (*have >= bytes && *p) return;
+  if (*p) Check(hipHostFree(*p), "hipHostFree");
+  *p = nullptr;
+  *have = 0;
+  const size_t want = bytes + bytes / 4 + 4096;   // grow with some slack: batches differ by a few rows
+  Check(hipHostMalloc(p, want, hipHostMallocDefault), "hipHostMalloc");
+  *have = want;
+}
+
+float* Engine::HostFeats(int slot, size_t rows) {
+  if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
+  HostSlot& S = host_slots_[slot];
+  if (S.pending) throw EngineError("host slot reused before WaitHost");
+  Check(hipSetDevice(device_), "hipSetDevice");
+  EnsurePinned(&S.h_feats, &S.h_feats_bytes, std::max(rows, (size_t)1) * info_.input_dim * 4);
+  return (float*)S.h_feats;
+}
+
+void Engine::SubmitHost(int slot, const int32_t* row_offsets, int B) {
+  if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
+  HostSlot& S = host_slots_[slot];
+  if (S.pending) throw EngineError("host slot reused before WaitHost");
+  if (row_offsets[0] != 0) throw EngineError("SubmitHost: row_offsets[0] must be 0");
+  Check(hipSetDevice(device_), "hipSetDevice");
+  const size_t lane = (size_t)slot % lanes_.size();
+  hipStream_t s = lanes_[lane].stream;
+  if (!S.done) Check(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate(slot)");
+  S.plan.reset(new Plan());
+  std::vector<uint8_t> tables;
+  FillPlan(row_offsets, B, S.plan.get(), &tables);
+  const size_t fbytes = (size_t)row_offsets[B] * info_.input_dim * 4;
+  const size_t obytes = (size_t)(frame_mode_ ? S.plan->n_out : B) * info_.output_dim * 4;
+  if (fbytes > S.h_feats_bytes) throw EngineError("SubmitHost: the batch is larger than the buffer HostFeats returned");
+  // (re)allocation frees device memory, which waits for the device: buffers only grow
+  auto grow = [&](Buf* b, size_t need) {
+    if (b->bytes < need || !b->p) Ensure(b, need + need / 4 + 256, false);
+  };
+  grow(&S.d_feats, fbytes);
+  grow(&S.d_out, obytes);
+  grow(&S.d_tables, tables.size());
+  EnsurePinned(&S.h_tables, &S.h_tables_bytes, tables.size());
+  EnsurePinned(&S.h_out, &S.h_out_bytes, std::max(obytes, (size_t)4));
+  memcpy(S.h_tables, tables.data(), tables.size());
+  S.plan->d_tables = S.d_tables.p;
+  S.plan->borrowed_tables = true;
+  BindPlan(S.plan.get(), S.d_tables.p);
+  Check(hipMemcpyAsync(S.d_tables.p, S.h_tables, tables.size(), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plan tables)");
+  Check(hipMemcpyAsync(S.d_feats.p, S.h_feats, fbytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(feats)");
+  ForwardOnLane(lane, *S.plan, (const float*)S.d_feats.p, (float*)S.d_out.p, info_.output_dim, s);
+  Check(hipMemcpyAsync(S.h_out, S.d_out.p, obytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(out)");
+  Check(hipEventRecord(S.done, s), "hipEventRecord(slot)");
+  S.pending = true;
+}
+
+const float* Engine::WaitHost(int slot) {
+  if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
+  HostSlot& S = host_slots_[slot];
+  if (!S.pending) throw EngineError("WaitHost: nothing submitted on this slot");
+  Check(hipEventSynchronize(S.done), "hipEventSynchronize(slot)");
+  S.pending = false;
+  return (const float*)S.h_out;
 }
 
 void Engine::ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out) {

@@ -62,6 +62,16 @@ class Engine {
   // Host convenience: H2D, forward, D2H, synchronise.  Segment-level output: out is [B][output_dim]; frame-level
   // output: out is [sum of chunk lengths][output_dim] (one row per input frame), chunk b starting at OutRowOffset.
   void ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out);
+  // Asynchronous host path (table jobs): kNumHostSlots batches in flight, each with its own pinned staging buffers,
+  // device staging and plan tables, on the stream of lane (slot % lanes).  Usage per slot:
+  //   float* f = HostFeats(slot, rows);          // pinned buffer to pack the chunks of the batch into
+  //   SubmitHost(slot, row_offsets, B);          // H2D, forward, D2H - all asynchronous, returns at once
+  //   const float* out = WaitHost(slot);         // blocks until the batch is done; [B][output_dim] (pinned)
+  // A slot must be waited for before it is reused.  row_offsets[0] must be 0.
+  static constexpr int kNumHostSlots = 2;
+  float* HostFeats(int slot, size_t rows);
+  void SubmitHost(int slot, const int32_t* row_offsets, int B);
+  const float* WaitHost(int slot);
   bool frame_mode() const { return frame_mode_; }
   // Feature front-end on the device: sliding-window CMN (cmn_window <= 0: none) + selection of the rows listed in
   // sel_row (absolute raw rows, ascending; sel_utt = their utterance).  Host buffers in / out, blocking.
@@ -103,6 +113,24 @@ class Engine {
     Buf in_hi, in_lo, partial, stats_hi, stats_lo, out_f32, splitk_ws, frame_f32;
     int cap_rows = 0, cap_b = 0;
   };
+  struct HostSlot {
+    void* h_feats = nullptr;   // pinned
+    size_t h_feats_bytes = 0;
+    void* h_out = nullptr;     // pinned
+    size_t h_out_bytes = 0;
+    void* h_tables = nullptr;  // pinned copy of the plan tables
+    size_t h_tables_bytes = 0;
+    Buf d_feats, d_out, d_tables;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    std::unique_ptr<Plan> plan;   // its tables live in d_tables (not owned by the plan)
+  };
+  HostSlot host_slots_[kNumHostSlots];
+  void EnsurePinned(void** p, size_t* have, size_t bytes);
+  // host part of a plan: fills everything but the device pointers and returns the table image
+  void FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector<uint8_t>* tables) const;
+  static void BindPlan(Plan* plan, const void* device_tables);
+  void ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream);
   void Check(hipError_t e, const char* what) const;
   void Ensure(Buf* b, size_t bytes, bool zero);
   void EnsureCapacity(Lane& L, int rows, int b_pad);
@@ -133,7 +161,9 @@ class Engine {
 struct Engine::Plan {
   int B = 0, b_pad = 0, rows = 0, src_rows = 0;
   std::vector<int32_t> src_off;  // [B+1]
-  void* d_tables = nullptr;      // one device allocation holding all tables below
+  void* d_tables = nullptr;      // one device allocation holding all tables below (owned unless borrowed)
+  bool borrowed_tables = false;  // tables live in a host slot's buffer
+  size_t o_src = 0, o_dev = 0, o_gu = 0, o_gr = 0, o_g0 = 0, o_g1 = 0, o_cn = 0, o_or = 0;  // table offsets
   const int32_t* d_src_off = nullptr;
   const int32_t* d_dev_off = nullptr;
   const int32_t* d_grp_utt = nullptr;

@@ -120,4 +120,77 @@ void ExtractUtterances(Engine* eng, const ExtractOptions& opt, const float* feat
     }
 }
 
+void ExtractJob::Start(Engine* eng, const ExtractOptions& opt, int slot, const float* feats, const int32_t* row_offsets,
+                       int n_utts) {
+  eng_ = eng;
+  opt_ = opt;
+  slot_ = slot;
+  n_utts_ = n_utts;
+  feats_ = feats;
+  row_offsets_ = row_offsets;
+  async_ = false;
+  chunks_.clear();
+  ok_.assign(n_utts, 0);
+  why_.assign(n_utts, std::string());
+  long rows = 0;
+  for (int u = 0; u < n_utts; ++u) {
+    std::string reason;
+    const size_t before = chunks_.size();
+    ok_[u] = PlanChunks(u, row_offsets[u + 1] - row_offsets[u], opt.chunk_size, opt.min_chunk_size, opt.pad_input,
+                        eng->info().min_frames, &chunks_, &reason)
+                 ? 1
+                 : 0;
+    if (!ok_[u]) why_[u] = reason;
+    for (size_t k = before; k < chunks_.size(); ++k) rows += chunks_[k].len + chunks_[k].left_pad + chunks_[k].right_pad;
+  }
+  if (chunks_.empty() || rows > opt.max_batch_rows || (int)chunks_.size() > opt.max_batch_chunks) return;  // Finish() does it
+  const int D = eng->info().input_dim;
+  float* pack = eng->HostFeats(slot, (size_t)rows);
+  std::vector<int32_t> offs(1, 0);
+  size_t r = 0;
+  for (const Chunk& c : chunks_) {
+    const float* src = feats + ((size_t)row_offsets[c.utt] + c.start) * D;
+    for (int p = 0; p < c.left_pad; ++p, ++r) memcpy(pack + r * D, src, (size_t)D * 4);
+    memcpy(pack + r * D, src, (size_t)c.len * D * 4);
+    r += c.len;
+    for (int p = 0; p < c.right_pad; ++p, ++r) memcpy(pack + r * D, src + (size_t)(c.len - 1) * D, (size_t)D * 4);
+    offs.push_back((int32_t)r);
+  }
+  eng->SubmitHost(slot, offs.data(), (int)chunks_.size());
+  async_ = true;
+}
+
+void ExtractJob::Finish(float* out, int32_t* ok, std::vector<std::string>* why) {
+  Engine* eng = eng_;
+  eng_ = nullptr;
+  if (!eng) throw EngineError("ExtractJob::Finish without Start");
+  if (!async_) {
+    ExtractUtterances(eng, opt_, feats_, row_offsets_, n_utts_, out, ok, why);
+    return;
+  }
+  const float* emb = eng->WaitHost(slot_);
+  const int E = eng->info().output_dim;
+  for (int u = 0; u < n_utts_; ++u) {
+    ok[u] = ok_[u];
+    if (ok[u]) memset(out + (size_t)u * E, 0, (size_t)E * 4);
+  }
+  if (why) *why = why_;
+  std::vector<float> tot(n_utts_, 0.f);
+  for (size_t k = 0; k < chunks_.size(); ++k) {
+    // xvector_avg.AddVec(len, xvector) in fp32, like the reference binary
+    const Chunk& c = chunks_[k];
+    float* dst = out + (size_t)c.utt * E;
+    const float* e = emb + k * E;
+    const float w = (float)c.len;
+    for (int d = 0; d < E; ++d) dst[d] += w * e[d];
+    tot[c.utt] += w;
+  }
+  for (int u = 0; u < n_utts_; ++u)
+    if (ok[u]) {
+      const float s = 1.0f / tot[u];
+      float* dst = out + (size_t)u * E;
+      for (int d = 0; d < E; ++d) dst[d] *= s;
+    }
+}
+
 }  // namespace xv

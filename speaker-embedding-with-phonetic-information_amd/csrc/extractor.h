@@ -51,4 +51,27 @@ struct ExtractOptions {
 void ExtractUtterances(Engine* eng, const ExtractOptions& opt, const float* feats, const int32_t* row_offsets, int n_utts,
                        float* out, int32_t* ok, std::vector<std::string>* why);
 
+// The same computation split in two so that a table job can keep two batches in flight (the packing / writing of one
+// overlaps the device work of the other).  Start() plans the chunks and, when they fit one forward batch, packs them
+// into the engine's pinned buffer of `slot` and submits them asynchronously; Finish() waits, averages and reports.
+// Utterance sets that need several forward batches (long recordings cut into chunks) are processed synchronously
+// inside Finish().  feats / row_offsets must stay valid until Finish() returns.
+class ExtractJob {
+ public:
+  void Start(Engine* eng, const ExtractOptions& opt, int slot, const float* feats, const int32_t* row_offsets, int n_utts);
+  void Finish(float* out, int32_t* ok, std::vector<std::string>* why);
+  bool active() const { return eng_ != nullptr; }
+
+ private:
+  Engine* eng_ = nullptr;
+  ExtractOptions opt_;
+  int slot_ = 0, n_utts_ = 0;
+  const float* feats_ = nullptr;
+  const int32_t* row_offsets_ = nullptr;
+  bool async_ = false;
+  std::vector<Chunk> chunks_;
+  std::vector<int32_t> ok_;
+  std::vector<std::string> why_;
+};
+
 }  // namespace xv

@@ -70,12 +70,13 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
           ++num_fail_read;
           continue;
         }
+        // a batch never exceeds max_batch_rows (one forward pass) unless a single utterance does
+        if (!cur.utts.empty() && (rows + m.rows > opt.max_batch_rows || (int)cur.utts.size() >= opt.max_batch_chunks)) push(false);
         Utt u;
         u.key = key;
         u.feats = std::move(m);
         rows += u.feats.rows;
         cur.utts.push_back(std::move(u));
-        if (rows >= opt.max_batch_rows || (int)cur.utts.size() >= opt.max_batch_chunks) push(false);
       }
       res.reader_status = rd.Close();
       push(true);
@@ -90,16 +91,75 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   });
 
   const auto t0 = std::chrono::steady_clock::now();
-  std::vector<float> packed, emb, processed, post;
   const bool has_backend = !opt.backend_mean.empty() || !opt.backend_transform.empty() || opt.backend_normalize;
-  std::vector<int32_t> offs, ok, sel_row, sel_utt, poffs;
+  std::vector<int32_t> sel_row, sel_utt, poffs;
+  std::vector<float> processed, emb, post;
+  std::vector<int32_t> ok;
   std::vector<std::string> why;
   std::string fatal;
   const bool use_frontend = opt.cmn_window > 0 || !opt.vad_rspecifier.empty();
   std::unique_ptr<RandomAccessVectorReader> vad;
   if (!opt.vad_rspecifier.empty()) vad.reset(new RandomAccessVectorReader(opt.vad_rspecifier));
+
+  // Two batches in flight: while the device works on one (ExtractJob::Start returns at once), the previous one is
+  // averaged, post-processed and written, and the next one is packed.  Output order = input order.
+  struct Work {
+    Batch b;
+    std::vector<int> idx;        // utterances of b that entered the device batch
+    std::vector<float> packed;   // their rows (after the optional front-end), back to back
+    std::vector<int32_t> offs;
+    ExtractJob job;
+  };
+  Work work[Engine::kNumHostSlots];
+  int cur = 0;
+  // stage timing of the consumer thread (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
+  const bool timing = getenv("XVEC_TIMING") != nullptr;
+  double t_wait = 0, t_pack = 0, t_start = 0, t_fin = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
+
+  auto finalize = [&](Work& w) {
+    const int n = (int)w.idx.size();
+    emb.resize((size_t)n * E);
+    ok.assign(n, 0);
+    why.assign(n, std::string());
+    w.job.Finish(emb.data(), ok.data(), &why);
+    const float* vec = emb.data();
+    int VE = E;
+    if (n && has_backend) {
+      BackendOptions bo;
+      bo.mean = opt.backend_mean.empty() ? nullptr : opt.backend_mean.data();
+      bo.transform = opt.backend_transform.empty() ? nullptr : opt.backend_transform.data();
+      bo.t_rows = opt.backend_t_rows;
+      bo.t_cols = opt.backend_t_cols;
+      bo.normalize = opt.backend_normalize;
+      bo.scaleup = opt.backend_scaleup;
+      VE = bo.transform ? bo.t_rows : E;
+      post.resize((size_t)n * VE);
+      for (int k = 0; k < n; ++k)
+        if (!ok[k]) std::fill(emb.begin() + (size_t)k * E, emb.begin() + (size_t)(k + 1) * E, 0.f);
+      BackendApply(engine->device(), emb.data(), n, E, bo, post.data(), nullptr);
+      vec = post.data();
+    }
+    for (int k = 0; k < n; ++k) {
+      const Utt& u = w.b.utts[w.idx[k]];
+      if (!ok[k]) {
+        warn(why[k] + ": " + u.key);
+        ++res.num_fail;
+        continue;
+      }
+      writer.WriteVec(u.key, vec + (size_t)k * VE, VE);
+      res.frames += u.feats.rows;
+      ++res.num_success;
+    }
+    w.b = Batch();
+  };
+
   for (;;) {
     Batch b;
+    const auto tw0 = now();
     {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return !queue.empty(); });
@@ -107,16 +167,24 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       queue.pop_front();
       cv.notify_all();
     }
+    t_wait += secs(tw0, now());
+    const bool last = b.last;
     if (!b.utts.empty() && fatal.empty()) {
       try {
+        const auto tp0 = now();
+        Work& w = work[cur];
+        w.b = std::move(b);
+        std::vector<float>& packed = w.packed;
+        std::vector<int32_t>& offs = w.offs;
+        std::vector<int>& idx = w.idx;
         offs.assign(1, 0);
+        idx.clear();
         size_t total = 0;
-        for (const Utt& u : b.utts) total += (size_t)u.feats.rows;
+        for (const Utt& u : w.b.utts) total += (size_t)u.feats.rows;
         packed.resize(total * D);
         size_t r = 0;
-        std::vector<int> idx;  // utterances that enter the device batch
-        for (size_t i = 0; i < b.utts.size(); ++i) {
-          const Utt& u = b.utts[i];
+        for (size_t i = 0; i < w.b.utts.size(); ++i) {
+          const Utt& u = w.b.utts[i];
           if (u.feats.rows > 0 && u.feats.cols != D) {
             std::ostringstream m;
             m << "feature dimension " << u.feats.cols << " of utterance " << u.key << " does not match the model's " << D;
@@ -139,7 +207,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
           std::vector<int32_t> raw_off2(1, 0);
           std::vector<float> raw2;
           for (int k = 0; k < n; ++k) {
-            const Utt& u = b.utts[idx[k]];
+            const Utt& u = w.b.utts[idx[k]];
             const int T = u.feats.rows;
             const std::vector<float>* v = nullptr;
             if (vad) {
@@ -183,42 +251,40 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
           packed.swap(processed);
           offs = poffs;
         }
-        emb.resize((size_t)n * E);
-        ok.assign(n, 0);
-        if (n) ExtractUtterances(engine, opt, packed.data(), offs.data(), n, emb.data(), ok.data(), &why);
-        const float* vec = emb.data();
-        int VE = E;
-        if (n && has_backend) {
-          BackendOptions bo;
-          bo.mean = opt.backend_mean.empty() ? nullptr : opt.backend_mean.data();
-          bo.transform = opt.backend_transform.empty() ? nullptr : opt.backend_transform.data();
-          bo.t_rows = opt.backend_t_rows;
-          bo.t_cols = opt.backend_t_cols;
-          bo.normalize = opt.backend_normalize;
-          bo.scaleup = opt.backend_scaleup;
-          VE = bo.transform ? bo.t_rows : E;
-          post.resize((size_t)n * VE);
-          for (int k = 0; k < n; ++k)
-            if (!ok[k]) std::fill(emb.begin() + (size_t)k * E, emb.begin() + (size_t)(k + 1) * E, 0.f);
-          BackendApply(engine->device(), emb.data(), n, E, bo, post.data(), nullptr);
-          vec = post.data();
-        }
-        for (int k = 0; k < n; ++k) {
-          const Utt& u = b.utts[idx[k]];
-          if (!ok[k]) {
-            warn(why[k] + ": " + u.key);
-            ++res.num_fail;
-            continue;
-          }
-          writer.WriteVec(u.key, vec + (size_t)k * VE, VE);
-          res.frames += u.feats.rows;
-          ++res.num_success;
+        const auto tp1 = now();
+        t_pack += secs(tp0, tp1);
+        if (n) {
+          w.job.Start(engine, opt, cur, packed.data(), offs.data(), n);
+          const auto tp2 = now();
+          t_start += secs(tp1, tp2);
+          Work& prev = work[cur ^ 1];
+          if (prev.job.active()) finalize(prev);
+          t_fin += secs(tp2, now());
+          cur ^= 1;
+        } else {
+          w.b = Batch();
         }
       } catch (const std::exception& ex) {
         fatal = ex.what();  // keep draining the queue so the reader can finish
       }
     }
-    if (b.last) break;
+    if (last) break;
+  }
+  // the batches still in flight, oldest first
+  for (int k = 0; k < Engine::kNumHostSlots && fatal.empty(); ++k) {
+    Work& w = work[(cur + k) % Engine::kNumHostSlots];
+    if (!w.job.active()) continue;
+    try {
+      finalize(w);
+    } catch (const std::exception& ex) {
+      fatal = ex.what();
+    }
+  }
+  if (timing) {
+    std::ostringstream m;
+    m << "consumer stages: wait for reader " << t_wait << " s, pack " << t_pack << " s, plan+submit " << t_start
+      << " s, finish+write " << t_fin << " s";
+    log("LOG", m.str());
   }
   reader.join();
   writer.Close();

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the drop-in command line (file in, file out; PCIe and Kaldi I/O included): writes a synthetic
+binary feature archive, runs bin/nnet3-xvector-compute on it exactly as extract_xvectors_new.sh:92-93 would, and
+reports utterances/s from the wall clock and from the tool's own "Time taken" line."""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+from oracle import kaldi_io as kio  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    extra = sys.argv[3:]
+    d = tempfile.mkdtemp(prefix="xvcli", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    net, line = H.synth_model("v2_xvector")
+    open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
+    pool = [H.features(1000 + i, T) for i in range(64)]
+    with open(os.path.join(d, "feats.ark"), "wb") as f:
+        for i in range(n):
+            f.write(("utt%07d " % i).encode() + b"\0B")
+            kio.write_matrix(f, pool[i % 64])
+    binp = os.path.join(ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
+    cmd = [binp, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine"] + extra + [
+        os.path.join(d, "final.raw"), "ark:%s/feats.ark" % d, "ark,scp:%s/x.ark,%s/x.scp" % (d, d)]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    wall = time.perf_counter() - t0
+    err = r.stderr.decode()
+    m = re.search(r"Time taken ([0-9.e+-]+)s", err)
+    loop = float(m.group(1)) if m else None
+    print(json.dumps({"utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
+                      "loop_s": loop, "loop_utt_per_s": n / loop if loop else None,
+                      "feature_GB": n * T * 23 * 4 / 1e9, "tail": [l for l in err.strip().splitlines() if "stages" in l or "Done" in l]}))
+    for fn in os.listdir(d):
+        os.remove(os.path.join(d, fn))
+    os.rmdir(d)
+
+
+if __name__ == "__main__":
+    main()
