@@ -93,6 +93,9 @@ struct GemmArgs {
   int ksplit;
   int ksteps_per_slice;
   float* splitk_ws;
+  // start stagger of the 256x128 variant (set by the launcher): the first stagger_wgs workgroups sleep up to
+  // stagger_units x 2048 cycles, see the kernel
+  int stagger_wgs, stagger_units;
 };
 
 // Launches the spliced-affine GEMM. Returns hipSuccess or the launch error.

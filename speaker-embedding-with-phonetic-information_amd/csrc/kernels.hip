@@ -436,6 +436,14 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   if (mt >= m_tiles) return;
   const int m0 = mt * 256;
   const int n0 = nt * kBN;
+  // Start stagger: the first workgroup of every CU waits a different fraction of one tile time.  All tiles take the
+  // same time, so without it every CU reaches its epilogue in the same microsecond and the 32 MB store burst of a
+  // round (128 KiB per CU) runs at the HBM write rate with nothing to overlap; staggered, the stores of one CU drain
+  // while the others multiply.  The late starters simply take one tile less (6.25 tiles per CU -> 6 or 7).
+  if (a.stagger_units > 0 && bid < a.stagger_wgs) {
+    const int n = (((bid >> 3) * 37 + (bid & 7) * 5) & 31) * a.stagger_units >> 5;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);   // 2048 cycles each
+  }
 
   const int ld_row = lane >> 2;
   const int ld_chunk = (lane & 3) ^ ((lane >> 3) & 3);
@@ -651,6 +659,17 @@ static void build_groups(GemmArgs* g) {
   }
 }
 
+static int device_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
@@ -667,6 +686,17 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   dim3 grid(mt8 * a.n_tiles), block(512);
   GemmArgs b = a;
   build_groups(&b);
+  {
+    // stagger window = XVEC_GEMM_STAGGER percent of the modelled tile time (K steps x ~2200 cycles + ~14000 fixed)
+    static int pct = -1;
+    if (pct < 0) {
+      const char* e = getenv("XVEC_GEMM_STAGGER");
+      pct = (e && *e) ? atoi(e) : 85;
+    }
+    const int cus = device_cu_count();
+    b.stagger_wgs = cus;
+    b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * 2200 + 14000) * pct / 100 / 2048) : 0;
+  }
   hipLaunchKernelGGL((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
   return hipGetLastError();
 }
