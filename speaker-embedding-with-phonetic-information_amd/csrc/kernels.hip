@@ -88,11 +88,60 @@ __device__ __forceinline__ int swap_fields(int rho) {
 
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
 
+// Per-lane epilogue parameters.  Variant 2 loads them BEFORE the K loop: read inside the epilogue, the dependent global
+// loads (bias / scale / offset, and for the statistics epilogue the valid-row table) sat on every tile's critical path.
+struct EpiRegs {
+  float bs[16], sc[16], of[16];   // act / f32: index p*4 + r;  stats: index q (one column per 16-column fragment)
+  int first[4], last[4];          // stats: valid rows [first, last) of the four 16-row fragments p
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int mbase, const int nbase, const int lane,
+                                                  EpiRegs& e) {
+  const int fr_i = lane & 15;
+  const int fr_g = lane >> 4;
+  if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
+    // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
+    // h = p>>1, position inside the group (p&1)*4 + r
+    const int ncol = nbase + fr_g * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = ncol + (p >> 1) * 32 + (p & 1) * 4;
+      const f32x4 b4 = *(const f32x4*)(a.bias + c);
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, o4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.bn) {
+        s4 = *(const f32x4*)(a.scale + c);
+        o4 = *(const f32x4*)(a.offset + c);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e.bs[p * 4 + r] = b4[r];
+        e.sc[p * 4 + r] = s4[r];
+        e.of[p * 4 + r] = o4[r];
+      }
+    }
+  } else if constexpr (EPI == kEpiStats) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = nbase + q * 16 + fr_i;
+      e.bs[q] = a.bias[col];
+      e.sc[q] = a.bn ? a.scale[col] : 1.f;
+      e.of[q] = a.bn ? a.offset[col] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int grp = (mbase + p * 16) >> 4;
+      e.first[p] = a.grp_range[2 * grp];
+      e.last[p] = a.grp_range[2 * grp + 1];
+    }
+  }
+}
+
 // Shared epilogue of the GEMM kernels.  acc[p][q] is the 16x16 fragment (P-tile fragment p) x (Q-tile fragment q)
 // of one wave's 64x64 tile whose first frame is mbase and first output column nbase.
 template <int PREC, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], const int mbase, const int nbase,
-                                              const int lane) {
+                                              const int lane, const EpiRegs& e) {
   constexpr bool SPLIT = (PREC == kPrecBf16x3);
   constexpr bool F16 = (PREC == kPrecFp16);
   const int fr_i = lane & 15;
@@ -111,29 +160,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
     // h = p>>1, position inside the group (p&1)*4 + r
     const int ncol = nbase + fr_g * 8;
-    float bs[16], sc[16], of[16];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int c = ncol + (p >> 1) * 32 + (p & 1) * 4;
-      const f32x4 b4 = *(const f32x4*)(a.bias + c);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bs[p * 4 + r] = b4[r];
-      if (a.bn) {
-        const f32x4 s4 = *(const f32x4*)(a.scale + c);
-        const f32x4 o4 = *(const f32x4*)(a.offset + c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sc[p * 4 + r] = s4[r];
-          of[p * 4 + r] = o4[r];
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sc[p * 4 + r] = 1.f;
-          of[p * 4 + r] = 0.f;
-        }
-      }
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = mbase + q * 16 + fr_i;
@@ -142,9 +168,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + bs[p * 4 + r];
+          float z = acc[p][q][r] + e.bs[p * 4 + r];
           if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
-          if (a.bn) z = z * sc[p * 4 + r] + of[p * 4 + r];
+          if (a.bn) z = z * e.sc[p * 4 + r] + e.of[p * 4 + r];
           y[p * 4 + r] = z;
         }
       if constexpr (EPI == kEpiF32) {
@@ -179,26 +205,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       }
     }
   } else {
-    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i
+    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i.  After the cross-lane adds all four lanes
+    // of a column hold the sums of every fragment p, so lane group fr_g stores fragment p = fr_g: two store
+    // instructions per q (4 fragments x 16 columns each) instead of eight 16-lane ones - the epilogue is bound by the
+    // number of store instructions a CU can issue, not by their bytes.
+    const int grp0 = mbase >> 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = nbase + q * 16 + fr_i;
-      const float b = a.bias[col];
-      const float sc = a.bn ? a.scale[col] : 1.f;
-      const float of = a.bn ? a.offset[col] : 0.f;
+      float s1v[4], s2v[4];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int grp = (mbase + p * 16) >> 4;
-        const int first = a.grp_range[2 * grp];
-        const int last = a.grp_range[2 * grp + 1];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + b;
+          float z = acc[p][q][r] + e.bs[q];
           if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
-          if (a.bn) z = z * sc + of;
+          if (a.bn) z = z * e.sc[q] + e.of[q];
           const int rr = fr_g * 4 + r;
-          const bool ok = (rr >= first) && (rr < last);
+          const bool ok = (rr >= e.first[p]) && (rr < e.last[p]);
           s1 += ok ? z : 0.f;
           s2 += ok ? z * z : 0.f;
         }
@@ -206,10 +231,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         s2 += __shfl_xor(s2, 16);
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
-        float* dst = a.partial + (long)grp * 2 * a.ldp + col;
-        if (fr_g == 0) dst[0] = s1;
-        if (fr_g == 1) dst[a.ldp] = s2;
+        s1v[p] = s1;
+        s2v[p] = s2;
       }
+      const float v1 = fr_g == 0 ? s1v[0] : fr_g == 1 ? s1v[1] : fr_g == 2 ? s1v[2] : s1v[3];
+      const float v2 = fr_g == 0 ? s2v[0] : fr_g == 1 ? s2v[1] : fr_g == 2 ? s2v[2] : s2v[3];
+      float* dst = a.partial + (long)(grp0 + fr_g) * 2 * a.ldp + col;
+      dst[0] = v1;
+      dst[a.ldp] = v2;
     }
   }
 }
@@ -370,7 +399,9 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done with this one
   }
 
-  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane);
+  EpiRegs er;
+  epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
+  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,6 +475,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     const int n = (((bid >> 3) * 37 + (bid & 7) * 5) & 31) * a.stagger_units >> 5;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);   // 2048 cycles each
   }
+
+  EpiRegs er;   // epilogue parameters, in flight during the K loop
+  epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
 
   const int ld_row = lane >> 2;
   const int ld_chunk = (lane & 3) ^ ((lane >> 3) & 3);
@@ -615,7 +649,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     plain_barrier();
   }
   if (group == 0) plain_barrier();
-  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane);
+  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
 }
 
 // Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring.  XVEC_GEMM_VARIANT overrides.
