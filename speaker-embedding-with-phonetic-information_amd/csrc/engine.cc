@@ -761,13 +761,13 @@ float* Engine::HostFeats(int slot, size_t rows) {
   return (float*)S.h_feats;
 }
 
-void Engine::SubmitHost(int slot, const int32_t* row_offsets, int B) {
+void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B) {
   if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
   HostSlot& S = host_slots_[slot];
   if (S.pending) throw EngineError("host slot reused before WaitHost");
   if (row_offsets[0] != 0) throw EngineError("SubmitHost: row_offsets[0] must be 0");
   Check(hipSetDevice(device_), "hipSetDevice");
-  const size_t lane = (size_t)slot % lanes_.size();
+  const size_t lane = (size_t)seq % lanes_.size();
   hipStream_t s = lanes_[lane].stream;
   if (!S.done) Check(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate(slot)");
   S.plan.reset(new Plan());

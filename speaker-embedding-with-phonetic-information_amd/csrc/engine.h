@@ -62,15 +62,16 @@ class Engine {
   // Host convenience: H2D, forward, D2H, synchronise.  Segment-level output: out is [B][output_dim]; frame-level
   // output: out is [sum of chunk lengths][output_dim] (one row per input frame), chunk b starting at OutRowOffset.
   void ForwardHost(const float* feats, const int32_t* row_offsets, int B, float* out);
-  // Asynchronous host path (table jobs): kNumHostSlots batches in flight, each with its own pinned staging buffers,
-  // device staging and plan tables, on the stream of lane (slot % lanes).  Usage per slot:
+  // Asynchronous host path (table jobs): kNumHostSlots batches queued or in flight, each with its own pinned staging
+  // buffers, device staging and plan tables; batch number `seq` runs on the stream of lane (seq % lanes), so
+  // consecutive batches alternate lanes while a third one is already queued behind them.  Usage per slot:
   //   float* f = HostFeats(slot, rows);          // pinned buffer to pack the chunks of the batch into
-  //   SubmitHost(slot, row_offsets, B);          // H2D, forward, D2H - all asynchronous, returns at once
+  //   SubmitHost(slot, seq, row_offsets, B);     // H2D, forward, D2H - all asynchronous, returns at once
   //   const float* out = WaitHost(slot);         // blocks until the batch is done; [B][output_dim] (pinned)
   // A slot must be waited for before it is reused.  row_offsets[0] must be 0.
-  static constexpr int kNumHostSlots = 2;
+  static constexpr int kNumHostSlots = 3;
   float* HostFeats(int slot, size_t rows);
-  void SubmitHost(int slot, const int32_t* row_offsets, int B);
+  void SubmitHost(int slot, long seq, const int32_t* row_offsets, int B);
   const float* WaitHost(int slot);
   bool frame_mode() const { return frame_mode_; }
   // Feature front-end on the device: sliding-window CMN (cmn_window <= 0: none) + selection of the rows listed in

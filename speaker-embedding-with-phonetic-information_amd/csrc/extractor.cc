@@ -120,8 +120,8 @@ void ExtractUtterances(Engine* eng, const ExtractOptions& opt, const float* feat
     }
 }
 
-void ExtractJob::Start(Engine* eng, const ExtractOptions& opt, int slot, const float* feats, const int32_t* row_offsets,
-                       int n_utts) {
+void ExtractJob::Start(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* feats,
+                       const int32_t* row_offsets, int n_utts) {
   eng_ = eng;
   opt_ = opt;
   slot_ = slot;
@@ -156,7 +156,7 @@ void ExtractJob::Start(Engine* eng, const ExtractOptions& opt, int slot, const f
     for (int p = 0; p < c.right_pad; ++p, ++r) memcpy(pack + r * D, src + (size_t)(c.len - 1) * D, (size_t)D * 4);
     offs.push_back((int32_t)r);
   }
-  eng->SubmitHost(slot, offs.data(), (int)chunks_.size());
+  eng->SubmitHost(slot, seq, offs.data(), (int)chunks_.size());
   async_ = true;
 }
 

@@ -58,7 +58,9 @@ void ExtractUtterances(Engine* eng, const ExtractOptions& opt, const float* feat
 // inside Finish().  feats / row_offsets must stay valid until Finish() returns.
 class ExtractJob {
  public:
-  void Start(Engine* eng, const ExtractOptions& opt, int slot, const float* feats, const int32_t* row_offsets, int n_utts);
+  // seq = running number of the batch (selects the engine lane)
+  void Start(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* feats, const int32_t* row_offsets,
+             int n_utts);
   void Finish(float* out, int32_t* ok, std::vector<std::string>* why);
   bool active() const { return eng_ != nullptr; }
 

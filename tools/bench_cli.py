@@ -22,7 +22,8 @@ from oracle import kaldi_io as kio  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-    extra = sys.argv[3:]
+    extra = [a for a in sys.argv[3:] if a.startswith("--")]
+    wspec = ([a for a in sys.argv[3:] if not a.startswith("--")] or [None])[0]
     d = tempfile.mkdtemp(prefix="xvcli", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     net, line = H.synth_model("v2_xvector")
     open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
@@ -33,7 +34,7 @@ def main():
             kio.write_matrix(f, pool[i % 64])
     binp = os.path.join(ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
     cmd = [binp, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine"] + extra + [
-        os.path.join(d, "final.raw"), "ark:%s/feats.ark" % d, "ark,scp:%s/x.ark,%s/x.scp" % (d, d)]
+        os.path.join(d, "final.raw"), "ark:%s/feats.ark" % d, wspec or "ark,scp:%s/x.ark,%s/x.scp" % (d, d)]
     t0 = time.perf_counter()
     r = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
     wall = time.perf_counter() - t0
@@ -42,7 +43,7 @@ def main():
     loop = float(m.group(1)) if m else None
     print(json.dumps({"utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
                       "loop_s": loop, "loop_utt_per_s": n / loop if loop else None,
-                      "feature_GB": n * T * 23 * 4 / 1e9, "tail": [l for l in err.strip().splitlines() if "stages" in l or "Done" in l]}))
+                      "feature_GB": n * T * 23 * 4 / 1e9, "tail": [l for l in err.strip().splitlines() if "stages" in l or "Done" in l or "WaitHost" in l]}))
     for fn in os.listdir(d):
         os.remove(os.path.join(d, fn))
     os.rmdir(d)
