@@ -320,6 +320,10 @@ Engine::~Engine() {
     fr(S.d_feats);
     fr(S.d_out);
     fr(S.d_tables);
+    fr(S.d_raw);
+    fr(S.d_prefix);
+    fr(S.d_fetab);
+    if (S.h_fetab) (void)hipHostFree(S.h_fetab);
     if (S.h_feats) (void)hipHostFree(S.h_feats);
     if (S.h_out) (void)hipHostFree(S.h_out);
     if (S.h_tables) (void)hipHostFree(S.h_tables);
@@ -761,7 +765,7 @@ float* Engine::HostFeats(int slot, size_t rows) {
   return (float*)S.h_feats;
 }
 
-void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B) {
+void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, const FrontEndJob* fe) {
   if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
   HostSlot& S = host_slots_[slot];
   if (S.pending) throw EngineError("host slot reused before WaitHost");
@@ -775,7 +779,9 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B) {
   FillPlan(row_offsets, B, S.plan.get(), &tables);
   const size_t fbytes = (size_t)row_offsets[B] * info_.input_dim * 4;
   const size_t obytes = (size_t)(frame_mode_ ? S.plan->n_out : B) * info_.output_dim * 4;
-  if (fbytes > S.h_feats_bytes) throw EngineError("SubmitHost: the batch is larger than the buffer HostFeats returned");
+  const size_t hbytes = fe ? (size_t)fe->raw_off[fe->n_utts] * info_.input_dim * 4 : fbytes;   // what the pinned buffer holds
+  if (hbytes > S.h_feats_bytes) throw EngineError("SubmitHost: the batch is larger than the buffer HostFeats returned");
+  if (fe && fe->n_out != row_offsets[B]) throw EngineError("SubmitHost: front-end output rows do not match row_offsets");
   // (re)allocation frees device memory, which waits for the device: buffers only grow
   auto grow = [&](Buf* b, size_t need) {
     if (b->bytes < need || !b->p) Ensure(b, need + need / 4 + 256, false);
@@ -790,7 +796,38 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B) {
   S.plan->borrowed_tables = true;
   BindPlan(S.plan.get(), S.d_tables.p);
   Check(hipMemcpyAsync(S.d_tables.p, S.h_tables, tables.size(), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plan tables)");
-  Check(hipMemcpyAsync(S.d_feats.p, S.h_feats, fbytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(feats)");
+  if (!fe) {
+    Check(hipMemcpyAsync(S.d_feats.p, S.h_feats, fbytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(feats)");
+  } else {
+    const int D = info_.input_dim;
+    const long raw_rows = fe->raw_off[fe->n_utts];
+    const size_t o_off = 0, o_row = Align256((size_t)(fe->n_utts + 1) * 4), o_utt = Align256(o_row + (size_t)fe->n_out * 4);
+    const size_t tab = Align256(o_utt + (size_t)fe->n_out * 4);
+    grow(&S.d_raw, hbytes);
+    grow(&S.d_prefix, (size_t)(raw_rows + fe->n_utts) * D * 8);
+    grow(&S.d_fetab, tab);
+    EnsurePinned(&S.h_fetab, &S.h_fetab_bytes, tab);
+    uint8_t* ht = (uint8_t*)S.h_fetab;
+    memcpy(ht + o_off, fe->raw_off, (size_t)(fe->n_utts + 1) * 4);
+    memcpy(ht + o_row, fe->sel_row, (size_t)fe->n_out * 4);
+    memcpy(ht + o_utt, fe->sel_utt, (size_t)fe->n_out * 4);
+    Check(hipMemcpyAsync(S.d_fetab.p, S.h_fetab, tab, hipMemcpyHostToDevice, s), "hipMemcpyAsync(front-end tables)");
+    Check(hipMemcpyAsync(S.d_raw.p, S.h_feats, hbytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(raw feats)");
+    FrontEndArgs fa;
+    fa.raw = (const float*)S.d_raw.p;
+    fa.raw_off = (const int32_t*)((const uint8_t*)S.d_fetab.p + o_off);
+    fa.prefix = (double*)S.d_prefix.p;
+    fa.n_utts = fe->n_utts;
+    fa.dim = D;
+    fa.sel_row = (const int32_t*)((const uint8_t*)S.d_fetab.p + o_row);
+    fa.sel_utt = (const int32_t*)((const uint8_t*)S.d_fetab.p + o_utt);
+    fa.n_out = fe->n_out;
+    fa.cmn_window = fe->cmn_window;
+    fa.center = fe->center ? 1 : 0;
+    fa.min_window = fe->min_window;
+    fa.out = (float*)S.d_feats.p;
+    Check(launch_frontend(fa, s), "front-end launch");
+  }
   ForwardOnLane(lane, *S.plan, (const float*)S.d_feats.p, (float*)S.d_out.p, info_.output_dim, s);
   Check(hipMemcpyAsync(S.h_out, S.d_out.p, obytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(out)");
   Check(hipEventRecord(S.done, s), "hipEventRecord(slot)");

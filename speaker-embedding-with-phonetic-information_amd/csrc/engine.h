@@ -71,7 +71,20 @@ class Engine {
   // A slot must be waited for before it is reused.  row_offsets[0] must be 0.
   static constexpr int kNumHostSlots = 3;
   float* HostFeats(int slot, size_t rows);
-  void SubmitHost(int slot, long seq, const int32_t* row_offsets, int B);
+  // With a FrontEndJob the pinned buffer holds RAW feature rows; sliding CMN + frame selection run on the device in
+  // front of the network (same stream) and their output never visits the host.  row_offsets then describe the
+  // selected rows (row_offsets[B] == fe->n_out).
+  struct FrontEndJob {
+    const int32_t* raw_off;   // [n_utts + 1] rows of every utterance inside the raw buffer
+    int n_utts;
+    const int32_t* sel_row;   // [n_out] absolute raw row of every kept frame, ascending
+    const int32_t* sel_utt;   // [n_out] its utterance
+    int n_out;
+    int cmn_window;
+    bool center;
+    int min_window;
+  };
+  void SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, const FrontEndJob* fe = nullptr);
   const float* WaitHost(int slot);
   bool frame_mode() const { return frame_mode_; }
   // Feature front-end on the device: sliding-window CMN (cmn_window <= 0: none) + selection of the rows listed in
@@ -122,6 +135,9 @@ class Engine {
     void* h_tables = nullptr;  // pinned copy of the plan tables
     size_t h_tables_bytes = 0;
     Buf d_feats, d_out, d_tables;
+    Buf d_raw, d_prefix, d_fetab;   // front-end: raw rows, per-utterance prefix sums (double), tables
+    void* h_fetab = nullptr;        // pinned
+    size_t h_fetab_bytes = 0;
     hipEvent_t done = nullptr;
     bool pending = false;
     std::unique_ptr<Plan> plan;   // its tables live in d_tables (not owned by the plan)

@@ -160,6 +160,75 @@ void ExtractJob::Start(Engine* eng, const ExtractOptions& opt, int slot, long se
   async_ = true;
 }
 
+bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot, long seq, int n_utts, const float* const* raw,
+                               const int32_t* raw_rows, const float* const* vad) {
+  const int D = eng->info().input_dim;
+  std::vector<Chunk> chunks;
+  std::vector<int32_t> ok(n_utts, 0), kept(n_utts, 0);
+  std::vector<std::string> why(n_utts);
+  long total_raw = 0, total_kept = 0;
+  for (int u = 0; u < n_utts; ++u) {
+    int k = raw_rows[u];
+    if (vad[u]) {
+      k = 0;
+      for (int t = 0; t < raw_rows[u]; ++t) k += vad[u][t] != 0.f;
+    }
+    kept[u] = k;
+    const size_t before = chunks.size();
+    std::string reason;
+    ok[u] = PlanChunks(u, k, opt.chunk_size, opt.min_chunk_size, opt.pad_input, eng->info().min_frames, &chunks, &reason) ? 1 : 0;
+    if (!ok[u]) {
+      why[u] = reason;
+      continue;
+    }
+    if (chunks.size() != before + 1) return false;   // cut into several chunks: host path
+    const Chunk& c = chunks.back();
+    if (c.start != 0 || c.len != k || c.left_pad != 0 || c.right_pad != 0) return false;
+    total_raw += raw_rows[u];
+    total_kept += k;
+  }
+  if (chunks.empty() || total_kept > opt.max_batch_rows || (int)chunks.size() > opt.max_batch_chunks) return false;
+  eng_ = eng;
+  opt_ = opt;
+  slot_ = slot;
+  n_utts_ = n_utts;
+  feats_ = nullptr;
+  row_offsets_ = nullptr;
+  chunks_ = chunks;
+  ok_ = ok;
+  why_ = why;
+  float* buf = eng->HostFeats(slot, (size_t)total_raw);
+  std::vector<int32_t> raw_off(1, 0), sel_row, sel_utt, offs(1, 0);
+  sel_row.reserve(total_kept);
+  sel_utt.reserve(total_kept);
+  int j = 0;   // index among the utterances that enter the device batch
+  for (int u = 0; u < n_utts; ++u) {
+    if (!ok[u]) continue;
+    const int base = raw_off.back();
+    memcpy(buf + (size_t)base * D, raw[u], (size_t)raw_rows[u] * D * 4);
+    for (int t = 0; t < raw_rows[u]; ++t)
+      if (!vad[u] || vad[u][t] != 0.f) {
+        sel_row.push_back(base + t);
+        sel_utt.push_back(j);
+      }
+    raw_off.push_back(base + raw_rows[u]);
+    offs.push_back((int32_t)sel_row.size());
+    ++j;
+  }
+  Engine::FrontEndJob fe;
+  fe.raw_off = raw_off.data();
+  fe.n_utts = j;
+  fe.sel_row = sel_row.data();
+  fe.sel_utt = sel_utt.data();
+  fe.n_out = (int)sel_row.size();
+  fe.cmn_window = opt.cmn_window;
+  fe.center = opt.cmn_center;
+  fe.min_window = opt.cmn_min_window;
+  eng->SubmitHost(slot, seq, offs.data(), j, &fe);
+  async_ = true;
+  return true;
+}
+
 void ExtractJob::Finish(float* out, int32_t* ok, std::vector<std::string>* why) {
   Engine* eng = eng_;
   eng_ = nullptr;

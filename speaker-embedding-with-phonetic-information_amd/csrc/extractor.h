@@ -61,6 +61,12 @@ class ExtractJob {
   // seq = running number of the batch (selects the engine lane)
   void Start(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* feats, const int32_t* row_offsets,
              int n_utts);
+  // Table jobs with the device front-end: raw[u] = the utterance's raw rows (raw_rows[u] of them), vad[u] = its VAD
+  // decisions (or null: keep every row; every utterance keeps at least one).  When every utterance maps to exactly one
+  // unpadded chunk (the normal case) the raw rows are staged, CMN + selection + network run on the device without a
+  // host round trip, and true is returned; otherwise nothing is submitted and the caller uses FrontEndHost + Start.
+  bool StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot, long seq, int n_utts, const float* const* raw,
+                     const int32_t* raw_rows, const float* const* vad);
   void Finish(float* out, int32_t* ok, std::vector<std::string>* why);
   bool active() const { return eng_ != nullptr; }
 

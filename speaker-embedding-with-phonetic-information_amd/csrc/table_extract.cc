@@ -202,14 +202,12 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
           idx.push_back((int)i);
         }
         int n = (int)idx.size();
+        bool submitted = false;
         if (use_frontend && n) {
           // sliding CMN over the WHOLE utterance first, then keep the voiced frames (order of the two pipe stages)
-          sel_row.clear();
-          sel_utt.clear();
-          poffs.assign(1, 0);
           std::vector<int> keep_idx;
-          std::vector<int32_t> raw_off2(1, 0);
-          std::vector<float> raw2;
+          std::vector<const float*> rawp, vadp;
+          std::vector<int32_t> rrows;
           for (int k = 0; k < n; ++k) {
             const Utt& u = w.b.utts[idx[k]];
             const int T = u.feats.rows;
@@ -228,37 +226,54 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
                 ++res.num_fail;
                 continue;
               }
-            }
-            const int32_t base = raw_off2.back();
-            const size_t before = sel_row.size();
-            for (int t = 0; t < T; ++t)
-              if (!v || (*v)[t] != 0.f) {
-                sel_row.push_back(base + t);
-                sel_utt.push_back((int32_t)keep_idx.size());
+              bool any = false;
+              for (int t = 0; t < T && !any; ++t) any = (*v)[t] != 0.f;
+              if (T > 0 && !any) {
+                warn("No features were judged as voiced for utterance " + u.key);
+                ++res.num_fail;
+                continue;
               }
-            if (T > 0 && sel_row.size() == before) {
-              warn("No features were judged as voiced for utterance " + u.key);
-              ++res.num_fail;
-              continue;
             }
-            raw2.insert(raw2.end(), u.feats.data.begin(), u.feats.data.end());
-            raw_off2.push_back(base + T);
             keep_idx.push_back(idx[k]);
-            poffs.push_back((int32_t)sel_row.size());
+            rawp.push_back(u.feats.data.data());
+            vadp.push_back(v ? v->data() : nullptr);
+            rrows.push_back(T);
           }
           idx.swap(keep_idx);
           n = (int)idx.size();
-          processed.resize(sel_row.size() * (size_t)D);
-          if (n)
+          // device path: raw rows in, CMN + selection + network on the lane's stream, nothing comes back but embeddings
+          if (n) submitted = w.job.StartFrontEnd(engine, opt, cur, seq, n, rawp.data(), rrows.data(), vadp.data());
+          if (submitted) ++seq;
+          if (n && !submitted) {
+            // utterances that are cut into several chunks or padded: front-end result back to the host, then Start()
+            sel_row.clear();
+            sel_utt.clear();
+            poffs.assign(1, 0);
+            std::vector<int32_t> raw_off2(1, 0);
+            std::vector<float> raw2;
+            for (int k = 0; k < n; ++k) {
+              const int T = rrows[k];
+              const int32_t base = raw_off2.back();
+              for (int t = 0; t < T; ++t)
+                if (!vadp[k] || vadp[k][t] != 0.f) {
+                  sel_row.push_back(base + t);
+                  sel_utt.push_back(k);
+                }
+              raw2.insert(raw2.end(), rawp[k], rawp[k] + (size_t)T * D);
+              raw_off2.push_back(base + T);
+              poffs.push_back((int32_t)sel_row.size());
+            }
+            processed.resize(sel_row.size() * (size_t)D);
             engine->FrontEndHost(raw2.data(), raw_off2.data(), n, sel_row.data(), sel_utt.data(), (int)sel_row.size(),
                                  opt.cmn_window, opt.cmn_center, opt.cmn_min_window, processed.data());
-          packed.swap(processed);
-          offs = poffs;
+            packed.swap(processed);
+            offs = poffs;
+          }
         }
         const auto tp1 = now();
         t_pack += secs(tp0, tp1);
         if (n) {
-          w.job.Start(engine, opt, cur, seq++, packed.data(), offs.data(), n);
+          if (!submitted) w.job.Start(engine, opt, cur, seq++, packed.data(), offs.data(), n);
           const auto tp2 = now();
           t_start += secs(tp1, tp2);
           cur = (cur + 1) % NS;

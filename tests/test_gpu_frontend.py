@@ -43,7 +43,8 @@ def test_sliding_cmn_and_vad_selection(ctx, center):
     assert np.array_equal(out2, raw) and np.array_equal(off2, offs)
 
 
-def test_cli_with_fused_front_end(tmp_path):
+@pytest.mark.parametrize("chunk", [10000, 150])   # 150: utterances are cut into chunks -> the host round-trip path
+def test_cli_with_fused_front_end(tmp_path, chunk):
     net, line = H.synth_model("v2_xvector")
     (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
     lens = [500, 120, 64, 900]
@@ -52,7 +53,7 @@ def test_cli_with_fused_front_end(tmp_path):
     vads[2] = ("utt2", np.zeros(64, np.float32))                          # nothing voiced -> skipped with a warning
     kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"))
     kio.write_ark_vectors(str(tmp_path / "vad.ark"), vads, scp_path=str(tmp_path / "vad.scp"))
-    r = subprocess.run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000",
+    r = subprocess.run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=%d" % chunk,
                         "--output-node=tdnn6.affine", "--cmn-window=300", "--cmn-center=true",
                         "--vad-rspecifier=scp,s,cs:%s/vad.scp" % tmp_path, str(tmp_path / "final.raw"),
                         "scp:%s/feats.scp" % tmp_path, "ark,scp:%s/x.ark,%s/x.scp" % (tmp_path, tmp_path)],
@@ -68,7 +69,7 @@ def test_cli_with_fused_front_end(tmp_path):
         if f is None:
             assert k not in got
             continue
-        ref = H.xo.extract_xvector(ev, f, 10000, 25, True)
+        ref = H.xo.extract_xvector(ev, f, chunk, 25, True)
         assert H.rel_err(got[k][None], ref[None]) < 1e-4, k
     assert "No features were judged as voiced for utterance utt2" in err
     assert "Done 3 utterances, failed for 1" in err
