@@ -88,8 +88,8 @@ __device__ __forceinline__ int swap_fields(int rho) {
 
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
 
-// Per-lane epilogue parameters.  Variant 2 loads them BEFORE the K loop: read inside the epilogue, the dependent global
-// loads (bias / scale / offset, and for the statistics epilogue the valid-row table) sat on every tile's critical path.
+// Per-lane epilogue parameters (bias / scale / offset, and for the statistics epilogue the valid-row table), fetched
+// by epilogue_prefetch: before the K loop where the registers are affordable (see variant 2), else right before use.
 struct EpiRegs {
   float bs[16], sc[16], of[16];   // act / f32: index p*4 + r;  stats: index q (one column per 16-column fragment)
   int first[4], last[4];          // stats: valid rows [first, last) of the four 16-row fragments p
@@ -476,8 +476,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);   // 2048 cycles each
   }
 
-  EpiRegs er;   // epilogue parameters, in flight during the K loop
-  epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
+  // epilogue parameters: the statistics epilogue's few registers are fetched now and are in flight during the K
+  // loop; the 48 of the activation epilogue are fetched after it (held across the loop they push the single-pass
+  // kernels from 120 to 162 VGPRs, i.e. from two co-resident workgroups per CU to one: -20 % measured)
+  EpiRegs er;
+  if constexpr (EPI == kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
 
   const int ld_row = lane >> 2;
   const int ld_chunk = (lane & 3) ^ ((lane >> 3) & 3);
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     plain_barrier();
   }
   if (group == 0) plain_barrier();
+  if constexpr (EPI != kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
   gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
 }
 
@@ -721,7 +725,8 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   GemmArgs b = a;
   build_groups(&b);
   {
-    // stagger window = XVEC_GEMM_STAGGER percent of the modelled tile time (K steps x ~2200 cycles + ~14000 fixed)
+    // stagger window = XVEC_GEMM_STAGGER percent of the modelled tile time (K steps x ~2200 cycles in split mode,
+    // ~1000 single pass, + ~14000 fixed)
     static int pct = -1;
     if (pct < 0) {
       const char* e = getenv("XVEC_GEMM_STAGGER");
@@ -729,7 +734,7 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
     }
     const int cus = device_cu_count();
     b.stagger_wgs = cus;
-    b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * 2200 + 14000) * pct / 100 / 2048) : 0;
+    b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * (PREC == kPrecBf16x3 ? 2200 : 1000) + 14000) * pct / 100 / 2048) : 0;
   }
   hipLaunchKernelGGL((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
   return hipGetLastError();
