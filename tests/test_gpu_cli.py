@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+from oracle import frontend as fe
 from oracle import kaldi_io as kio
 
 pytestmark = pytest.mark.gpu
@@ -121,3 +122,40 @@ def test_nnet3_compute_cli_frame_level(tmp_path):
     r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--output-node=tdnn5.batchnorm", str(tmp_path / "am.raw"),
               "ark:%s/f.ark" % tmp_path, "ark:/dev/null"])
     assert r.returncode == 255 and b"frame-level" in r.stderr
+
+
+@pytest.mark.parametrize("frontend", [False, True])
+def test_cli_many_small_batches_keep_order_and_values(tmp_path, frontend):
+    """The table loop keeps three batches queued on the device (Engine::SubmitHost / WaitHost); with --batch-frames=1500
+    a 48-utterance ragged job is 15-20 batches, so every slot is reused several times.  Order and values must not depend
+    on the batching: compared with the oracle and with a single-batch run, bit for bit."""
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    rng = np.random.default_rng(77)
+    lens = [int(t) for t in rng.integers(26, 420, 48)]
+    lens[5], lens[17] = 9, 0                                       # a too-short and an empty utterance in the middle
+    utts = [("k%02d" % i, (H.features(1500 + i, T) + 0.7) if T else np.zeros((0, 23), np.float32)) for i, T in enumerate(lens)]
+    kio.write_ark_matrices(str(tmp_path / "f.ark"), utts)
+    extra = ["--cmn-window=300"] if frontend else []
+    outs = []
+    for bf in (1500, 1 << 17):
+        out = tmp_path / ("x%d.ark" % bf)
+        r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--pad-input=false", "--output-node=tdnn6.affine",
+                  "--batch-frames=%d" % bf] + extra + [str(tmp_path / "final.raw"), "ark:%s/f.ark" % tmp_path, "ark:%s" % out])
+        assert r.returncode == 0, r.stderr.decode()
+        assert b"Done 46 utterances, failed for 2" in r.stderr
+        outs.append(list(kio.read_ark(str(out), "vector")))
+    small, big = outs
+    assert [k for k, _ in small] == [k for k, _ in big] == [k for (k, _), T in zip(utts, lens) if T >= 25]
+    for (k, a), (_, b) in zip(small, big):
+        np.testing.assert_array_equal(a, b, err_msg=k)             # batch composition never changes a result
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    ev = H.xo.GraphEvaluator(n2, np.float32)
+    got = dict(small)
+    for k, x in utts[:12]:
+        if x.shape[0] < 25:
+            continue
+        f = fe.sliding_cmn(x, 300, True).astype(np.float32) if frontend else x
+        ref = H.xo.extract_xvector(ev, f, -1, 25, False)
+        assert H.rel_err(got[k][None], ref[None]) < TOL, k

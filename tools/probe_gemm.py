@@ -15,10 +15,11 @@ import helpers as H  # noqa: E402
 HALO = 32
 
 
-def run(P, rows, n_pad, segs, epi, reps=20):
+def run(P, rows, n_pad, segs, epi, reps=20, separate_sources=False):
     dev = torch.device("cuda:0")
     ld = max(s[1] for s in segs)
-    X = torch.randn(rows + 2 * HALO, ld, device=dev)
+    nsrc = len(segs) if separate_sources else 1
+    X = torch.randn(nsrc, rows + 2 * HALO, ld, device=dev)
     xh = X.to(torch.bfloat16); xl = (X - xh.float()).to(torch.bfloat16)
     K = sum(s[3] for s in segs)
     W = torch.randn(n_pad, K, device=dev) / np.sqrt(K)
@@ -30,8 +31,9 @@ def run(P, rows, n_pad, segs, epi, reps=20):
     d = P.GemmDesc()
     d.precision, d.epilogue, d.nseg = 0, epi, len(segs)
     for j, (si, l, shift, klen) in enumerate(segs):
-        d.seg[j].hi = xh.data_ptr() + HALO * ld * 2
-        d.seg[j].lo = xl.data_ptr() + HALO * ld * 2
+        src = j if separate_sources else 0
+        d.seg[j].hi = xh[src].data_ptr() + HALO * ld * 2
+        d.seg[j].lo = xl[src].data_ptr() + HALO * ld * 2
         d.seg[j].ld, d.seg[j].row_shift, d.seg[j].k_len = ld, shift, klen
     d.w_hi, d.w_lo, d.ldw = wh.data_ptr(), wl.data_ptr(), K
     d.rows, d.n_pad = rows, n_pad
@@ -64,6 +66,10 @@ def main():
         for K in (32, 64, 128, 256, 512, 1024):
             t = run(P, rows, n_pad, [(0, max(K, 32), 0, K)], epi)
             print("  %-5s nshift=1 K=%4d steps=%2d : %.4f ms" % (name, K, K // 32, t))
+        t = run(P, rows, n_pad, [(0, 256, 0, 256)], epi)
+        print("  %-5s K=256 one strided source (64-B row segments)       : %.4f ms" % (name, t))
+        t = run(P, rows, n_pad, [(j, 32, 0, 32) for j in range(8)], epi, separate_sources=True)
+        print("  %-5s K=256 as 8 planes of 32 columns (contiguous 1 KiB)  : %.4f ms" % (name, t))
         for kseg in (32, 128, 512):
             t = run(P, rows, n_pad, [(0, kseg, -2, kseg), (0, kseg, 0, kseg), (0, kseg, 2, kseg)], epi)
             print("  %-5s nshift=3 K=%4d steps=%2d : %.4f ms" % (name, 3 * kseg, 3 * kseg // 32, t))
