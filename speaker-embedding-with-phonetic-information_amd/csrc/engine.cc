@@ -532,13 +532,28 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
   pa.out_lo = ActBase(L.in_lo, in_ld_);
   pa.pad_left = pad_left_;
   pa.pad_right = pad_right_;
+  // profiling: every launch_* call below is bracketed by its own (start, stop) event pair, stamped by the dispatch
+  // itself (kernels.hip: set_launch_events) - no extra packets between the kernels of the timed region
   std::vector<hipEvent_t> prof_run;
   const bool first_prof = prof_on_ && prof_labels_.empty();
-  if (prof_on_) ProfMark(s, &prof_run);
+  auto arm = [&](const std::string& label) {
+    if (!prof_on_) return;
+    hipEvent_t e0, e1;
+    Check(hipEventCreate(&e0), "hipEventCreate");
+    Check(hipEventCreate(&e1), "hipEventCreate");
+    prof_run.push_back(e0);
+    prof_run.push_back(e1);
+    if (first_prof) prof_labels_.push_back(label);
+    set_launch_events(e0, e1);
+  };
+  auto disarm = [&]() {
+    if (prof_on_) set_launch_events(nullptr, nullptr);
+  };
+  arm("prep_input");
   Check(launch_prep_input(pa, prec, s), "prep_input launch");
-  if (prof_on_) ProfMark(s, &prof_run);
-  if (first_prof) prof_labels_.push_back("prep_input");
+  disarm();
 
+  bool direct_out = false;   // the output layer wrote into out_dev itself
   for (size_t i = 0; i < layers_.size(); ++i) {
     const BlobLayerInfo& li = info_.layers[i];
     DevLayer& dl = layers_[i];
@@ -613,8 +628,12 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       }
       if ((int)i == info_.output_layer) {
         epi = kEpiF32;
-        ga.out_f32 = (float*)L.out_f32.p;
-        ga.ldf = li.n_pad;
+        // the embedding goes straight into the caller's buffer when its rows can take the 16-byte stores of all n_pad
+        // columns (no padding columns, aligned); otherwise through out_f32 and a strided copy
+        direct_out = !li.log_softmax && li.n_pad == info_.output_dim && (out_ld & 3) == 0 && out_ld >= li.n_pad &&
+                     ((uintptr_t)out_dev & 15) == 0;
+        ga.out_f32 = direct_out ? out_dev : (float*)L.out_f32.p;
+        ga.ldf = direct_out ? out_ld : li.n_pad;
         ga.m_valid = plan.B;
       } else {
         epi = kEpiAct;
@@ -623,10 +642,9 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         ga.ldo = li.n_pad;
       }
     }
+    arm(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
     Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
-    if (prof_on_) ProfMark(s, &prof_run);
-    if (first_prof)
-      prof_labels_.push_back(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
+    disarm();
 
     if ((int)i == info_.pooled_layer) {
       PoolArgs po;
@@ -641,9 +659,9 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       po.out_hi = (uint16_t*)L.stats_hi.p;
       po.out_lo = (uint16_t*)L.stats_lo.p;
       po.ld = stats_ld_;
+      arm("pool_finalise");
       Check(launch_pool_finalise(po, prec, s), "pool_finalise launch");
-      if (prof_on_) ProfMark(s, &prof_run);
-      if (first_prof) prof_labels_.push_back("pool_finalise");
+      disarm();
     }
   }
   const BlobLayerInfo& ol = info_.layers[info_.output_layer];
@@ -657,7 +675,9 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     fo.log_softmax = ol.log_softmax;
     fo.out = out_dev;
     fo.out_ld = out_ld;
+    arm("frame_output");
     Check(launch_frame_output(fo, s), "frame_output launch");
+    disarm();
   } else if (ol.log_softmax) {
     // pooled output taken after a LogSoftmaxComponent (e.g. the speaker posteriors of the unedited x-vector net)
     FrameOutArgs fo;
@@ -669,25 +689,17 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     fo.log_softmax = 1;
     fo.out = out_dev;
     fo.out_ld = out_ld;
+    arm("frame_output");
     Check(launch_frame_output(fo, s), "frame_output launch");
-  } else
-  Check(hipMemcpy2DAsync(out_dev, (size_t)out_ld * 4, L.out_f32.p, (size_t)ol.n_pad * 4, (size_t)info_.output_dim * 4,
-                         (size_t)plan.B, hipMemcpyDeviceToDevice, s),
-        "hipMemcpy2DAsync(out)");
+    disarm();
+  } else if (!direct_out) {
+    Check(hipMemcpy2DAsync(out_dev, (size_t)out_ld * 4, L.out_f32.p, (size_t)ol.n_pad * 4, (size_t)info_.output_dim * 4,
+                           (size_t)plan.B, hipMemcpyDeviceToDevice, s),
+          "hipMemcpy2DAsync(out)");
+  }
   Check(hipEventRecord(L.done, s), "hipEventRecord(lane)");
   L.busy = true;
-  if (prof_on_) {
-    ProfMark(s, &prof_run);
-    if (first_prof) prof_labels_.push_back("copy_out");
-    prof_runs_.push_back(std::move(prof_run));
-  }
-}
-
-void Engine::ProfMark(hipStream_t s, std::vector<hipEvent_t>* run) {
-  hipEvent_t e;
-  Check(hipEventCreate(&e), "hipEventCreate");
-  Check(hipEventRecord(e, s), "hipEventRecord");
-  run->push_back(e);
+  if (prof_on_) prof_runs_.push_back(std::move(prof_run));
 }
 
 std::string Engine::ProfileReport() {
@@ -695,9 +707,9 @@ std::string Engine::ProfileReport() {
   Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
   std::vector<double> tot(prof_labels_.size(), 0.0);
   for (auto& run : prof_runs_) {
-    for (size_t i = 0; i + 1 < run.size() && i < tot.size(); ++i) {
+    for (size_t i = 0; 2 * i + 1 < run.size() && i < tot.size(); ++i) {   // (start, stop) pair of launch i
       float ms = 0.f;
-      Check(hipEventElapsedTime(&ms, run[i], run[i + 1]), "hipEventElapsedTime");
+      Check(hipEventElapsedTime(&ms, run[2 * i], run[2 * i + 1]), "hipEventElapsedTime");
       tot[i] += ms;
     }
     for (hipEvent_t e : run) (void)hipEventDestroy(e);

@@ -96,7 +96,8 @@ class Engine {
   int num_lanes() const { return (int)lanes_.size(); }
   // last forward's per-kernel launch list (name, m_tiles*n_tiles) for logging / tests
   size_t weight_bytes() const { return blob_data_bytes_; }
-  // Per-launch timing with HIP events recorded on the stream the kernels are launched on.
+  // Per-launch timing with HIP events stamped by the kernel dispatches themselves (hipExtLaunchKernelGGL), on the
+  // stream the kernels are launched on.
   void SetProfiling(bool on) { prof_on_ = on; }
   // "label<TAB>launches<TAB>total_ms" lines for everything recorded since the last report; resets.
   std::string ProfileReport();
@@ -172,7 +173,6 @@ class Engine {
   bool prof_on_ = false;
   std::vector<std::string> prof_labels_;
   std::vector<std::vector<hipEvent_t>> prof_runs_;
-  void ProfMark(hipStream_t s, std::vector<hipEvent_t>* run);
 };
 
 struct Engine::Plan {

@@ -98,6 +98,10 @@ struct GemmArgs {
   int stagger_wgs, stagger_units;
 };
 
+// Arms a (start, stop) event pair for the kernels of the NEXT launch_* call of this thread (profiling; see kernels.hip).
+// Pass (nullptr, nullptr) to disarm.
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+
 // Launches the spliced-affine GEMM. Returns hipSuccess or the launch error.
 hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipStream_t s);
 

@@ -26,6 +26,8 @@
 //     reduction is 3 in-register adds + 2 cross-lane adds.
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -39,6 +41,23 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define XV_AS1 __attribute__((address_space(1)))
 #define XV_AS3 __attribute__((address_space(3)))
+
+// Per-launch timing without extra packets on the stream: when the engine has armed a (start, stop) event pair
+// (set_launch_events), the kernels of the next launch_* call are dispatched with hipExtLaunchKernelGGL, which stamps
+// the events from the dispatch itself - the first kernel takes the start event, every kernel re-records the stop
+// event (the last one wins, so a GEMM + split-K reduction pair is timed as one).
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) {
+  g_ev_start = start;
+  g_ev_stop = stop;
+}
+#define XV_LAUNCH(kern, grid, block, lds, stream, ...)                                           \
+  do {                                                                                           \
+    hipEvent_t _st = g_ev_start, _sp = g_ev_stop;                                                \
+    g_ev_start = nullptr;                                                                        \
+    if (_st || _sp) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, _st, _sp, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                        \
+  } while (0)
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   // 16 bytes per lane, LDS destination = wave-uniform base + lane*16
@@ -736,7 +755,7 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
     b.stagger_wgs = cus;
     b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * (PREC == kPrecBf16x3 ? 2200 : 1000) + 14000) * pct / 100 / 2048) : 0;
   }
-  hipLaunchKernelGGL((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
+  XV_LAUNCH((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
   return hipGetLastError();
 }
 
@@ -754,7 +773,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   const int mt8 = (a.m_tiles + 7) / 8 * 8;
   dim3 grid(mt8 * a.n_tiles), block(256);
-  hipLaunchKernelGGL((tdnn_gemm_kernel<PREC, EPI>), grid, block, lds, s, a);
+  XV_LAUNCH((tdnn_gemm_kernel<PREC, EPI>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 
@@ -813,11 +832,11 @@ static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
   }
   const int mt8 = (a.m_tiles + 7) / 8 * 8;
   dim3 grid(mt8 * a.n_tiles, a.ksplit), block(256);
-  hipLaunchKernelGGL((tdnn_gemm_kernel<PREC, kEpiSplitK>), grid, block, lds, s, a);
+  XV_LAUNCH((tdnn_gemm_kernel<PREC, kEpiSplitK>), grid, block, lds, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const long total = (long)a.m_tiles * kBM * (a.n_tiles * kBN / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<PREC, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  XV_LAUNCH((splitk_reduce_kernel<PREC, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -894,9 +913,9 @@ hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s) {
   const long total = (long)a.rows * (a.ld >> 3);
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   switch (precision) {
-    case kPrecBf16x3: hipLaunchKernelGGL(prep_input_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
-    case kPrecBf16: hipLaunchKernelGGL(prep_input_kernel<kPrecBf16>, grid, block, 0, s, a); break;
-    case kPrecFp16: hipLaunchKernelGGL(prep_input_kernel<kPrecFp16>, grid, block, 0, s, a); break;
+    case kPrecBf16x3: XV_LAUNCH(prep_input_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
+    case kPrecBf16: XV_LAUNCH(prep_input_kernel<kPrecBf16>, grid, block, 0, s, a); break;
+    case kPrecFp16: XV_LAUNCH(prep_input_kernel<kPrecFp16>, grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -957,10 +976,10 @@ __global__ __launch_bounds__(256) void cmn_select_kernel(const FrontEndArgs a) {
 
 hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s) {
   if (a.dim > 64) return hipErrorInvalidValue;
-  if (a.cmn_window > 0 && a.n_utts > 0) hipLaunchKernelGGL(cmn_prefix_kernel, dim3(a.n_utts), dim3(64), 0, s, a);
+  if (a.cmn_window > 0 && a.n_utts > 0) XV_LAUNCH(cmn_prefix_kernel, dim3(a.n_utts), dim3(64), 0, s, a);
   if (a.n_out > 0) {
     const long total = (long)a.n_out * a.dim;
-    hipLaunchKernelGGL(cmn_select_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    XV_LAUNCH(cmn_select_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }
@@ -997,7 +1016,7 @@ __global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a)
 
 hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
-  hipLaunchKernelGGL(frame_output_kernel, dim3(a.n_out), dim3(256), 0, s, a);
+  XV_LAUNCH(frame_output_kernel, dim3(a.n_out), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -1043,9 +1062,9 @@ __global__ __launch_bounds__(256) void pool_finalise_kernel(const PoolArgs a) {
 hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s) {
   dim3 grid((a.dim + 255) / 256, a.B), block(256);
   switch (precision) {
-    case kPrecBf16x3: hipLaunchKernelGGL(pool_finalise_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
-    case kPrecBf16: hipLaunchKernelGGL(pool_finalise_kernel<kPrecBf16>, grid, block, 0, s, a); break;
-    case kPrecFp16: hipLaunchKernelGGL(pool_finalise_kernel<kPrecFp16>, grid, block, 0, s, a); break;
+    case kPrecBf16x3: XV_LAUNCH(pool_finalise_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
+    case kPrecBf16: XV_LAUNCH(pool_finalise_kernel<kPrecBf16>, grid, block, 0, s, a); break;
+    case kPrecFp16: XV_LAUNCH(pool_finalise_kernel<kPrecFp16>, grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1192,12 +1211,12 @@ __global__ __launch_bounds__(256) void backend_rowwise_kernel(const BackendArgs 
 static hipError_t launch_backend_gemm(const BackendArgs& a, hipStream_t s) {
   const dim3 grid((a.n + kBkVB - 1) / kBkVB), block(256);
   const int rf = (a.t_rows + 15) / 16;
-  if (rf <= 2) hipLaunchKernelGGL(backend_gemm_kernel<2>, grid, block, 0, s, a);
-  else if (rf <= 4) hipLaunchKernelGGL(backend_gemm_kernel<4>, grid, block, 0, s, a);
-  else if (rf <= 7) hipLaunchKernelGGL(backend_gemm_kernel<7>, grid, block, 0, s, a);
-  else if (rf <= 10) hipLaunchKernelGGL(backend_gemm_kernel<10>, grid, block, 0, s, a);
-  else if (rf <= 13) hipLaunchKernelGGL(backend_gemm_kernel<13>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(backend_gemm_kernel<16>, grid, block, 0, s, a);
+  if (rf <= 2) XV_LAUNCH(backend_gemm_kernel<2>, grid, block, 0, s, a);
+  else if (rf <= 4) XV_LAUNCH(backend_gemm_kernel<4>, grid, block, 0, s, a);
+  else if (rf <= 7) XV_LAUNCH(backend_gemm_kernel<7>, grid, block, 0, s, a);
+  else if (rf <= 10) XV_LAUNCH(backend_gemm_kernel<10>, grid, block, 0, s, a);
+  else if (rf <= 13) XV_LAUNCH(backend_gemm_kernel<13>, grid, block, 0, s, a);
+  else XV_LAUNCH(backend_gemm_kernel<16>, grid, block, 0, s, a);
   return hipGetLastError();
 }
 
@@ -1205,7 +1224,7 @@ hipError_t launch_backend(const BackendArgs& a, hipStream_t s) {
   if (a.n <= 0) return hipSuccess;
   if (a.dim < 1 || (a.t && a.t_cols != a.dim && a.t_cols != a.dim + 1)) return hipErrorInvalidValue;
   if (!a.t) {
-    hipLaunchKernelGGL(backend_rowwise_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, a);
+    XV_LAUNCH(backend_rowwise_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
   }
   if (a.t_rows <= kBkMaxRF * 16) return launch_backend_gemm(a, s);
@@ -1227,7 +1246,7 @@ hipError_t launch_backend(const BackendArgs& a, hipStream_t s) {
     c.dim = a.t_rows;
     c.mean = nullptr;
     c.t = nullptr;
-    hipLaunchKernelGGL(backend_rowwise_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, c);
+    XV_LAUNCH(backend_rowwise_kernel, dim3((a.n + 3) / 4), dim3(256), 0, s, c);
     return hipGetLastError();
   }
   return hipSuccess;
@@ -1251,8 +1270,8 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const SegMeanArgs a) 
 
 hipError_t launch_segment_mean(const SegMeanArgs& a, hipStream_t s) {
   if (a.n_seg <= 0) return hipSuccess;
-  if (a.acc64) hipLaunchKernelGGL(segment_mean_kernel<double>, dim3(a.n_seg), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(segment_mean_kernel<float>, dim3(a.n_seg), dim3(256), 0, s, a);
+  if (a.acc64) XV_LAUNCH(segment_mean_kernel<double>, dim3(a.n_seg), dim3(256), 0, s, a);
+  else XV_LAUNCH(segment_mean_kernel<float>, dim3(a.n_seg), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
