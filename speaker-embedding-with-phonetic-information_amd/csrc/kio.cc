@@ -307,6 +307,21 @@ static void ReadTextNumbers(Input& in, std::vector<float>* vals, std::vector<int
   if (in.Peek() == '\n') in.Get();
 }
 
+// Reads n elements growing the vector block by block: a corrupted dimension in a header then fails at the end of the
+// input after at most one block of extra allocation, instead of zero-filling gigabytes first.
+template <typename T>
+static void ReadGrow(Input& in, std::vector<T>* v, size_t n) {
+  constexpr size_t kBlock = (size_t)1 << 22;   // elements
+  v->clear();
+  size_t done = 0;
+  while (done < n) {
+    const size_t take = n - done < kBlock ? n - done : kBlock;
+    v->resize(done + take);
+    in.Read(v->data() + done, take * sizeof(T));
+    done += take;
+  }
+}
+
 void ReadVector(Input& in, bool binary, std::vector<float>* v) {
   v->clear();
   if (binary) {
@@ -314,12 +329,12 @@ void ReadVector(Input& in, bool binary, std::vector<float>* v) {
     ReadToken(in, true, &tok);
     int32_t n = ReadInt32(in, true);
     if (n < 0) throw KioError("negative vector dimension");
-    v->resize((size_t)n);
     if (tok == "FV") {
-      in.Read(v->data(), (size_t)n * 4);
+      ReadGrow(in, v, (size_t)n);
     } else if (tok == "DV") {
-      std::vector<double> d((size_t)n);
-      in.Read(d.data(), (size_t)n * 8);
+      std::vector<double> d;
+      ReadGrow(in, &d, (size_t)n);
+      v->resize((size_t)n);
       for (int i = 0; i < n; ++i) (*v)[i] = (float)d[i];
     } else {
       throw KioError("expected FV or DV, got " + tok);
@@ -341,12 +356,13 @@ static void ReadCompressed(Input& in, const std::string& tok, Matrix* m) {
   if (h.rows < 0 || h.cols < 0) throw KioError("bad compressed-matrix header");
   m->rows = h.rows;
   m->cols = h.cols;
-  m->data.assign((size_t)h.rows * h.cols, 0.f);
+  const size_t total = (size_t)h.rows * h.cols;
   if (tok == "CM") {
-    std::vector<uint16_t> hdr((size_t)h.cols * 4);
-    in.Read(hdr.data(), hdr.size() * 2);
-    std::vector<uint8_t> bytes((size_t)h.rows * h.cols);
-    in.Read(bytes.data(), bytes.size());
+    std::vector<uint16_t> hdr;
+    ReadGrow(in, &hdr, (size_t)h.cols * 4);
+    std::vector<uint8_t> bytes;
+    ReadGrow(in, &bytes, total);
+    m->data.assign(total, 0.f);
     for (int c = 0; c < h.cols; ++c) {
       const float p0 = U16ToFloat(h.min_value, h.range, hdr[4 * c]);
       const float p25 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 1]);
@@ -363,13 +379,15 @@ static void ReadCompressed(Input& in, const std::string& tok, Matrix* m) {
       }
     }
   } else if (tok == "CM2") {
-    std::vector<uint16_t> d((size_t)h.rows * h.cols);
-    in.Read(d.data(), d.size() * 2);
+    std::vector<uint16_t> d;
+    ReadGrow(in, &d, total);
+    m->data.assign(total, 0.f);
     const float inc = h.range * (1.0f / 65535.0f);
     for (size_t i = 0; i < d.size(); ++i) m->data[i] = d[i] * inc + h.min_value;
   } else {  // CM3
-    std::vector<uint8_t> d((size_t)h.rows * h.cols);
-    in.Read(d.data(), d.size());
+    std::vector<uint8_t> d;
+    ReadGrow(in, &d, total);
+    m->data.assign(total, 0.f);
     const float inc = h.range * (1.0f / 255.0f);
     for (size_t i = 0; i < d.size(); ++i) m->data[i] = d[i] * inc + h.min_value;
   }
@@ -388,12 +406,12 @@ void ReadMatrix(Input& in, bool binary, Matrix* m) {
     if (r < 0 || c < 0) throw KioError("negative matrix dimension");
     m->rows = r;
     m->cols = c;
-    m->data.resize((size_t)r * c);
     if (tok == "FM") {
-      in.Read(m->data.data(), m->data.size() * 4);
+      ReadGrow(in, &m->data, (size_t)r * c);
     } else {
-      std::vector<double> d(m->data.size());
-      in.Read(d.data(), d.size() * 8);
+      std::vector<double> d;
+      ReadGrow(in, &d, (size_t)r * c);
+      m->data.resize(d.size());
       for (size_t i = 0; i < d.size(); ++i) m->data[i] = (float)d[i];
     }
     return;
