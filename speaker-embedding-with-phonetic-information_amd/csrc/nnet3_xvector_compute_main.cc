@@ -77,6 +77,7 @@ const char* kUsage =
     "  --backend-mean=<vec> --backend-transform=<mat> --backend-normalize-length=true|false [--backend-scaleup=true]\n"
     "                                   apply ivector-subtract-global-mean | transform-vec | ivector-normalize-length\n"
     "                                   on the device to every embedding before it is written\n"
+    "  --profile-json=<file>            per-kernel device time of the whole job (HIP events stamped by the dispatches)\n"
     "  --config=<file>  --verbose=<int>  --print-args=true|false  --help\n";
 
 struct Options {
@@ -94,6 +95,7 @@ struct Options {
   bool cmn_center = true;
   std::string vad_rspecifier;
   std::string backend_mean, backend_transform;
+  std::string profile_json;
   bool backend_normalize = false, backend_scaleup = true;
 };
 
@@ -159,6 +161,7 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   else if (name == "device") return need_int(&o->device);
   else if (name == "cmn-window") return need_int(&o->cmn_window);
   else if (name == "vad-rspecifier") o->vad_rspecifier = value;
+  else if (name == "profile-json") o->profile_json = value;
   else if (name == "backend-mean") o->backend_mean = value;
   else if (name == "backend-transform") o->backend_transform = value;
   else if (name == "backend-normalize-length") {
@@ -311,6 +314,30 @@ int main(int argc, char** argv) {
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
                    << opt.precision << ", " << (engine.weight_bytes() >> 20) << " MiB of packed weights");
 
+    if (!opt.profile_json.empty()) engine.SetProfiling(true);
+    // --profile-json: {"kernels": [{"name", "launches", "total_ms"}], "utterances", "failed", "frames", "seconds"}
+    auto write_profile = [&](const xv::TableExtractResult& r) {
+      if (opt.profile_json.empty()) return;
+      std::istringstream rep(engine.ProfileReport());
+      std::ostringstream js;
+      js << "{\"kernels\": [";
+      std::string line;
+      bool first = true;
+      while (std::getline(rep, line)) {
+        const size_t a = line.find('\t'), b = line.rfind('\t');
+        if (a == std::string::npos || b == a) continue;
+        js << (first ? "" : ", ") << "{\"name\": \"" << line.substr(0, a) << "\", \"launches\": " << line.substr(a + 1, b - a - 1)
+           << ", \"total_ms\": " << line.substr(b + 1) << "}";
+        first = false;
+      }
+      js << "], \"utterances\": " << r.num_success << ", \"failed\": " << r.num_fail << ", \"frames\": " << (long)r.frames
+         << ", \"seconds\": " << r.seconds << ", \"device\": " << device << ", \"precision\": \"" << opt.precision << "\"}\n";
+      xv::Output out;
+      out.Open(opt.profile_json);
+      out.Puts(js.str());
+      out.Close();
+    };
+
     if (g_frame_job) {
       xv::TableExtractResult fr = xv::RunTableCompute(
           &engine, opt.batch_frames, g_apply_exp, feat_rspec, vec_wspec,
@@ -318,6 +345,7 @@ int main(int argc, char** argv) {
       XLOG("Time taken " << fr.seconds << "s: real-time factor assuming 100 frames/sec is "
                          << (fr.seconds * 100.0 / std::max(fr.frames, 1.0)));
       XLOG("Done " << fr.num_success << " utterances, failed for " << fr.num_fail);
+      write_profile(fr);
       return fr.num_success != 0 ? 0 : 1;
     }
     // ---- the utterance loop (reader thread -> batches -> device -> ark,scp writer) ---------------------------
@@ -345,6 +373,7 @@ int main(int argc, char** argv) {
     XLOG("Time taken " << res.seconds << "s: real-time factor assuming 100 frames/sec is "
                        << (res.seconds * 100.0 / std::max(res.frames, 1.0)));
     XLOG("Done " << res.num_success << " utterances, failed for " << res.num_fail);
+    write_profile(res);
     return res.num_success != 0 ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "ERROR (%s[xvec-hip-0.1]:main()) %s\n", kProg, e.what());

@@ -159,3 +159,17 @@ def test_cli_many_small_batches_keep_order_and_values(tmp_path, frontend):
         f = fe.sliding_cmn(x, 300, True).astype(np.float32) if frontend else x
         ref = H.xo.extract_xvector(ev, f, -1, 25, False)
         assert H.rel_err(got[k][None], ref[None]) < TOL, k
+
+
+def test_cli_profile_json(job):
+    import json
+    d, utts, ev = job
+    prof = d / "profile.json"
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine", "--batch-frames=600",
+              "--profile-json=%s" % prof, str(d / "final.raw"), "ark:%s/feats.ark" % d, "ark:/dev/null"])
+    assert r.returncode == 0, r.stderr.decode()
+    p = json.loads(prof.read_text())
+    names = [k["name"] for k in p["kernels"]]
+    assert names[0] == "prep_input" and "tdnn_gemm<stats>:tdnn5.batchnorm" in names and "tdnn_gemm<f32>:tdnn6.affine" in names
+    assert all(k["launches"] == p["kernels"][0]["launches"] >= 3 and k["total_ms"] > 0 for k in p["kernels"])
+    assert p["utterances"] == 7 and p["failed"] == 1 and p["frames"] > 0 and p["seconds"] > 0
