@@ -316,6 +316,7 @@ Engine::~Engine() {
       (void)hipEventSynchronize(S.done);
       (void)hipEventDestroy(S.done);
     }
+    if (S.h2d_done) (void)hipEventDestroy(S.h2d_done);
     S.plan.reset();
     fr(S.d_feats);
     fr(S.d_out);
@@ -335,6 +336,7 @@ Engine::~Engine() {
   fr(fe_out_);
   fr(out_stage_);
   if (d_blob_) (void)hipFree(d_blob_);
+  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -786,6 +788,11 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
   const size_t lane = (size_t)seq % lanes_.size();
   hipStream_t s = lanes_[lane].stream;
   if (!S.done) Check(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate(slot)");
+  if (!S.h2d_done) Check(hipEventCreateWithFlags(&S.h2d_done, hipEventDisableTiming), "hipEventCreate(slot)");
+  if (!copy_stream_) Check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate(copy)");
+  // The uploads go on their own stream: the lane may still be busy with an older batch, and queued behind it the
+  // 12 MB copy would only start when that batch ends and the lane would then idle for the length of the copy.
+  hipStream_t cs = copy_stream_;
   S.plan.reset(new Plan());
   std::vector<uint8_t> tables;
   FillPlan(row_offsets, B, S.plan.get(), &tables);
@@ -807,9 +814,11 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
   S.plan->d_tables = S.d_tables.p;
   S.plan->borrowed_tables = true;
   BindPlan(S.plan.get(), S.d_tables.p);
-  Check(hipMemcpyAsync(S.d_tables.p, S.h_tables, tables.size(), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plan tables)");
+  Check(hipMemcpyAsync(S.d_tables.p, S.h_tables, tables.size(), hipMemcpyHostToDevice, cs), "hipMemcpyAsync(plan tables)");
   if (!fe) {
-    Check(hipMemcpyAsync(S.d_feats.p, S.h_feats, fbytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(feats)");
+    Check(hipMemcpyAsync(S.d_feats.p, S.h_feats, fbytes, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(feats)");
+    Check(hipEventRecord(S.h2d_done, cs), "hipEventRecord(upload)");
+    Check(hipStreamWaitEvent(s, S.h2d_done, 0), "hipStreamWaitEvent(upload)");
   } else {
     const int D = info_.input_dim;
     const long raw_rows = fe->raw_off[fe->n_utts];
@@ -823,8 +832,10 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
     memcpy(ht + o_off, fe->raw_off, (size_t)(fe->n_utts + 1) * 4);
     memcpy(ht + o_row, fe->sel_row, (size_t)fe->n_out * 4);
     memcpy(ht + o_utt, fe->sel_utt, (size_t)fe->n_out * 4);
-    Check(hipMemcpyAsync(S.d_fetab.p, S.h_fetab, tab, hipMemcpyHostToDevice, s), "hipMemcpyAsync(front-end tables)");
-    Check(hipMemcpyAsync(S.d_raw.p, S.h_feats, hbytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(raw feats)");
+    Check(hipMemcpyAsync(S.d_fetab.p, S.h_fetab, tab, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(front-end tables)");
+    Check(hipMemcpyAsync(S.d_raw.p, S.h_feats, hbytes, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(raw feats)");
+    Check(hipEventRecord(S.h2d_done, cs), "hipEventRecord(upload)");
+    Check(hipStreamWaitEvent(s, S.h2d_done, 0), "hipStreamWaitEvent(upload)");
     FrontEndArgs fa;
     fa.raw = (const float*)S.d_raw.p;
     fa.raw_off = (const int32_t*)((const uint8_t*)S.d_fetab.p + o_off);

@@ -140,6 +140,7 @@ class Engine {
     void* h_fetab = nullptr;        // pinned
     size_t h_fetab_bytes = 0;
     hipEvent_t done = nullptr;
+    hipEvent_t h2d_done = nullptr;   // uploads run on copy_stream_, ahead of the lane that will consume them
     bool pending = false;
     std::unique_ptr<Plan> plan;   // its tables live in d_tables (not owned by the plan)
   };
@@ -160,6 +161,7 @@ class Engine {
   int pad_left_ = 0, pad_right_ = 0;
   int nplanes_ = 1;
   hipStream_t stream_ = nullptr;
+  hipStream_t copy_stream_ = nullptr;   // host-slot uploads (SubmitHost)
   void* d_blob_ = nullptr;
   size_t blob_data_bytes_ = 0;
   std::vector<DevLayer> layers_;
