@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# precision mode -> MFMAs executed per algorithmic product in the frame-level GEMMs
+PRECISION_NOTES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "auto": None, "bf16": 1, "fp16": 1}
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
@@ -59,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16"])
+    ap.add_argument("--precision", default="bf16x3", choices=sorted(PRECISION_NOTES))
     ap.add_argument("--topology", default="v2_xvector")
     ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
     ap.add_argument("--frames", type=int, default=400)
@@ -238,11 +240,15 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        mfma_passes = PRECISION_NOTES[args.precision]
+        if mfma_passes is None:   # auto: two-pass kernels for chunks that pool >= the engine's threshold, else three
+            thr = int(os.environ.get("XVEC_FAST_MIN_POOLED", "300"))
+            mfma_passes = 2 if pool_frames >= thr and not frame_level and not args.ragged else 3
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
                     "kernel": "tdnn_gemm_kernel<%s,act>" % args.precision, "launches_per_step": n_act_per_step,
                     "avg_launch_ms": avg_launch_ms, "alg_flops_per_launch": flops_per_launch,
-                    "mfma_per_alg_mac": 3 if args.precision == "bf16x3" else 1,
+                    "mfma_per_alg_mac": mfma_passes,
                     "whole_step_alg_tflops": 2.0 * macs * B * args.steps / dt / 1e12 * 1.0,
                     "gemm_ms_per_step": gemm_ms / args.steps, "all_kernels_ms_per_step": total_prof_ms / args.steps}
         # ---- parity spot check against the oracle on the same inputs (not timed) ------------------------------
@@ -271,7 +277,7 @@ def main():
             "parity_rel_err_vs_oracle_fp32": parity,
             "kernels_ms_per_step": {l: ms / max(1, c) for (l, c, ms) in prof},
         }
-        if world == 1 and not args.no_extra_modes and args.precision == "bf16x3" and not frame_level and not args.ragged:
+        if world == 1 and not args.no_extra_modes and PRECISION_NOTES[args.precision] != 1 and not frame_level and not args.ragged:
             # single-pass modes, reported next to the parity mode with their measured error (never `value`)
             extra = {}
             os.environ["XVEC_LANES"] = "2"

@@ -35,7 +35,14 @@ typedef enum {
 typedef enum {
   XV_PREC_BF16X3 = 0,  /* split-bf16 MFMA (3 products, fp32 accumulate): the <=1e-4 parity mode, default */
   XV_PREC_BF16 = 1,    /* single-pass bf16 MFMA */
-  XV_PREC_FP16 = 2     /* single-pass fp16 MFMA */
+  XV_PREC_FP16 = 2,    /* single-pass fp16 MFMA */
+  XV_PREC_FP16X3 = 3,  /* split-fp16 MFMA (3 products of 11+11-bit operands, fp32 accumulate) */
+  XV_PREC_FP16X2 = 4,  /* fp16 activations x split-fp16 weights (2 products): removes the weight rounding error, which
+                          is coherent over the frames of a chunk; the activation rounding error averages out in the
+                          statistics pooling.  Layers after the pooling run XV_PREC_FP16X3.  Not for frame-level
+                          outputs (they run XV_PREC_FP16X3) */
+  XV_PREC_AUTO = 5     /* XV_PREC_FP16X2 for chunks that pool >= 300 frames (XVEC_FAST_MIN_POOLED), XV_PREC_FP16X3 for
+                          shorter ones; the choice depends on the chunk's own length only */
 } xv_precision;
 
 typedef struct xv_model xv_model; /* host side: parsed nnet3 model lowered to a TDNN program */
@@ -167,7 +174,7 @@ xv_status xv_segment_mean(int device, const float* x, int32_t n, int32_t dim, co
 /* ---- kernel-level entry (unit tests of the HIP GEMM against a plain fp32 reference) ------------------- */
 typedef struct {
   const void* hi;   /* device plane (bf16 / fp16) at logical row 0 */
-  const void* lo;   /* residual plane (XV_PREC_BF16X3 only) */
+  const void* lo;   /* residual plane (XV_PREC_BF16X3 / XV_PREC_FP16X3 only) */
   int32_t ld;       /* leading dimension in elements */
   int32_t row_shift;
   int32_t k_len;    /* multiple of 32 */

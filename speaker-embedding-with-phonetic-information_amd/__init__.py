@@ -17,8 +17,10 @@ BIN_DIR = os.path.join(_HERE, "bin")
 
 XV_OK = 0
 XV_ERR_IO, XV_ERR_MODEL, XV_ERR_DEVICE, XV_ERR_ARG, XV_ERR_INTERNAL = 1, 2, 3, 4, 5
-PREC_BF16X3, PREC_BF16, PREC_FP16 = 0, 1, 2
-PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16}
+PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO = 0, 1, 2, 3, 4, 5
+PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3,
+              "fp16x2": PREC_FP16X2, "auto": PREC_AUTO}
+MFMA_PASSES = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp16x3": 3, "fp16x2": 2}   # MFMAs per algorithmic product
 EPI_ACT, EPI_F32, EPI_STATS = 0, 1, 2
 
 

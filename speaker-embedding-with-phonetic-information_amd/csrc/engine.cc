@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <sstream>
 
 namespace xv {
@@ -41,10 +42,9 @@ inline uint64_t Align256(uint64_t x) { return (x + 255) & ~255ull; }
 }  // namespace
 
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
-  if (precision != kPrecBf16x3 && precision != kPrecBf16 && precision != kPrecFp16)
-    throw EngineError("unknown precision mode");
-  const bool split = precision == kPrecBf16x3;
-  const bool f16 = precision == kPrecFp16;
+  if (precision < kPrecBf16x3 || precision > kPrecAuto) throw EngineError("unknown precision mode");
+  const bool split = PrecWPlanes(precision) == 2;
+  const bool f16 = PrecF16(precision);
   const int nl = (int)prog.layers.size();
   std::vector<BlobLayer> bl(nl);
   uint64_t cur = 0;
@@ -67,7 +67,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     b.k_pad = kp;
     b.n_pad = RoundUp(L.out_dim, kBN);
     b.relu = L.relu;
-    b.bn = L.bn;
+    b.bn = L.bn || (f16 && split);   // scaled split-fp16 weights: the epilogue's scale step undoes the scaling
     b.log_softmax = L.log_softmax;
     b.segment_level = L.segment_level;
     b.left = L.left;
@@ -117,14 +117,29 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     const BlobLayer& b = bl[i];
     uint16_t* whi = (uint16_t*)(data + b.w_hi);
     uint16_t* wlo = split ? (uint16_t*)(data + b.w_lo) : nullptr;
+    // Split fp16: the residual plane holds values 2^-12 times smaller than the weights, which for |w| ~ 0.03 is the
+    // fp16 subnormal range (< 2^-14).  The whole matrix is therefore scaled by a power of two that puts max |w| just
+    // below 2^14; the exact inverse goes into the epilogue (bias * 2^S before ReLU, BatchNorm scale * 2^-S after it:
+    // power-of-two factors commute with every rounding, so the result is bit-identical to the unscaled computation).
+    float wscale = 1.f;
+    if (f16 && split) {
+      float mx = 0.f;
+      for (size_t k = 0; k < L.w.size(); ++k) mx = std::max(mx, std::fabs(L.w[k]));
+      if (mx > 0.f && std::isfinite(mx)) {
+        int e;
+        frexpf(mx, &e);              // mx = m * 2^e, m in [0.5, 1)
+        wscale = ldexpf(1.f, 14 - e);
+      }
+    }
     for (int n = 0; n < L.out_dim; ++n) {
       int kcol = 0, kpad = 0;
       for (int j = 0; j < b.nsrc; ++j) {
         for (int d = 0; d < b.src_dim[j]; ++d) {
-          const float w = L.w[(size_t)n * L.in_dim + kcol + d];
+          const float w = L.w[(size_t)n * L.in_dim + kcol + d] * wscale;
           const size_t o = (size_t)n * b.k_pad + kpad + d;
           if (f16) {
             whi[o] = host_f32_to_f16(w);
+            if (split) wlo[o] = host_f32_to_f16(w - host_f16_to_f32(whi[o]));
           } else {
             whi[o] = host_f32_to_bf16(w);
             if (split) wlo[o] = host_f32_to_bf16(w - host_bf16_to_f32(whi[o]));
@@ -137,9 +152,10 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     float* bias = (float*)(data + b.bias);
     float* scale = (float*)(data + b.scale);
     float* offset = (float*)(data + b.offset);
+    const float inv = 1.f / wscale;
     for (int n = 0; n < L.out_dim; ++n) {
-      bias[n] = L.bias[n];
-      scale[n] = L.bn ? L.bn_scale[n] : 1.f;
+      bias[n] = L.bias[n] * wscale;
+      scale[n] = (L.bn ? L.bn_scale[n] : 1.f) * inv;
       offset[n] = L.bn ? L.bn_offset[n] : 0.f;
     }
     // padded output columns: bias 0, scale 0, offset 0 -> they stay exactly 0 downstream
@@ -251,7 +267,16 @@ Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
         if (s.layer == info_.pooled_layer)
           throw EngineError("the pooled layer must feed only the statistics pooling");
   }
-  nplanes_ = info_.precision == kPrecBf16x3 ? 2 : 1;
+  nplanes_ = PrecWPlanes(info_.precision);   // residual planes exist for every split mode
+  // Kernel modes.  slow_prec_ runs everything that is not a frame-level GEMM of a "fast" chunk; fast chunks (only
+  // kPrecFp16x2 / kPrecAuto have them) are those that pool at least fast_min_pooled_ frames, see FillPlan.
+  slow_prec_ = (info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto) ? (int)kPrecFp16x3 : info_.precision;
+  has_fast_ = !frame_mode_ && (info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto);
+  fast_min_pooled_ = 0;
+  if (info_.precision == kPrecAuto) {
+    const char* e = getenv("XVEC_FAST_MIN_POOLED");
+    fast_min_pooled_ = (e && *e) ? atoi(e) : kDefaultFastMinPooled;
+  }
   Check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   {
     const char* e = getenv("XVEC_LANES");
@@ -412,16 +437,34 @@ void Engine::FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector
   plan->b_pad = RoundUp(B, kBM);
   plan->src_off.assign(row_offsets, row_offsets + B + 1);
   plan->src_rows = row_offsets[B];
-  std::vector<int32_t> dev_off(B);
-  long off = 0;
-  for (int b = 0; b < B; ++b) {
-    dev_off[b] = (int32_t)off;
-    off += RoundUp(key[b] + pad_left_ + pad_right_, kRowAlign);
-    if (off > (1l << 30)) throw EngineError("batch too large (more than 2^30 device rows)");
+  // Device row layout: the chunks that take the two-pass kernels ("fast": they pool enough frames for the
+  // activation rounding error to average out) come first, then, from a 256-row boundary on, the others.  Which
+  // region a chunk lands in depends on its own length only, so its embedding does not depend on the batch around it.
+  const BlobLayerInfo& pl = info_.layers[frame_mode_ ? 0 : info_.pooled_layer];
+  const int pool_first = std::max(pl.left, -info_.pool_left);
+  std::vector<int32_t> dev_off(B), cnt(B, 0);
+  std::vector<char> fast(B, 0);
+  for (int b = 0; b < B && !frame_mode_; ++b) {
+    // frames of the pooled layer that exist, intersected with the pooling window of output index t=0
+    const int last = std::min(key[b] - 1 - pl.right, info_.pool_right);
+    if (last < pool_first) throw EngineError("chunk has no frame inside the pooling window");
+    cnt[b] = last - pool_first + 1;
+    fast[b] = has_fast_ && cnt[b] >= fast_min_pooled_;
   }
-  plan->rows = RoundUp((int)off, 2 * kBM);  // the 256-row GEMM variant needs an even number of 128-row tiles
+  long off = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int b = 0; b < B; ++b) {
+      if ((pass == 0) != (fast[b] != 0)) continue;
+      dev_off[b] = (int32_t)off;
+      off += RoundUp(key[b] + pad_left_ + pad_right_, kRowAlign);
+      if (off > (1l << 30)) throw EngineError("batch too large (more than 2^30 device rows)");
+    }
+    off = RoundUp((int)off, 2 * kBM);  // the 256-row GEMM variant needs an even number of 128-row tiles
+    if (pass == 0) plan->rows_fast = (int)off;
+  }
+  plan->rows = (int)off;
   const int ngrp = plan->rows / kRowAlign;
-  std::vector<int32_t> grp_utt(ngrp, -1), g0(B), g1(B), cnt(B);
+  std::vector<int32_t> grp_utt(ngrp, -1), g0(B), g1(B);
   std::vector<int8_t> grp_range((size_t)ngrp * 2, 0);
   std::vector<int32_t> out_row;
   if (frame_mode_) {
@@ -436,14 +479,10 @@ void Engine::FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector
     }
     plan->n_out = (int)out_row.size();
   }
-  const BlobLayerInfo& pl = info_.layers[frame_mode_ ? 0 : info_.pooled_layer];
   for (int b = 0; b < B && !frame_mode_; ++b) {
     const int T = key[b];
-    // frames of the pooled layer that exist, intersected with the pooling window of output index t=0
-    const int first = std::max(pl.left, -info_.pool_left);
-    const int last = std::min(T - 1 - pl.right, info_.pool_right);
-    if (last < first) throw EngineError("chunk has no frame inside the pooling window");
-    cnt[b] = last - first + 1;
+    const int first = pool_first;
+    const int last = first + cnt[b] - 1;
     g0[b] = dev_off[b] / kRowAlign;
     g1[b] = (dev_off[b] + RoundUp(T, kRowAlign)) / kRowAlign;
     for (int g = g0[b]; g < g1[b]; ++g) {
@@ -520,7 +559,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
   hipStream_t s = stream ? stream : L.stream;
   if (L.busy) Check(hipStreamWaitEvent(s, L.done, 0), "hipStreamWaitEvent(lane)");
   EnsureCapacity(L, plan.rows, plan.b_pad);
-  const int prec = info_.precision;
+  const int prec = slow_prec_;
 
   PrepArgs pa;
   pa.feats = feats_dev;
@@ -645,7 +684,29 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       }
     }
     arm(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
-    Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
+    if (li.segment_level || plan.rows_fast == 0) {
+      Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
+    } else {
+      // rows [0, rows_fast): two-pass kernels; the rest: slow_prec_.  Same arguments, row base moved.
+      for (int region = 0; region < 2; ++region) {
+        const long r0 = region == 0 ? 0 : plan.rows_fast;
+        const long r1 = region == 0 ? plan.rows_fast : plan.rows;
+        if (r1 <= r0) continue;
+        GemmArgs gr = ga;
+        gr.m_tiles = (int)((r1 - r0) / kBM);
+        for (int j = 0; j < gr.nseg; ++j) {
+          gr.seg[j].hi += r0 * gr.seg[j].ld;
+          if (gr.seg[j].lo) gr.seg[j].lo += r0 * gr.seg[j].ld;
+        }
+        if (gr.out_hi) gr.out_hi += r0 * gr.ldo;
+        if (gr.out_lo) gr.out_lo += r0 * gr.ldo;
+        if (gr.out_f32) gr.out_f32 += r0 * gr.ldf;
+        if (gr.partial) gr.partial += (r0 / kRowAlign) * 2 * gr.ldp;
+        if (gr.grp_range) gr.grp_range += (r0 / kRowAlign) * 2;
+        gr.m_valid = (int)(r1 - r0);
+        Check(launch_tdnn_gemm(gr, region == 0 ? (int)kPrecFp16x2 : prec, epi, s), "tdnn_gemm launch");
+      }
+    }
     disarm();
 
     if ((int)i == info_.pooled_layer) {

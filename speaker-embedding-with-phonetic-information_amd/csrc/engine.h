@@ -160,6 +160,12 @@ class Engine {
   bool frame_mode_ = false;   // output is one row per input frame (nnet3-compute semantics), no pooling
   int pad_left_ = 0, pad_right_ = 0;
   int nplanes_ = 1;
+  // precision policy (engine.cc, constructor): kernel mode of everything but the frame-level GEMMs of "fast" chunks,
+  // whether fast chunks exist at all, and the number of pooled frames that makes a chunk fast
+  static constexpr int kDefaultFastMinPooled = 300;
+  int slow_prec_ = 0;
+  bool has_fast_ = false;
+  int fast_min_pooled_ = 0;
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;   // host-slot uploads (SubmitHost)
   void* d_blob_ = nullptr;
@@ -179,6 +185,7 @@ class Engine {
 
 struct Engine::Plan {
   int B = 0, b_pad = 0, rows = 0, src_rows = 0;
+  int rows_fast = 0;             // device rows [0, rows_fast) hold the chunks that run the two-pass kernels
   std::vector<int32_t> src_off;  // [B+1]
   void* d_tables = nullptr;      // one device allocation holding all tables below (owned unless borrowed)
   bool borrowed_tables = false;  // tables live in a host slot's buffer

@@ -28,7 +28,18 @@ enum Precision : int {
   kPrecBf16x3 = 0,  // split bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate (parity mode)
   kPrecBf16 = 1,    // single-pass bf16 MFMA
   kPrecFp16 = 2,    // single-pass fp16 MFMA
+  kPrecFp16x3 = 3,  // split fp16: hi*hi + hi*lo + lo*hi (22-bit operands), fp32 accumulate
+  kPrecFp16x2 = 4,  // fp16 activations (one plane) x split fp16 weights (hi + lo): two MFMAs per product.  The weight
+                    // rounding error - coherent over the frames of a chunk, so the pooling does not average it - is
+                    // removed; the activation rounding error is independent per frame and averages out in the
+                    // statistics pooling (measured: DESIGN.md section 3.1).  Frame-level layers only.
+  kPrecAuto = 5,    // engine policy, not a kernel mode: kPrecFp16x2 for chunks that pool >= a threshold of frames,
+                    // kPrecFp16x3 for the others (same packed weights)
 };
+constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto; }
+constexpr int PrecXPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3) ? 2 : 1; }   // kernel modes only
+constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto) ? 2 : 1; }
+constexpr int PrecPasses(int p) { return PrecXPlanes(p) + PrecWPlanes(p) - 1; }   // MFMAs per algorithmic product
 
 enum Epilogue : int {
   kEpiAct = 0,    // bias -> ReLU? -> BatchNorm? -> split to 16-bit planes

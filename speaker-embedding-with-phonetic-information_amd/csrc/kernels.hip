@@ -161,8 +161,8 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
 template <int PREC, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], const int mbase, const int nbase,
                                               const int lane, const EpiRegs& e) {
-  constexpr bool SPLIT = (PREC == kPrecBf16x3);
-  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
+  constexpr bool F16 = PrecF16(PREC);
   const int fr_i = lane & 15;
   const int fr_g = lane >> 4;
   // ---- epilogues ---------------------------------------------------------------------------
@@ -264,11 +264,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 
 template <int PREC, int EPI>
 __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
-  constexpr bool SPLIT = (PREC == kPrecBf16x3);
-  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
+  constexpr bool WSPLIT = PrecWPlanes(PREC) == 2;  // weights carry a residual plane
+  constexpr bool F16 = PrecF16(PREC);
   constexpr bool SWAP = (EPI != kEpiStats);  // weight tile is the MFMA A operand
-  constexpr int NPL = SPLIT ? 2 : 1;
-  constexpr int STAGE = kTileBytes * 2 * NPL;
+  constexpr int NPX = SPLIT ? 2 : 1, NPW = WSPLIT ? 2 : 1;
+  constexpr int STAGE = kTileBytes * (NPX + NPW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     const int wrow = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
     const long off = (long)(n0 + wrow) * a.ldw + ld_chunk * 8;
     wp_hi[u] = a.w_hi + off;
-    wp_lo[u] = SPLIT ? a.w_lo + off : nullptr;
+    wp_lo[u] = WSPLIT ? a.w_lo + off : nullptr;
   }
 
   // activation-side staging pointers of the current K segment (one Append() term); they are
@@ -330,14 +331,12 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
       const int c = c0 + u;
       glds16(xp_hi[u], st + c * 1024);
       if constexpr (SPLIT) glds16(xp_lo[u], st + kTileBytes + c * 1024);
-      glds16(wp_hi[u], st + NPL * kTileBytes + c * 1024);
-      if constexpr (SPLIT) glds16(wp_lo[u], st + (NPL + 1) * kTileBytes + c * 1024);
+      glds16(wp_hi[u], st + NPX * kTileBytes + c * 1024);
+      if constexpr (WSPLIT) glds16(wp_lo[u], st + (NPX + 1) * kTileBytes + c * 1024);
       xp_hi[u] += kBK;
       wp_hi[u] += kBK;
-      if constexpr (SPLIT) {
-        xp_lo[u] += kBK;
-        wp_lo[u] += kBK;
-      }
+      if constexpr (SPLIT) xp_lo[u] += kBK;
+      if constexpr (WSPLIT) wp_lo[u] += kBK;
     }
     if (--seg_left == 0 && ld_seg + 1 < a.nseg) open_seg(++ld_seg);
   };
@@ -347,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   const int fr_g = lane >> 4;
   const int fr_chunk = fr_g ^ ((fr_i >> 1) & 3);
   const int x_rd = (wave_m * 64 + fr_i) * 64 + fr_chunk * 16;                     // + f*1024
-  const int w_rd = NPL * kTileBytes + (wave_n * 64 + fr_i) * 64 + fr_chunk * 16;  // + f*1024
+  const int w_rd = NPX * kTileBytes + (wave_n * 64 + fr_i) * 64 + fr_chunk * 16;  // + f*1024
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -365,10 +364,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
       for (int u = 0; u < 2; ++u) {
         xp_hi[u] += kBK;
         wp_hi[u] += kBK;
-        if constexpr (SPLIT) {
-          xp_lo[u] += kBK;
-          wp_lo[u] += kBK;
-        }
+        if constexpr (SPLIT) xp_lo[u] += kBK;
+        if constexpr (WSPLIT) wp_lo[u] += kBK;
       }
       if (--seg_left == 0 && ld_seg + 1 < a.nseg) open_seg(++ld_seg);
     }
@@ -384,10 +381,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     for (int f = 0; f < 4; ++f) {
       xh[f] = *(const s16x8*)(st + x_rd + f * 1024);
       wh[f] = *(const s16x8*)(st + w_rd + f * 1024);
-      if constexpr (SPLIT) {
-        xl[f] = *(const s16x8*)(st + x_rd + kTileBytes + f * 1024);
-        wl[f] = *(const s16x8*)(st + w_rd + kTileBytes + f * 1024);
-      }
+      if constexpr (SPLIT) xl[f] = *(const s16x8*)(st + x_rd + kTileBytes + f * 1024);
+      if constexpr (WSPLIT) wl[f] = *(const s16x8*)(st + w_rd + kTileBytes + f * 1024);
     }
     // stage the next K step into the other buffer: every wave finished reading it before the
     // barrier that ended the previous iteration.
@@ -398,16 +393,12 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if constexpr (SWAP) {
-          if constexpr (SPLIT) {
-            acc[p][q] = mfma16<F16>(wl[p], xh[q], acc[p][q]);
-            acc[p][q] = mfma16<F16>(wh[p], xl[q], acc[p][q]);
-          }
+          if constexpr (WSPLIT) acc[p][q] = mfma16<F16>(wl[p], xh[q], acc[p][q]);
+          if constexpr (SPLIT) acc[p][q] = mfma16<F16>(wh[p], xl[q], acc[p][q]);
           acc[p][q] = mfma16<F16>(wh[p], xh[q], acc[p][q]);
         } else {
-          if constexpr (SPLIT) {
-            acc[p][q] = mfma16<F16>(xl[p], wh[q], acc[p][q]);
-            acc[p][q] = mfma16<F16>(xh[p], wl[q], acc[p][q]);
-          }
+          if constexpr (SPLIT) acc[p][q] = mfma16<F16>(xl[p], wh[q], acc[p][q]);
+          if constexpr (WSPLIT) acc[p][q] = mfma16<F16>(xh[p], wl[q], acc[p][q]);
           acc[p][q] = mfma16<F16>(xh[p], wh[q], acc[p][q]);
         }
       }
@@ -453,21 +444,23 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int PREC, int EPI>
 __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
-  constexpr bool SPLIT = (PREC == kPrecBf16x3);
-  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
+  constexpr bool WSPLIT = PrecWPlanes(PREC) == 2;  // weights carry a residual plane
+  constexpr bool F16 = PrecF16(PREC);
   constexpr bool SWAP = (EPI != kEpiStats);
-  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int NPX = SPLIT ? 2 : 1, NPW = WSPLIT ? 2 : 1;
   constexpr int XROWS = 256 + 16;              // tile rows + halo for the time offsets of a group
   constexpr int XT = XROWS * kBK * 2;          // 17 KiB: one activation plane slot
   constexpr int WT = kTileBytes;               //  8 KiB: one 128-row weight plane slot
-  constexpr int XSLOT = NPL * XT;
-  constexpr int WSLOT = NPL * WT;
+  constexpr int XSLOT = NPX * XT;
+  constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;             // weight ring behind the activation ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -513,7 +506,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     const int wrow = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
     const long off = (long)(n0 + wrow) * a.ldw + ld_chunk * 8;
     wrow_hi = a.w_hi + off;
-    wrow_lo = SPLIT ? a.w_lo + off : nullptr;
+    wrow_lo = WSPLIT ? a.w_lo + off : nullptr;
   }
   const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
 
@@ -533,12 +526,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
         glds16_asm(gi.hi + off, st + c * 1024);
         if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + c * 1024);
       }
-      n += 2 * NPL;
+      n += 2 * NPX;
       if (wave == 0 && gi.nshift > 1) {  // halo rows 256..271 (only read by displaced offsets)
         const long off = (long)(m0 + gi.shift0 + 256 + ld_row) * gi.ld + col;
         glds16_asm(gi.hi + off, st + 16 * 1024);
         if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + 16 * 1024);
-        n += NPL;
+        n += NPX;
       }
       ixslot = ixslot == 2 ? 0 : ixslot + 1;
     }
@@ -546,8 +539,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
       const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
       glds16_asm(wrow_hi + wcol, st);
-      if constexpr (SPLIT) glds16_asm(wrow_lo + wcol, st + WT);
-      n += NPL;
+      if constexpr (WSPLIT) glds16_asm(wrow_lo + wcol, st + WT);
+      n += NPW;
       iwslot = iwslot == 2 ? 0 : iwslot + 1;
     }
     if (++ij == gi.nshift) {
@@ -579,10 +572,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     for (int i = 0; i < 4; ++i) {
       f.xh[i] = *(const s16x8*)(xs + x_rd + i * 1024);
       f.wh[i] = *(const s16x8*)(ws + w_rd + i * 1024);
-      if constexpr (SPLIT) {
-        f.xl[i] = *(const s16x8*)(xs + x_rd + XT + i * 1024);
-        f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
-      }
+      if constexpr (SPLIT) f.xl[i] = *(const s16x8*)(xs + x_rd + XT + i * 1024);
+      if constexpr (WSPLIT) f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
     }
     rwslot = rwslot == 2 ? 0 : rwslot + 1;
     if (++rj == r_nshift) {
@@ -610,16 +601,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if constexpr (SWAP) {
-          if constexpr (SPLIT) {
-            acc[p][q] = mfma16<F16>(f.wl[p], f.xh[q], acc[p][q]);
-            acc[p][q] = mfma16<F16>(f.wh[p], f.xl[q], acc[p][q]);
-          }
+          if constexpr (WSPLIT) acc[p][q] = mfma16<F16>(f.wl[p], f.xh[q], acc[p][q]);
+          if constexpr (SPLIT) acc[p][q] = mfma16<F16>(f.wh[p], f.xl[q], acc[p][q]);
           acc[p][q] = mfma16<F16>(f.wh[p], f.xh[q], acc[p][q]);
         } else {
-          if constexpr (SPLIT) {
-            acc[p][q] = mfma16<F16>(f.xl[p], f.wh[q], acc[p][q]);
-            acc[p][q] = mfma16<F16>(f.xh[p], f.wl[q], acc[p][q]);
-          }
+          if constexpr (SPLIT) acc[p][q] = mfma16<F16>(f.xl[p], f.wh[q], acc[p][q]);
+          if constexpr (WSPLIT) acc[p][q] = mfma16<F16>(f.xh[p], f.wl[q], acc[p][q]);
           acc[p][q] = mfma16<F16>(f.xh[p], f.wh[q], acc[p][q]);
         }
       }
@@ -635,15 +622,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   //        every reader passes before its LOAD_{j+1}.
   //   WAR: the slots written for step j+2 were last read for step j-1 (weights) or earlier (activations); both
   //        groups finished those reads (lgkmcnt(0) before their barrier) at least one barrier earlier.
-  // n = DMA instructions this wave may leave in flight: NPL (weights only), 3*NPL (+2 activation chunks), 4*NPL
-  // (wave 0, + halo chunk).
+  // n = DMA instructions this wave may leave in flight: NPW (weights only), NPW + 2*NPX (+2 activation chunks),
+  // NPW + 3*NPX (wave 0, + halo chunk).
   auto wait_and_barrier = [&](int n) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) through the builtin: hipcc's scoreboard then knows about it
     if (n == 0) wait_vm_lgkm0_barrier<0>();
-    else if (n == NPL) wait_vm_lgkm0_barrier<NPL>();
-    else if (n == 3 * NPL) wait_vm_lgkm0_barrier<3 * NPL>();
-    else wait_vm_lgkm0_barrier<4 * NPL>();
+    else if (n == NPW) wait_vm_lgkm0_barrier<NPW>();
+    else if (n == NPW + 2 * NPX) wait_vm_lgkm0_barrier<NPW + 2 * NPX>();
+    else wait_vm_lgkm0_barrier<NPW + 3 * NPX>();
     __builtin_amdgcn_sched_barrier(0);
   };
   auto plain_barrier = [&]() {
@@ -729,8 +716,7 @@ static int device_cu_count() {
 
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
-  constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
-  constexpr int lds = NPL * 3 * ((256 + 16) * kBK * 2 + kTileBytes);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel_v2<PREC, EPI>,
@@ -753,7 +739,7 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
     }
     const int cus = device_cu_count();
     b.stagger_wgs = cus;
-    b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * (PREC == kPrecBf16x3 ? 2200 : 1000) + 14000) * pct / 100 / 2048) : 0;
+    b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * (400 + 600 * PrecPasses(PREC)) + 14000) * pct / 100 / 2048) : 0;
   }
   XV_LAUNCH((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
   return hipGetLastError();
@@ -762,8 +748,7 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (gemm_variant() == 2 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
-  constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
-  constexpr int lds = kTileBytes * 2 * NPL * 2;
+  constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, EPI>,
@@ -781,8 +766,8 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
 // Split-K reduction: out = epilogue(sum over K slices, in slice order, + bias).  One thread = 4 columns of a row.
 template <int PREC, int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
-  constexpr bool SPLIT = (PREC == kPrecBf16x3);
-  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
+  constexpr bool F16 = PrecF16(PREC);
   const int n_pad = a.n_tiles * kBN;
   const int rows = a.m_tiles * kBM;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -821,8 +806,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 
 template <int PREC, int EPI>
 static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
-  constexpr int NPL = (PREC == kPrecBf16x3) ? 2 : 1;
-  constexpr int lds = kTileBytes * 2 * NPL * 2;
+  constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, kEpiSplitK>,
@@ -861,6 +845,8 @@ hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipS
     case kPrecBf16x3: return launch_prec<kPrecBf16x3>(a, epilogue, s);
     case kPrecBf16: return launch_prec<kPrecBf16>(a, epilogue, s);
     case kPrecFp16: return launch_prec<kPrecFp16>(a, epilogue, s);
+    case kPrecFp16x3: return launch_prec<kPrecFp16x3>(a, epilogue, s);
+    case kPrecFp16x2: return launch_prec<kPrecFp16x2>(a, epilogue, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -869,8 +855,8 @@ hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipS
 // prep_input: packed fp32 feature rows -> aligned 16-bit planes.  One thread = 8 columns of a row.
 template <int PREC>
 __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
-  constexpr bool SPLIT = (PREC == kPrecBf16x3);
-  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
+  constexpr bool F16 = PrecF16(PREC);
   const int per_row = a.ld >> 3;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.rows * per_row;
@@ -916,6 +902,7 @@ hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s) {
     case kPrecBf16x3: XV_LAUNCH(prep_input_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
     case kPrecBf16: XV_LAUNCH(prep_input_kernel<kPrecBf16>, grid, block, 0, s, a); break;
     case kPrecFp16: XV_LAUNCH(prep_input_kernel<kPrecFp16>, grid, block, 0, s, a); break;
+    case kPrecFp16x3: XV_LAUNCH(prep_input_kernel<kPrecFp16x3>, grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1025,8 +1012,8 @@ hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s) {
 // only on the position inside the utterance, so results do not depend on batch composition).
 template <int PREC>
 __global__ __launch_bounds__(256) void pool_finalise_kernel(const PoolArgs a) {
-  constexpr bool SPLIT = (PREC == kPrecBf16x3);
-  constexpr bool F16 = (PREC == kPrecFp16);
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
+  constexpr bool F16 = PrecF16(PREC);
   const int b = blockIdx.y;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= a.dim) return;
@@ -1065,6 +1052,7 @@ hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s)
     case kPrecBf16x3: XV_LAUNCH(pool_finalise_kernel<kPrecBf16x3>, grid, block, 0, s, a); break;
     case kPrecBf16: XV_LAUNCH(pool_finalise_kernel<kPrecBf16>, grid, block, 0, s, a); break;
     case kPrecFp16: XV_LAUNCH(pool_finalise_kernel<kPrecFp16>, grid, block, 0, s, a); break;
+    case kPrecFp16x3: XV_LAUNCH(pool_finalise_kernel<kPrecFp16x3>, grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

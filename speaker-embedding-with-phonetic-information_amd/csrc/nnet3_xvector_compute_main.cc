@@ -68,7 +68,9 @@ const char* kUsage =
     "  --pad-input=true|false           pad short chunks by edge replication instead of skipping (default true)\n"
     "  --output-node=<name>             compute this node as the output (native form of nnet3-copy --nnet-config)\n"
     "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
-    "  --precision=bf16x3|bf16|fp16     arithmetic of the MFMA GEMMs (default bf16x3: fp32-grade)\n"
+    "  --precision=bf16x3|fp16x3|fp16x2|auto|bf16|fp16\n"
+    "                                   arithmetic of the MFMA GEMMs (default bf16x3: fp32-grade; auto = fp16x2 for\n"
+    "                                   chunks that pool >= 300 frames, fp16x3 for shorter ones)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
@@ -271,6 +273,9 @@ int main(int argc, char** argv) {
     if (opt.precision == "bf16x3") precision = xv::kPrecBf16x3;
     else if (opt.precision == "bf16") precision = xv::kPrecBf16;
     else if (opt.precision == "fp16") precision = xv::kPrecFp16;
+    else if (opt.precision == "fp16x3") precision = xv::kPrecFp16x3;
+    else if (opt.precision == "fp16x2") precision = xv::kPrecFp16x2;
+    else if (opt.precision == "auto") precision = xv::kPrecAuto;
     else {
       fprintf(stderr, "%s: invalid --precision=%s\n", kProg, opt.precision.c_str());
       return 1;

@@ -61,6 +61,66 @@ def test_v2_ragged_batch_parity_and_batch_invariance(v2):
     assert np.array_equal(out2, out[perm])
 
 
+def test_v2_fp16x3_parity(v2):
+    P, net, line, model = v2
+    ctx = P.Context(model, precision=P.PREC_FP16X3)
+    ev64 = _oracle(net, line, np.float64)
+    for T in (400, 15, 16, 25, 137):
+        x = H.features(T, T)
+        err = H.rel_err(ctx.forward_batch(x, [0, T]), ev64.compute(x))
+        assert err < TOL_PARITY, (T, err)
+
+
+def test_v2_auto_mode_parity_and_batch_invariance(v2):
+    """XV_PREC_AUTO: chunks that pool >= 300 frames take the two-pass kernels (fp16 activations x split-fp16 weights),
+    shorter ones the three-pass ones.  Every chunk stays within the parity tolerance, and which arithmetic a chunk
+    gets depends on its own length only: solo == batched == permuted, bit for bit."""
+    P, net, line, model = v2
+    ctx = P.Context(model, precision=P.PREC_AUTO)
+    ev64 = _oracle(net, line, np.float64)
+    lens = [400, 215, 16, 33, 400, 601, 25, 128, 313, 314, 15, 1000]
+    utts = [H.features(100 + i, T) for i, T in enumerate(lens)]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    ref = np.stack([ev64.compute(u)[0] for u in utts])
+    for i, T in enumerate(lens):
+        err = H.rel_err(out[i:i + 1], ref[i:i + 1])
+        assert err < TOL_PARITY, (T, err)
+    for i in (0, 3, 5, 9, 10):
+        solo = ctx.forward_batch(utts[i], [0, lens[i]])
+        assert np.array_equal(solo[0], out[i]), i
+    perm = [5, 0, 11, 2, 7]
+    f2, o2 = H.pack([utts[i] for i in perm])
+    assert np.array_equal(ctx.forward_batch(f2, o2), out[perm])
+    # all-long and all-short batches (one region only)
+    for sel in ([0, 4, 5, 11], [2, 3, 6, 10]):
+        f3, o3 = H.pack([utts[i] for i in sel])
+        assert np.array_equal(ctx.forward_batch(f3, o3), out[sel])
+    # the long chunks really took the two-pass arithmetic, the short ones the three-pass one
+    x3 = P.Context(model, precision=P.PREC_FP16X3)
+    x2 = P.Context(model, precision=P.PREC_FP16X2)
+    assert np.array_equal(x2.forward_batch(utts[0], [0, 400])[0], out[0])
+    assert np.array_equal(x3.forward_batch(utts[1], [0, 215])[0], out[1])
+    assert not np.array_equal(x3.forward_batch(utts[0], [0, 400])[0], out[0])
+
+
+@pytest.mark.parametrize("topology", ["v5_cvector", "v3_multitask"])
+def test_other_topologies_auto_mode(topology):
+    P = H.pkg()
+    net, line = H.synth_model(topology)
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    ctx = P.Context(model, precision=P.PREC_AUTO)
+    ev64 = _oracle(net, line, np.float64)
+    lens = [400, 21, 330]
+    utts = [H.features(300 + i, T) for i, T in enumerate(lens)]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    ref = np.stack([ev64.compute(u)[0] for u in utts])
+    for i, T in enumerate(lens):
+        err = H.rel_err(out[i:i + 1], ref[i:i + 1])
+        assert err < TOL_PARITY, (topology, T, err)
+
+
 @pytest.mark.parametrize("prec", [1, 2])
 def test_v2_single_pass_modes(v2, prec):
     P, net, line, model = v2

@@ -18,15 +18,18 @@ def _torch():
     return torch
 
 
-def _split(t, prec, torch):
+F16_MODES = (2, 3, 4)          # fp16, fp16x3, fp16x2
+X_SPLIT = (0, 3)               # modes whose activations carry a residual plane
+W_SPLIT = (0, 3, 4)            # modes whose weights carry one (fp16x2: fp16 activations x split weights)
+
+
+def _split(t, prec, torch, split):
     """fp32 tensor -> (hi, lo) 16-bit planes the way the kernels define them."""
-    if prec == 2:
-        return t.to(torch.float16), None
-    hi = t.to(torch.bfloat16)
-    if prec == 1:
+    dt = torch.float16 if prec in F16_MODES else torch.bfloat16
+    hi = t.to(dt)
+    if not split:
         return hi, None
-    lo = (t - hi.float()).to(torch.bfloat16)
-    return hi, lo
+    return hi, (t - hi.float()).to(dt)
 
 
 def _planes_value(hi, lo):
@@ -43,14 +46,17 @@ def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None):
     src_ld = {}
     for s in segs:
         src_ld[s[0]] = max(src_ld.get(s[0], 0), s[1])
-    X = [torch.randn(rows + 2 * HALO, src_ld[i], generator=g).to(dev) for i in range(nsrc)]
+    # split-fp16 residuals are 2^-12 of the value: operands are scaled up so that they stay fp16 normals (the engine
+    # scales its packed weights the same way, PackModel)
+    amp = 16.0 if prec in (3, 4) else 1.0
+    X = [(torch.randn(rows + 2 * HALO, src_ld[i], generator=g) * amp).to(dev) for i in range(nsrc)]
     K = sum(s[3] for s in segs)
-    W = (torch.randn(n_pad, K, generator=g) / np.sqrt(K)).to(dev)
+    W = (torch.randn(n_pad, K, generator=g) * (amp * amp / np.sqrt(K))).to(dev)
     bias = (torch.randn(n_pad, generator=g) * 0.1).to(dev)
     scale = (torch.rand(n_pad, generator=g) + 0.5).to(dev)
     offset = (torch.randn(n_pad, generator=g) * 0.1).to(dev)
-    Xp = [_split(x, prec, torch) for x in X]
-    Wp = _split(W, prec, torch)
+    Xp = [_split(x, prec, torch, prec in X_SPLIT) for x in X]
+    Wp = _split(W, prec, torch, prec in W_SPLIT)
 
     d = P.GemmDesc()
     d.precision, d.epilogue, d.nseg = prec, epi, len(segs)
@@ -83,12 +89,12 @@ def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None):
 
     torch.cuda.synchronize()
     if epi == P.EPI_ACT:
-        oh = torch.zeros(rows, n_pad, dtype=torch.float16 if prec == 2 else torch.bfloat16, device=dev)
+        oh = torch.zeros(rows, n_pad, dtype=torch.float16 if prec in F16_MODES else torch.bfloat16, device=dev)
         ol = torch.zeros_like(oh)
-        d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), (ol.data_ptr() if prec == 0 else None), n_pad
+        d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), (ol.data_ptr() if prec in X_SPLIT else None), n_pad
         P.kernel_tdnn_gemm(d)
         torch.cuda.synchronize()
-        return _planes_value(oh, ol if prec == 0 else None).double().cpu().numpy(), z.cpu().numpy()
+        return _planes_value(oh, ol if prec in X_SPLIT else None).double().cpu().numpy(), z.cpu().numpy()
     if epi == P.EPI_F32:
         of = torch.full((rows, n_pad), -7.0, dtype=torch.float32, device=dev)
         d.out_f32, d.ldf, d.m_valid = of.data_ptr(), n_pad, rows if m_valid is None else m_valid
@@ -118,11 +124,12 @@ AM5 = [(0, 768, -6, 672), (0, 768, -3, 672), (0, 768, 0, 672)]             # AM 
 
 # tolerance on max|err| / max|ref| : the reference already uses the quantised operands, so what is left is
 # the dropped lo*lo term (split mode, ~2^-16 relative per product) and fp32 accumulation order.
-TOL = {0: 2e-5, 1: 2e-5, 2: 2e-5}
-OUT_Q = {0: 2.0 ** -16, 1: 2.0 ** -8, 2: 2.0 ** -10}   # extra error of re-quantising the OUTPUT planes
+TOL = {0: 2e-5, 1: 2e-5, 2: 2e-5, 3: 2e-5, 4: 2e-5}
+OUT_Q = {0: 2.0 ** -16, 1: 2.0 ** -8, 2: 2.0 ** -10, 3: 2.0 ** -16, 4: 2.0 ** -10}   # re-quantising the OUTPUT planes
+ALL_PREC = [0, 1, 2, 3, 4]
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("prec", ALL_PREC)
 @pytest.mark.parametrize("segs", [TDNN2, TDNN1, CVEC5, AM5], ids=["tdnn2", "tdnn1", "cvec5", "am5"])
 def test_gemm_f32_epilogue(prec, segs):
     out, ref = _run_case(prec, 1, 256, 256, segs, relu=True, bn=True)
@@ -130,7 +137,7 @@ def test_gemm_f32_epilogue(prec, segs):
     assert err < TOL[prec], err
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("prec", ALL_PREC)
 def test_gemm_act_epilogue(prec):
     out, ref = _run_case(prec, 0, 384, 512, TDNN2, relu=True, bn=True, seed=1)
     err = np.abs(out - ref).max() / np.abs(ref).max()
@@ -149,14 +156,14 @@ def test_gemm_m_valid_rows_untouched():
     assert np.all(out[70:] == -7.0)
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("prec", ALL_PREC)
 def test_gemm_stats_epilogue(prec):
     out, ref = _run_case(prec, 2, 256, 1536, [(0, 512, 0, 512)], relu=True, bn=True, seed=4)
     scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
     assert (np.abs(out - ref) / scale).max() < 3e-5
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 3, 4])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_even_tile_count_uses_256_row_variant(prec, epi):
     # 22 row tiles of 128 -> 11 tiles of 256 (not a multiple of 8 either); three K segments with shifts

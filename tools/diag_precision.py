@@ -9,9 +9,9 @@ net, line = H.synth_model("v2_xvector")
 model = P.Model(raw=net.to_bytes(True), nnet_config=line)
 n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True)); n2.apply_nnet_config(line)
 ev32 = H.xo.GraphEvaluator(n2, np.float32); ev64 = H.xo.GraphEvaluator(n2, np.float64)
-for prec in (0, 1, 2):
+for prec in (0, 3, 4, 5, 1, 2):
     ctx = P.Context(model, precision=prec)
-    for T in (400, 57, 15, 16, 25, 137, 1000):
+    for T in (400, 330, 314, 200, 57, 15, 16, 25, 137, 1000):
         x = H.features(T, T)
         out = ctx.forward_batch(x, [0, T])
         r32 = ev32.compute(x); r64 = ev64.compute(x)
