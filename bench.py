@@ -10,11 +10,14 @@ Rank 0 prints ONE JSON line.
   workload BASELINE.json configs[1]: v2 x-vector TDNN, batch = 256 chunks x 400 frames per GPU ("weak" scaling:
            per-GPU work is fixed, utterances are sharded, the only collective is ONE RCCL broadcast of the packed
            weights at start-up - SURVEY.md §8(e))
-  dtype    bf16x3 by default = split-bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate): the mode that meets the
-           1e-4 parity bar.  --precision bf16|fp16 measure the single-pass modes (their error is reported).
+  dtype    "auto" by default: chunks that pool >= 300 frames (the 400-frame workload does) run fp16x2 = fp16
+           activations x split-fp16 weights (hi + lo planes), two fp16 MFMAs per product, fp32 accumulate; shorter
+           chunks run fp16x3 (split activations as well, three MFMAs).  Both meet the 1e-4 parity bar (measured error
+           reported in the line).  --precision bf16|fp16 measure the single-pass modes, which do not.
   roofline dominant kernel = tdnn_gemm_kernel<.., act>; achieved = algorithmic FLOPs per launch / average launch
            duration measured with HIP events on the launch stream inside the timed region; peak = 2.5 PFLOP/s
-           dense bf16 MFMA (MI355X_MICROARCH.md).  Note the split mode executes 3 MFMAs per algorithmic MAC.
+           dense bf16/fp16 MFMA (MI355X_MICROARCH.md).  The split modes execute 2 (fp16x2) or 3 MFMAs per algorithmic
+           MAC ("mfma_per_alg_mac"); "mfma_executed_frac" = frac x that factor is the matrix-pipe rate actually sustained.
   cpu_baseline  the numpy/OpenBLAS fp32 oracle ("port": this repo's restatement of Kaldi's semantics, NOT Kaldi,
            which is neither vendored by the reference nor installed) run the way the recipes run Kaldi on CPU - one
            single-threaded process per host core, an utterance at a time - rank 0, N=1 only, ~12 s.
@@ -61,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x3", choices=sorted(PRECISION_NOTES))
+    ap.add_argument("--precision", default="auto", choices=sorted(PRECISION_NOTES))
     ap.add_argument("--topology", default="v2_xvector")
     ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
     ap.add_argument("--frames", type=int, default=400)
@@ -246,9 +249,9 @@ def main():
             mfma_passes = 2 if pool_frames >= thr and not frame_level and not args.ragged else 3
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
-                    "kernel": "tdnn_gemm_kernel<%s,act>" % args.precision, "launches_per_step": n_act_per_step,
+                    "kernel": "tdnn_gemm_kernel_v2<%s,act>" % ({3: "fp16x3", 2: "fp16x2"}[mfma_passes] if args.precision == "auto" else args.precision), "launches_per_step": n_act_per_step,
                     "avg_launch_ms": avg_launch_ms, "alg_flops_per_launch": flops_per_launch,
-                    "mfma_per_alg_mac": mfma_passes,
+                    "mfma_per_alg_mac": mfma_passes, "mfma_executed_frac": achieved * mfma_passes / PEAK_TFLOPS,
                     "whole_step_alg_tflops": 2.0 * macs * B * args.steps / dt / 1e12 * 1.0,
                     "gemm_ms_per_step": gemm_ms / args.steps, "all_kernels_ms_per_step": total_prof_ms / args.steps}
         # ---- parity spot check against the oracle on the same inputs (not timed) ------------------------------
@@ -265,7 +268,8 @@ def main():
         res = {
             "metric": "utterance-embeddings/sec (400-frame chunks)", "value": value, "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {3: "fp16x3", 2: "fp16x2"}[mfma_passes] if args.precision == "auto" else args.precision,
             "data": "synthetic",
             "config": {"workload": "%s TDNN, %d chunks x %d frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
                                    % (args.topology, B, T), "topology": args.topology, "batch_chunks_per_gpu": B,
@@ -278,7 +282,7 @@ def main():
             "kernels_ms_per_step": {l: ms / max(1, c) for (l, c, ms) in prof},
         }
         if world == 1 and not args.no_extra_modes and PRECISION_NOTES[args.precision] != 1 and not frame_level and not args.ragged:
-            # single-pass modes, reported next to the parity mode with their measured error (never `value`)
+            # the three-pass mode and the single-pass modes, reported with their measured error (never `value`)
             extra = {}
             os.environ["XVEC_LANES"] = "2"
             c3 = P.Context(model, device=local_rank, precision=prec)
@@ -294,7 +298,7 @@ def main():
                                         "kernels overlap the other's); not used for value/roofline"}
             del c3
             os.environ["XVEC_LANES"] = str(args.lanes)
-            for pname in ("bf16", "fp16"):
+            for pname in ("fp16x3", "bf16", "fp16"):
                 c2 = P.Context(model, device=local_rank, precision=P.PRECISIONS[pname])
                 o2 = torch.empty_like(out)
                 prewarm(lambda: c2.forward_batch_device(feats.data_ptr(), offs, o2.data_ptr(), o2.shape[1], stream))
@@ -307,7 +311,7 @@ def main():
                                 "alg_tflops": 2.0 * macs * B * args.steps / d2 / 1e12,
                                 "rel_err_vs_oracle_fp32": H.rel_err(o2[:2].cpu().numpy(), ref)}
                 del c2
-            res["single_pass_modes"] = extra
+            res["other_modes"] = extra
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.topology, int(np.mean(lens)), args.cpu_seconds)
         print(json.dumps(res))

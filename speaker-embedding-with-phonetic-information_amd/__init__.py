@@ -170,7 +170,7 @@ class Model:
         lib().xv_model_describe(self._h, buf, n)
         return buf.value.decode()
 
-    def pack(self, precision=PREC_BF16X3):
+    def pack(self, precision=PREC_AUTO):
         n = ctypes.c_size_t(0)
         _check(lib().xv_model_pack(self._h, precision, None, ctypes.byref(n)))
         buf = ctypes.create_string_buffer(n.value)
@@ -181,7 +181,7 @@ class Model:
 class Context:
     """Weights resident on one MI355X + workspaces.  Raises XvError(XV_ERR_DEVICE) without a gfx950 GPU."""
 
-    def __init__(self, model=None, blob=None, device=0, precision=PREC_BF16X3):
+    def __init__(self, model=None, blob=None, device=0, precision=PREC_AUTO):
         L = lib()
         self._h = ctypes.c_void_p()
         if blob is not None:

@@ -69,8 +69,9 @@ const char* kUsage =
     "  --output-node=<name>             compute this node as the output (native form of nnet3-copy --nnet-config)\n"
     "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
     "  --precision=bf16x3|fp16x3|fp16x2|auto|bf16|fp16\n"
-    "                                   arithmetic of the MFMA GEMMs (default bf16x3: fp32-grade; auto = fp16x2 for\n"
-    "                                   chunks that pool >= 300 frames, fp16x3 for shorter ones)\n"
+    "                                   arithmetic of the MFMA GEMMs (default auto = fp16x2, i.e. fp16 activations x\n"
+    "                                   split-fp16 weights, for chunks that pool >= 300 frames, fp16x3 for shorter\n"
+    "                                   ones and for frame-level outputs; bf16x3 / fp16x3: fp32-grade everywhere)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
@@ -89,7 +90,7 @@ struct Options {
   bool pad_input = true;
   std::string output_node;
   std::string nnet_config;
-  std::string precision = "bf16x3";
+  std::string precision = "auto";
   int batch_frames = 1 << 17;
   int device = -1;
   bool print_args = true;
