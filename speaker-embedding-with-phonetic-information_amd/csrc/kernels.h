@@ -107,6 +107,12 @@ struct GemmArgs {
   // start stagger of the 256x128 variant (set by the launcher): the first stagger_wgs workgroups sleep up to
   // stagger_units x 2048 cycles, see the kernel
   int stagger_wgs, stagger_units;
+  // stream-K variant (set by the launcher): row tiles of the launch, workspace slots of raw accumulators
+  // [workgroup][tile rows x 128], one flag per workgroup, value a flag must hold to count for this launch
+  int sk_mtiles;
+  float* sk_ws;
+  unsigned* sk_flags;
+  unsigned sk_epoch;
 };
 
 // Arms a (start, stop) event pair for the kernels of the NEXT launch_* call of this thread (profiling; see kernels.hip).

@@ -31,6 +31,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace xv {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -446,6 +450,7 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
@@ -662,13 +667,25 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
 }
 
-// Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring.  XVEC_GEMM_VARIANT overrides.
+// Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring, 4 = stream-K (persistent; falls
+// back to 2 / 1 when the launch has too few tiles or an odd shape).  XVEC_GEMM_VARIANT overrides.
 static int gemm_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("XVEC_GEMM_VARIANT");
-    v = (e && *e) ? atoi(e) : 2;
-    if (v != 1 && v != 2) v = 2;
+    v = (e && *e) ? atoi(e) : 4;
+    if (v != 1 && v != 2 && v != 4) v = 4;
+  }
+  return v;
+}
+// Frame fragments per wave of the stream-K variant: 8 (512-row tiles) where the LDS allows, else 4.  XVEC_SK_MF = 4
+// forces the 256-row tiles.
+static int sk_max_mf() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("XVEC_SK_MF");
+    v = (e && *e) ? atoi(e) : 8;
+    if (v != 4 && v != 8) v = 8;
   }
   return v;
 }
@@ -714,6 +731,398 @@ static int device_cu_count() {
   return n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// v4 ("stream-K"): the v2 pipeline run by a persistent grid of one workgroup per CU.
+//
+//  * The K steps of all tiles of a launch (tiles x S) are dealt out evenly: the tiles are cut into 8 contiguous blocks
+//    (one per XCD, whole tiles), and inside a block workgroup j of G/8 takes steps [steps*j/(G/8), steps*(j+1)/(G/8)).
+//    A workgroup's range covers part of a first tile ("head": its last K steps), whole tiles, and part of a last tile
+//    ("tail": its first K steps).  6.25 tiles per CU then cost 6.25 tile times instead of 7 rounds.
+//  * Order inside a workgroup: tail part first - its raw accumulators go to a workspace slot and a flag is
+//    released -, then the whole tiles, then the head part, which starts from the accumulators the previous workgroup
+//    of the block left (its tail part, stored long before) and runs the epilogue.  The accumulation order of every
+//    output element is the plain K order, so results are bit-identical to the unsplit kernels.  A workgroup only ever
+//    waits for a lower-numbered one whose first action is the store it waits for: no deadlock under any dispatch.
+//  * MF = 16-row fragments per wave along the frames: 4 -> 256 x 128 tile as in v2; 8 -> 512 x 128 tile, a wave owns
+//    128 x 64 outputs: 16 fragment reads per 64 MFMA-pairs instead of 12 per 32 (the LOAD segment of v2's ping-pong
+//    schedule, not the MFMA segment, sets the step time once a product costs two MFMAs or one), and the activation
+//    tile of a time-offset group is reused by twice as many MFMAs.  147 KiB of LDS with split weights.
+template <int PREC, int EPI, int MF>
+__global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
+  constexpr bool SPLIT = PrecXPlanes(PREC) == 2;
+  constexpr bool WSPLIT = PrecWPlanes(PREC) == 2;
+  constexpr bool F16 = PrecF16(PREC);
+  constexpr bool SWAP = (EPI != kEpiStats);
+  constexpr int NPX = SPLIT ? 2 : 1, NPW = WSPLIT ? 2 : 1;
+  constexpr int TM = 64 * MF;                  // rows of a workgroup tile (4 waves x MF fragments x 16)
+  constexpr int CH = MF / 2;                   // 16-row activation chunks each wave stages per tile (TM / 16 / 8)
+  constexpr int NH = MF / 4;                   // 64-row halves of a wave's rows (the epilogues work on 64 x 64)
+  constexpr int XT = (TM + 16) * kBK * 2;      // one activation plane slot (tile rows + halo of a time-offset group)
+  constexpr int WT = kTileBytes;
+  constexpr int XSLOT = NPX * XT;
+  constexpr int WSLOT = NPW * WT;
+  constexpr int WBASE = 3 * XSLOT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave & 3;
+  const int wave_n = wave >> 2;
+  const int group = wave >> 2;
+  const int bid = blockIdx.x;
+
+  // ---- this workgroup's share of the K steps ---------------------------------------------------------------------
+  const int S = a.total_ksteps;
+  const int G8 = gridDim.x >> 3;
+  const int xcd = bid & 7, jb = bid >> 3;
+  const int tiles = a.sk_mtiles * a.n_tiles;
+  const int tb0 = (int)((long)tiles * xcd / 8), tb1 = (int)((long)tiles * (xcd + 1) / 8);
+  const long steps_b = (long)(tb1 - tb0) * S;
+  const long s0 = steps_b * jb / G8, s1 = steps_b * (jb + 1) / G8;
+  const int k_head = (int)(s0 % S), k_tail = (int)(s1 % S);
+  const int t_first = (int)((s0 + S - 1) / S), t_end = (int)(s1 / S);   // whole tiles [t_first, t_end) of the block
+  const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
+
+  const int ld_row = lane >> 2;
+  const int ld_chunk = (lane & 3) ^ ((lane >> 3) & 3);
+  const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
+  const int fr_i = lane & 15;
+  const int fr_g = lane >> 4;
+  const int w_rd = (wave_n * 64 + fr_i) * 64 + (fr_g ^ ((fr_i >> 1) & 3)) * 16;
+  int w_rho;
+  {
+    const int rho = wave * 16 + ld_row;
+    w_rho = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
+  }
+
+  // per-part state (set at the top of the part loop)
+  int m0 = 0, n0 = 0;
+  const uint16_t* wrow_hi = nullptr;
+  const uint16_t* wrow_lo = nullptr;
+  int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0;
+  bool force_x = true;
+  Grp gi = a.grp[0];
+  auto issue_step = [&]() -> int {
+    int n = 0;
+    if (ij == 0 || force_x) {
+      force_x = false;
+      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT);
+      const long col = (long)ikk * kBK + ld_chunk * 8;
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int c = wave + 8 * u;
+        const long off = (long)(m0 + gi.shift0 + c * 16 + ld_row) * gi.ld + col;
+        glds16_asm(gi.hi + off, st + c * 1024);
+        if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + c * 1024);
+      }
+      n += CH * NPX;
+      if (wave == 0 && gi.nshift > 1) {  // halo rows TM..TM+15 (only read by displaced offsets)
+        const long off = (long)(m0 + gi.shift0 + TM + ld_row) * gi.ld + col;
+        glds16_asm(gi.hi + off, st + (TM / 16) * 1024);
+        if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + (TM / 16) * 1024);
+        n += NPX;
+      }
+      ixslot = ixslot == 2 ? 0 : ixslot + 1;
+    }
+    {
+      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
+      const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
+      glds16_asm(wrow_hi + wcol, st);
+      if constexpr (WSPLIT) glds16_asm(wrow_lo + wcol, st + WT);
+      n += NPW;
+      iwslot = iwslot == 2 ? 0 : iwslot + 1;
+    }
+    if (++ij == gi.nshift) {
+      ij = 0;
+      if (++ikk == gi.ksteps) {
+        ikk = 0;
+        if (++ig < a.ngrp) gi = a.grp[ig];
+      }
+    }
+    return n;
+  };
+
+  int rg = 0, rkk = 0, rj = 0, rxslot = 0, rwslot = 0;
+  int r_nshift = 1, r_ksteps = 1, r_dstep = 0;
+  struct Frags {
+    s16x8 xh[MF], xl[SPLIT ? MF : 1], wh[4], wl[WSPLIT ? 4 : 1];
+  };
+  auto read_step = [&](Frags& f) {
+    const char* xs = smem + rxslot * XSLOT;
+    const char* ws = smem + WBASE + rwslot * WSLOT;
+    const int row = wave_m * (16 * MF) + fr_i + rj * r_dstep;  // displaced by the time offset of this step
+    const int x_rd = row * 64 + (fr_g ^ ((row >> 1) & 3)) * 16;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+      f.xh[i] = *(const s16x8*)(xs + x_rd + i * 1024);
+      if constexpr (SPLIT) f.xl[i] = *(const s16x8*)(xs + x_rd + XT + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f.wh[i] = *(const s16x8*)(ws + w_rd + i * 1024);
+      if constexpr (WSPLIT) f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
+    }
+    rwslot = rwslot == 2 ? 0 : rwslot + 1;
+    if (++rj == r_nshift) {
+      rj = 0;
+      rxslot = rxslot == 2 ? 0 : rxslot + 1;
+      if (++rkk == r_ksteps) {
+        rkk = 0;
+        if (++rg < a.ngrp) {
+          r_nshift = a.grp[rg].nshift;
+          r_ksteps = a.grp[rg].ksteps;
+          r_dstep = a.grp[rg].dstep;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[NH][4][4];   // [64-row half][p][q] as in the other variants
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if constexpr (SWAP) {
+            if constexpr (WSPLIT) acc[h][p][q] = mfma16<F16>(f.wl[p], f.xh[h * 4 + q], acc[h][p][q]);
+            if constexpr (SPLIT) acc[h][p][q] = mfma16<F16>(f.wh[p], f.xl[h * 4 + q], acc[h][p][q]);
+            acc[h][p][q] = mfma16<F16>(f.wh[p], f.xh[h * 4 + q], acc[h][p][q]);
+          } else {
+            if constexpr (SPLIT) acc[h][p][q] = mfma16<F16>(f.xl[h * 4 + p], f.wh[q], acc[h][p][q]);
+            if constexpr (WSPLIT) acc[h][p][q] = mfma16<F16>(f.xh[h * 4 + p], f.wl[q], acc[h][p][q]);
+            acc[h][p][q] = mfma16<F16>(f.xh[h * 4 + p], f.wh[q], acc[h][p][q]);
+          }
+        }
+      }
+    }
+  };
+  auto wait_and_barrier = [&](int n) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (n == 0) wait_vm_lgkm0_barrier<0>();
+    else if (n == NPW) wait_vm_lgkm0_barrier<NPW>();
+    else if (n == NPW + CH * NPX) wait_vm_lgkm0_barrier<NPW + CH * NPX>();
+    else wait_vm_lgkm0_barrier<NPW + (CH + 1) * NPX>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto plain_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // position of K step k in the (group, chunk, offset) walk
+  auto seek = [&](int k, int& g, int& kk, int& jj) {
+    g = 0;
+    for (;;) {
+      const int n = a.grp[g].ksteps * a.grp[g].nshift;
+      if (k < n || g + 1 >= a.ngrp) break;
+      k -= n;
+      ++g;
+    }
+    const int ns = a.grp[g].nshift;
+    kk = k / ns;
+    jj = k - kk * ns;
+  };
+
+  constexpr long kPartialFloats = (long)TM * kBN;
+  constexpr int kAuxCoherent = 1 | 16;   // sc0 sc1: performed at system scope, no cache keeps a copy
+  // ablation switches of tools/ablate_gemm.sh (timing experiments only, results are garbage): 1 no MFMAs, 2 no fragment
+  // reads, 4 no LDS-DMA, 8 no epilogue
+  const int dbg = a.stagger_units;   // one workspace slot: the raw accumulators of a tile
+#pragma nounroll
+  for (int part = 0; part < n_parts; ++part) {
+    // part order: tail (first K steps of the range's last tile), whole tiles, head (last K steps of its first tile)
+    int tile, kb, ke, kind;   // kind 0: whole tile, 1: tail part (accumulators -> workspace), 2: head part
+    if (k_tail && part == 0) {
+      tile = t_end; kb = 0; ke = k_tail; kind = 1;
+    } else {
+      const int w = part - (k_tail ? 1 : 0);
+      if (w < t_end - t_first) {
+        tile = t_first + w; kb = 0; ke = S; kind = 0;
+      } else {
+        tile = t_first - 1; kb = k_head; ke = S; kind = 2;
+      }
+    }
+    tile += tb0;
+    const int mt = tile / a.n_tiles, nt = tile - mt * a.n_tiles;
+    m0 = mt * TM;
+    n0 = nt * kBN;
+    {
+      const long off = (long)(n0 + w_rho) * a.ldw + ld_chunk * 8;
+      wrow_hi = a.w_hi + off;
+      wrow_lo = WSPLIT ? a.w_lo + off : nullptr;
+    }
+    seek(kb, ig, ikk, ij);
+    gi = a.grp[ig];
+    rg = ig; rkk = ikk; rj = ij;
+    r_nshift = gi.nshift; r_ksteps = gi.ksteps; r_dstep = gi.dstep;
+    ixslot = iwslot = rxslot = rwslot = 0;
+    force_x = true;
+
+    if (kind == 2) {
+      // accumulators the previous workgroup of this block left for this tile (its first action)
+      const int prev = bid - 8;
+      // The workspace is fine-grained (coherent) device memory and is accessed with cache-bypassing 16-byte loads /
+      // stores; the flag is a relaxed agent-scope atomic.  Acquire / release FENCES at agent scope would write back
+      // and invalidate the whole L2 of the XCD once per wave: measured ~70 us per launch.
+      if (tid == 0) {
+        while (__hip_atomic_load(a.sk_flags + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch)
+          __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.sk_ws + (long)prev * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[h][p][q] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent));
+    } else {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[h][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int n_steps = ke - kb;
+    const bool do_dma = !(dbg & 4);
+    if (do_dma) issue_step();
+    const int n1 = (n_steps > 1 && do_dma) ? issue_step() : 0;
+    wait_and_barrier(n1);
+    if (group == 1) plain_barrier();
+    Frags f;
+    if (dbg & 2) read_step(f);
+#pragma nounroll
+    for (int j = 0; j < n_steps; ++j) {
+      if (!(dbg & 2)) read_step(f);
+      const int n = (j + 2 < n_steps && do_dma) ? issue_step() : 0;
+      wait_and_barrier(n);
+      __builtin_amdgcn_s_setprio(1);
+      if (!(dbg & 1)) mfmas(f);
+      __builtin_amdgcn_s_setprio(0);
+      plain_barrier();
+    }
+    if (group == 0) plain_barrier();   // both groups are past their last LDS read: the next part may refill the rings
+
+    if (kind == 1) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.sk_ws + (long)bid * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[h][p][q]), rs, tid * 16,
+                                                   ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent);
+      // every store of this workgroup has been performed (acknowledged at agent scope) before the flag goes out
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), through the builtin so that hipcc's scoreboard knows
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.sk_flags + bid, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (!(dbg & 8)) {
+      EpiRegs er;
+      if constexpr (EPI != kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * (16 * MF), n0 + wave_n * 64, lane, er);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if constexpr (EPI == kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * (16 * MF) + h * 64, n0 + wave_n * 64, lane, er);
+        gemm_epilogue<PREC, EPI>(a, acc[h], m0 + wave_m * (16 * MF) + h * 64, n0 + wave_n * 64, lane, er);
+      }
+    }
+  }
+}
+
+// Workspace of the stream-K variant (one slot of raw accumulators + one flag per workgroup), per stream: launches on
+// different streams may overlap.  The epoch makes flags of earlier launches stale without clearing them.
+struct SkWorkspace {
+  float* ws = nullptr;
+  unsigned* flags = nullptr;
+  size_t ws_bytes = 0;
+  int grid = 0;
+};
+static hipError_t sk_workspace(hipStream_t s, int grid, size_t ws_bytes, SkWorkspace* out, unsigned* epoch) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SkWorkspace> table;
+  static unsigned next_epoch = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  SkWorkspace& w = table[std::make_pair(dev, s)];
+  if (w.ws_bytes < ws_bytes || w.grid < grid) {
+    // (re)allocation: only ever on the first launches of a stream; hipFree synchronises the device
+    if (w.ws) (void)hipFree(w.ws);
+    if (w.flags) (void)hipFree(w.flags);
+    w = SkWorkspace();
+    // fine-grained = coherent across the XCDs' L2s without cache maintenance (the exchange happens inside a kernel)
+    if ((e = hipExtMallocWithFlags((void**)&w.ws, ws_bytes, hipDeviceMallocFinegrained)) != hipSuccess) return e;
+    if ((e = hipExtMallocWithFlags((void**)&w.flags, (size_t)grid * sizeof(unsigned), hipDeviceMallocFinegrained)) != hipSuccess) return e;
+    if ((e = hipMemset(w.flags, 0, (size_t)grid * sizeof(unsigned))) != hipSuccess) return e;
+    w.ws_bytes = ws_bytes;
+    w.grid = grid;
+  }
+  if (++next_epoch == 0) ++next_epoch;   // 0 is the cleared state
+  *epoch = next_epoch;
+  *out = w;
+  return hipSuccess;
+}
+
+// True when the stream-K variant with MF fragments per wave can run this launch.
+template <int PREC, int MF>
+static bool sk_applicable(const GemmArgs& a) {
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
+  if (lds > 160 * 1024) return false;
+  const int rows = a.m_tiles * kBM;
+  if (rows % (64 * MF)) return false;
+  const int grid = device_cu_count() / 8 * 8;
+  if (grid < 8) return false;
+  const long tiles = (long)(rows / (64 * MF)) * a.n_tiles;
+  return tiles / 8 >= grid / 8;   // every workgroup gets at least one tile's worth of K steps
+}
+
+template <int PREC, int EPI, int MF>
+static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
+  if constexpr (lds > 160 * 1024) {
+    return hipErrorInvalidValue;
+  } else {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel_sk<PREC, EPI, MF>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_done = true;
+    }
+    const int grid = device_cu_count() / 8 * 8;
+    GemmArgs b = a;
+    build_groups(&b);
+    b.sk_mtiles = a.m_tiles * kBM / (64 * MF);
+    {
+      static int dbg = -1;
+      if (dbg < 0) {
+        const char* e = getenv("XVEC_SK_ABLATE");
+        dbg = (e && *e) ? atoi(e) : 0;
+      }
+      b.stagger_units = dbg;
+    }
+    SkWorkspace w;
+    hipError_t e = sk_workspace(s, grid, (size_t)grid * 64 * MF * kBN * sizeof(float), &w, &b.sk_epoch);
+    if (e != hipSuccess) return e;
+    b.sk_ws = w.ws;
+    b.sk_flags = w.flags;
+    XV_LAUNCH((tdnn_gemm_kernel_sk<PREC, EPI, MF>), dim3(grid), dim3(512), lds, s, b);
+    return hipGetLastError();
+  }
+}
+
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
@@ -747,7 +1156,11 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
-  if (gemm_variant() == 2 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
+  if (gemm_variant() == 4) {
+    if (sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
+    if (sk_applicable<PREC, 4>(a)) return launch_one_sk<PREC, EPI, 4>(a, s);
+  }
+  if (gemm_variant() >= 2 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
   constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
   static bool attr_done = false;
   if (!attr_done) {

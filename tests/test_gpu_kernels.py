@@ -180,3 +180,17 @@ def test_gemm_many_tiles_xcd_mapping():
     # 21 row tiles (not a multiple of 8) x 3 column tiles: exercises the XCD-aware block -> tile map
     out, ref = _run_case(1, 1, 21 * 128, 384, [(0, 64, -1, 64), (0, 64, 1, 64)], relu=True, bn=False, seed=5)
     assert np.abs(out - ref).max() / np.abs(ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("prec", [1, 3, 4])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_stream_k_variant(prec, epi):
+    # 66 x 512 rows x 4 column tiles = 264 tiles of 512 x 128 (528 of 256 x 128) for 256 workgroups: every workgroup
+    # gets a head part, whole tiles and a tail part; three K segments with time offsets (partial starts inside a group)
+    out, ref = _run_case(prec, epi, 66 * 512, 512, [(0, 64, -3, 64), (0, 64, 0, 64), (0, 64, 3, 64), (1, 32, 1, 32)],
+                         relu=True, bn=True, seed=8)
+    if epi == 2:
+        scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+        assert (np.abs(out - ref) / scale).max() < 3e-5
+    else:
+        assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[prec] + (OUT_Q[prec] if epi == 0 else 0)

@@ -1,0 +1,39 @@
+"""The stream-K GEMM variant (persistent grid, tiles split along K between neighbouring workgroups, 256- or 512-row
+tiles) accumulates every output element in the plain K order, so it must reproduce the per-tile kernels bit for bit.
+The variant is chosen per process (XVEC_GEMM_VARIANT, XVEC_SK_MF), hence the child processes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOOL = os.path.join(H.ROOT, "tools", "forward_dump.py")
+
+
+def _run(tmp_path, tag, env, *args):
+    out = str(tmp_path / (tag + ".npy"))
+    e = dict(os.environ, **env)
+    subprocess.run([sys.executable, TOOL, out] + [str(a) for a in args], check=True, env=e, timeout=600)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("prec,topology,n,T,ragged", [
+    ("fp16x2", "v2_xvector", 256, 400, False),    # BASELINE config 2: 512-row tiles, 3.1 tiles per CU
+    ("fp16x3", "v2_xvector", 256, 400, False),    # three-pass mode: 256-row tiles (LDS)
+    ("auto", "v2_xvector", 200, 400, True),       # two regions, ragged lengths
+    ("fp16x2", "v5_cvector", 160, 400, False),    # two-source Append, AM branch
+    ("bf16", "v2_xvector", 256, 400, False),
+])
+def test_stream_k_is_bit_identical_to_per_tile_kernels(tmp_path, prec, topology, n, T, ragged):
+    args = [topology, prec, n, T] + (["ragged"] if ragged else [])
+    ref = _run(tmp_path, "v2", {"XVEC_GEMM_VARIANT": "2"}, *args)
+    sk8 = _run(tmp_path, "sk8", {"XVEC_GEMM_VARIANT": "4", "XVEC_SK_MF": "8"}, *args)
+    sk4 = _run(tmp_path, "sk4", {"XVEC_GEMM_VARIANT": "4", "XVEC_SK_MF": "4"}, *args)
+    assert np.isfinite(ref).all()
+    assert np.array_equal(ref, sk4)
+    assert np.array_equal(ref, sk8)
