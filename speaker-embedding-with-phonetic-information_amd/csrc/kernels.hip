@@ -441,6 +441,17 @@ __device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_addr) {
       : "memory");
 }
 
+// Same, scalar base + 32-bit per-lane byte offset: the wave-uniform part of the address lives in SGPRs and moves with
+// scalar adds; a lane keeps one offset register for all its DMA instead of a 64-bit pointer per instruction.
+__device__ __forceinline__ void glds16_sbase(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -796,10 +807,18 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     w_rho = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
   }
 
+  // ablation switches (timing experiments only, results are garbage): 1 no MFMAs, 2 no fragment
+  // reads, 4 no LDS-DMA, 8 no epilogue, 16 no activation DMA, 32 no weight DMA
+#ifdef XV_SK_ABLATE
+  const int dbg = a.stagger_units;
+#else
+  constexpr int dbg = 0;
+#endif
   // per-part state (set at the top of the part loop)
   int m0 = 0, n0 = 0;
-  const uint16_t* wrow_hi = nullptr;
-  const uint16_t* wrow_lo = nullptr;
+  const uint16_t* wtile_hi = nullptr;   // weight row n0, wave-uniform
+  const uint16_t* wtile_lo = nullptr;
+  const unsigned woff = (unsigned)(w_rho * a.ldw + ld_chunk * 8) * 2u;   // this lane's row / chunk inside the tile
   int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0;
   bool force_x = true;
   Grp gi = a.grp[0];
@@ -808,19 +827,23 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     if (ij == 0 || force_x) {
       force_x = false;
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT);
-      const long col = (long)ikk * kBK + ld_chunk * 8;
+      // lane part of the address: (ld_row * ld + ld_chunk * 8) elements; everything else is wave-uniform
+      const unsigned xoff = (unsigned)(ld_row * gi.ld + ld_chunk * 8) * 2u;
+      const long ubase = (long)(m0 + gi.shift0) * gi.ld + (long)ikk * kBK;
+      if (!(dbg & 16)) {
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int c = wave + 8 * u;
-        const long off = (long)(m0 + gi.shift0 + c * 16 + ld_row) * gi.ld + col;
-        glds16_asm(gi.hi + off, st + c * 1024);
-        if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + c * 1024);
+        const long off = ubase + (long)(c * 16) * gi.ld;
+        glds16_sbase(gi.hi + off, xoff, st + c * 1024);
+        if constexpr (SPLIT) glds16_sbase(gi.lo + off, xoff, st + XT + c * 1024);
       }
       n += CH * NPX;
+      }
       if (wave == 0 && gi.nshift > 1) {  // halo rows TM..TM+15 (only read by displaced offsets)
-        const long off = (long)(m0 + gi.shift0 + TM + ld_row) * gi.ld + col;
-        glds16_asm(gi.hi + off, st + (TM / 16) * 1024);
-        if constexpr (SPLIT) glds16_asm(gi.lo + off, st + XT + (TM / 16) * 1024);
+        const long off = ubase + (long)TM * gi.ld;
+        glds16_sbase(gi.hi + off, xoff, st + (TM / 16) * 1024);
+        if constexpr (SPLIT) glds16_sbase(gi.lo + off, xoff, st + XT + (TM / 16) * 1024);
         n += NPX;
       }
       ixslot = ixslot == 2 ? 0 : ixslot + 1;
@@ -828,9 +851,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
       const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
-      glds16_asm(wrow_hi + wcol, st);
-      if constexpr (WSPLIT) glds16_asm(wrow_lo + wcol, st + WT);
+      if (!(dbg & 32)) {
+      glds16_sbase(wtile_hi + wcol, woff, st);
+      if constexpr (WSPLIT) glds16_sbase(wtile_lo + wcol, woff, st + WT);
       n += NPW;
+      }
       iwslot = iwslot == 2 ? 0 : iwslot + 1;
     }
     if (++ij == gi.nshift) {
@@ -929,9 +954,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
 
   constexpr long kPartialFloats = (long)TM * kBN;
   constexpr int kAuxCoherent = 1 | 16;   // sc0 sc1: performed at system scope, no cache keeps a copy
-  // ablation switches of tools/ablate_gemm.sh (timing experiments only, results are garbage): 1 no MFMAs, 2 no fragment
-  // reads, 4 no LDS-DMA, 8 no epilogue
-  const int dbg = a.stagger_units;   // one workspace slot: the raw accumulators of a tile
+   // one workspace slot: the raw accumulators of a tile
 #pragma nounroll
   for (int part = 0; part < n_parts; ++part) {
     // part order: tail (first K steps of the range's last tile), whole tiles, head (last K steps of its first tile)
@@ -950,11 +973,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     const int mt = tile / a.n_tiles, nt = tile - mt * a.n_tiles;
     m0 = mt * TM;
     n0 = nt * kBN;
-    {
-      const long off = (long)(n0 + w_rho) * a.ldw + ld_chunk * 8;
-      wrow_hi = a.w_hi + off;
-      wrow_lo = WSPLIT ? a.w_lo + off : nullptr;
-    }
+    wtile_hi = a.w_hi + (long)n0 * a.ldw;
+    wtile_lo = WSPLIT ? a.w_lo + (long)n0 * a.ldw : nullptr;
     seek(kb, ig, ikk, ij);
     gi = a.grp[ig];
     rg = ig; rkk = ikk; rj = ij;
@@ -992,6 +1012,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           for (int q = 0; q < 4; ++q) acc[h][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // Ping-pong schedule of v2 (two barrier intervals per K step; group 1 runs one interval behind group 0).  A
+    // one-barrier-per-step form (group 0: LOAD_j, COMPUTE_j; group 1: COMPUTE_{j-1}, LOAD_j) was measured 6 % slower:
+    // without the second barrier the groups drift into loading at the same time.
     const int n_steps = ke - kb;
     const bool do_dma = !(dbg & 4);
     if (do_dma) issue_step();
@@ -1010,7 +1033,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       __builtin_amdgcn_s_setprio(0);
       plain_barrier();
     }
-    if (group == 0) plain_barrier();   // both groups are past their last LDS read: the next part may refill the rings
+    if (group == 0) plain_barrier();
+    // every wave is past its last LDS read: the next part may refill the rings
 
     if (kind == 1) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
