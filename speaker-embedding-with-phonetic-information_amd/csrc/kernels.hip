@@ -240,15 +240,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         float s1 = 0.f, s2 = 0.f;
+        // all 16 rows of the group pooled (every group but the first / last ones of a chunk): no row mask.  first / last
+        // are the same in every lane, so the branch is wave-uniform; the arithmetic is that of the masked path (the
+        // square is rounded on its own there, hence __fmul_rn here).
+        const bool whole = __builtin_amdgcn_readfirstlane(e.first[p]) == 0 && __builtin_amdgcn_readfirstlane(e.last[p]) == 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float z = acc[p][q][r] + e.bs[q];
           if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
           if (a.bn) z = z * e.sc[q] + e.of[q];
-          const int rr = fr_g * 4 + r;
-          const bool ok = (rr >= e.first[p]) && (rr < e.last[p]);
-          s1 += ok ? z : 0.f;
-          s2 += ok ? z * z : 0.f;
+          if (whole) {
+            s1 += z;
+            s2 += __fmul_rn(z, z);
+          } else {
+            const int rr = fr_g * 4 + r;
+            const bool ok = (rr >= e.first[p]) && (rr < e.last[p]);
+            s1 += ok ? z : 0.f;
+            s2 += ok ? __fmul_rn(z, z) : 0.f;
+          }
         }
         s1 += __shfl_xor(s1, 16);
         s2 += __shfl_xor(s2, 16);
@@ -955,10 +964,14 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   constexpr long kPartialFloats = (long)TM * kBN;
   constexpr int kAuxCoherent = 1 | 16;   // sc0 sc1: performed at system scope, no cache keeps a copy
    // one workspace slot: the raw accumulators of a tile
-#pragma nounroll
-  for (int part = 0; part < n_parts; ++part) {
+  // Sets the issue / read state to the first K step of part `part` and puts the DMA of its first two steps in flight.
+  // Called for part i+1 BEFORE the epilogue of part i, so that the pipeline fill (DMA latency) of a part hides behind the
+  // previous part's epilogue; the first wait of a part therefore drains everything (vmcnt(0): the epilogue's stores were
+  // issued after these DMA instructions and the counter does not tell them apart).
+  int kind = 0, n_steps = 0;   // kind 0: whole tile, 1: tail part (accumulators -> workspace), 2: head part
+  auto open_part = [&](int part) {
     // part order: tail (first K steps of the range's last tile), whole tiles, head (last K steps of its first tile)
-    int tile, kb, ke, kind;   // kind 0: whole tile, 1: tail part (accumulators -> workspace), 2: head part
+    int tile, kb, ke;
     if (k_tail && part == 0) {
       tile = t_end; kb = 0; ke = k_tail; kind = 1;
     } else {
@@ -981,13 +994,22 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     r_nshift = gi.nshift; r_ksteps = gi.ksteps; r_dstep = gi.dstep;
     ixslot = iwslot = rxslot = rwslot = 0;
     force_x = true;
+    n_steps = ke - kb;
+    if (!(dbg & 4)) {
+      issue_step();
+      if (n_steps > 1) issue_step();
+    }
+  };
 
+  open_part(0);
+#pragma nounroll
+  for (int part = 0; part < n_parts; ++part) {
     if (kind == 2) {
-      // accumulators the previous workgroup of this block left for this tile (its first action)
+      // accumulators the previous workgroup of this block left for this tile (its first action).  The workspace is
+      // fine-grained (coherent) device memory accessed with cache-bypassing loads / stores, the flag a relaxed
+      // agent-scope atomic: acquire / release FENCES at agent scope would write back and invalidate the whole L2 of
+      // the XCD once per wave (measured ~70 us per launch).
       const int prev = bid - 8;
-      // The workspace is fine-grained (coherent) device memory and is accessed with cache-bypassing 16-byte loads /
-      // stores; the flag is a relaxed agent-scope atomic.  Acquire / release FENCES at agent scope would write back
-      // and invalidate the whole L2 of the XCD once per wave: measured ~70 us per launch.
       if (tid == 0) {
         while (__hip_atomic_load(a.sk_flags + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch)
           __builtin_amdgcn_s_sleep(8);
@@ -1015,28 +1037,30 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     // Ping-pong schedule of v2 (two barrier intervals per K step; group 1 runs one interval behind group 0).  A
     // one-barrier-per-step form (group 0: LOAD_j, COMPUTE_j; group 1: COMPUTE_{j-1}, LOAD_j) was measured 6 % slower:
     // without the second barrier the groups drift into loading at the same time.
-    const int n_steps = ke - kb;
     const bool do_dma = !(dbg & 4);
-    if (do_dma) issue_step();
-    const int n1 = (n_steps > 1 && do_dma) ? issue_step() : 0;
-    wait_and_barrier(n1);
+    wait_and_barrier(0);               // the first two steps have landed (and the previous epilogue's stores are out)
     if (group == 1) plain_barrier();
     Frags f;
     if (dbg & 2) read_step(f);
+    const int ns = n_steps;
 #pragma nounroll
-    for (int j = 0; j < n_steps; ++j) {
+    for (int j = 0; j < ns; ++j) {
+      if (dbg & 128) __builtin_amdgcn_s_setprio(2);
       if (!(dbg & 2)) read_step(f);
-      const int n = (j + 2 < n_steps && do_dma) ? issue_step() : 0;
+      const int n = (j + 2 < ns && do_dma) ? issue_step() : 0;
       wait_and_barrier(n);
-      __builtin_amdgcn_s_setprio(1);
+      if (dbg & 128) __builtin_amdgcn_s_setprio(0);
+      if (!(dbg & 64)) __builtin_amdgcn_s_setprio(1);
       if (!(dbg & 1)) mfmas(f);
-      __builtin_amdgcn_s_setprio(0);
+      if (!(dbg & 64)) __builtin_amdgcn_s_setprio(0);
       plain_barrier();
     }
     if (group == 0) plain_barrier();
-    // every wave is past its last LDS read: the next part may refill the rings
+    // every wave is past its last LDS read: the rings may be refilled for the next part while this one's results go out
+    const int e_kind = kind, e_m0 = m0, e_n0 = n0;
+    if (part + 1 < n_parts) open_part(part + 1);
 
-    if (kind == 1) {
+    if (e_kind == 1) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(a.sk_ws + (long)bid * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
 #pragma unroll
@@ -1047,18 +1071,35 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[h][p][q]), rs, tid * 16,
                                                    ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent);
-      // every store of this workgroup has been performed (acknowledged at agent scope) before the flag goes out
+      // every store of this workgroup has been performed (acknowledged) before the flag goes out
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), through the builtin so that hipcc's scoreboard knows
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(a.sk_flags + bid, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (!(dbg & 8)) {
       EpiRegs er;
-      if constexpr (EPI != kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * (16 * MF), n0 + wave_n * 64, lane, er);
+      epilogue_prefetch<EPI>(a, e_m0 + wave_m * (16 * MF), e_n0 + wave_n * 64, lane, er);
+      int first2[4], last2[4];   // statistics epilogue: valid-row table of the second 64-row half, fetched with the first
+      if constexpr (EPI == kEpiStats && NH == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int grp = (e_m0 + wave_m * (16 * MF) + 64 + p * 16) >> 4;
+          first2[p] = a.grp_range[2 * grp];
+          last2[p] = a.grp_range[2 * grp + 1];
+        }
+      }
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        if constexpr (EPI == kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * (16 * MF) + h * 64, n0 + wave_n * 64, lane, er);
-        gemm_epilogue<PREC, EPI>(a, acc[h], m0 + wave_m * (16 * MF) + h * 64, n0 + wave_n * 64, lane, er);
+        if constexpr (EPI == kEpiStats && NH == 2) {
+          if (h == 1) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              er.first[p] = first2[p];
+              er.last[p] = last2[p];
+            }
+          }
+        }
+        gemm_epilogue<PREC, EPI>(a, acc[h], e_m0 + wave_m * (16 * MF) + h * 64, e_n0 + wave_n * 64, lane, er);
       }
     }
   }
