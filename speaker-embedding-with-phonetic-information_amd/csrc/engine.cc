@@ -459,7 +459,9 @@ void Engine::FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector
       off += RoundUp(key[b] + pad_left_ + pad_right_, kRowAlign);
       if (off > (1l << 30)) throw EngineError("batch too large (more than 2^30 device rows)");
     }
-    off = RoundUp((int)off, 2 * kBM);  // the 256-row GEMM variant needs an even number of 128-row tiles
+    // the 256-row GEMM variant needs an even number of 128-row tiles; the region of the two-pass kernels is cut into
+    // 512-row tiles by the stream-K variant
+    off = RoundUp((int)off, (pass == 0 && has_fast_) ? 4 * kBM : 2 * kBM);
     if (pass == 0) plan->rows_fast = (int)off;
   }
   plan->rows = (int)off;
