@@ -249,7 +249,8 @@ def main():
             mfma_passes = 2 if pool_frames >= thr and not frame_level and not args.ragged else 3
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
-                    "kernel": "tdnn_gemm_kernel_v2<%s,act>" % ({3: "fp16x3", 2: "fp16x2"}[mfma_passes] if args.precision == "auto" else args.precision), "launches_per_step": n_act_per_step,
+                    "kernel": "tdnn_gemm_kernel_%s<%s,act>" % ("sk" if mfma_passes == 2 and not os.environ.get("XVEC_GEMM_VARIANT") else "v2",
+                                                                 {3: "fp16x3", 2: "fp16x2"}[mfma_passes] if args.precision == "auto" else args.precision), "launches_per_step": n_act_per_step,
                     "avg_launch_ms": avg_launch_ms, "alg_flops_per_launch": flops_per_launch,
                     "mfma_per_alg_mac": mfma_passes, "mfma_executed_frac": achieved * mfma_passes / PEAK_TFLOPS,
                     "whole_step_alg_tflops": 2.0 * macs * B * args.steps / dt / 1e12 * 1.0,

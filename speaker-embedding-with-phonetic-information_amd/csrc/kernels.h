@@ -110,6 +110,7 @@ struct GemmArgs {
   // stream-K variant (set by the launcher): row tiles of the launch, workspace slots of raw accumulators
   // [workgroup][tile rows x 128], one flag per workgroup, value a flag must hold to count for this launch
   int sk_mtiles;
+  int sk_lanes;          // column lanes per workgroup group (divides n_tiles)
   float* sk_ws;
   unsigned* sk_flags;
   unsigned sk_epoch;

@@ -796,13 +796,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const int bid = blockIdx.x;
 
   // ---- this workgroup's share of the K steps ---------------------------------------------------------------------
+  // XCD block `xcd` owns a contiguous range of whole ROW tiles.  Its G/8 workgroups form G/8/L groups of L "column
+  // lanes": lane l walks the column tiles [l*cpl, (l+1)*cpl) of every row tile of the block, and the K steps of that
+  // walk are dealt out evenly over the groups.  The L workgroups of a group therefore sit on the same row tile at the
+  // same time, so its activation rows come out of HBM once and out of the XCD's L2 for the others (a contiguous
+  // range of whole tiles per workgroup had 32 workgroups stream 32 different row tiles through a 4 MB L2: 1.3 GB of
+  // fabric reads per tdnn2 launch against 0.38 GB for the per-tile kernel).
   const int S = a.total_ksteps;
   const int G8 = gridDim.x >> 3;
   const int xcd = bid & 7, jb = bid >> 3;
-  const int tiles = a.sk_mtiles * a.n_tiles;
-  const int tb0 = (int)((long)tiles * xcd / 8), tb1 = (int)((long)tiles * (xcd + 1) / 8);
-  const long steps_b = (long)(tb1 - tb0) * S;
-  const long s0 = steps_b * jb / G8, s1 = steps_b * (jb + 1) / G8;
+  const int L = a.sk_lanes, cpl = a.n_tiles / L, Ng = G8 / L;
+  const int col_lane = jb % L, grp_j = jb / L;
+  const int tb0 = (int)((long)a.sk_mtiles * xcd / 8), tb1 = (int)((long)a.sk_mtiles * (xcd + 1) / 8);   // row tiles
+  const long steps_b = (long)(tb1 - tb0) * cpl * S;
+  const long s0 = steps_b * grp_j / Ng, s1 = steps_b * (grp_j + 1) / Ng;
   const int k_head = (int)(s0 % S), k_tail = (int)(s1 % S);
   const int t_first = (int)((s0 + S - 1) / S), t_end = (int)(s1 / S);   // whole tiles [t_first, t_end) of the block
   const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
@@ -985,8 +992,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
         tile = t_first - 1; kb = k_head; ke = S; kind = 2;
       }
     }
-    tile += tb0;
-    const int mt = tile / a.n_tiles, nt = tile - mt * a.n_tiles;
+    const int mt = tb0 + tile / cpl, nt = col_lane * cpl + tile % cpl;   // tile = index in this lane's walk
     m0 = mt * TM;
     n0 = nt * kBN;
     wtile_hi = a.w_hi + (long)n0 * a.ldw;
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       // fine-grained (coherent) device memory accessed with cache-bypassing loads / stores, the flag a relaxed
       // agent-scope atomic: acquire / release FENCES at agent scope would write back and invalidate the whole L2 of
       // the XCD once per wave (measured ~70 us per launch).
-      const int prev = bid - 8;
+      const int prev = bid - 8 * L;   // same lane, previous group
       if (tid == 0) {
         while (__hip_atomic_load(a.sk_flags + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch)
           __builtin_amdgcn_s_sleep(8);
@@ -1152,8 +1158,8 @@ static bool sk_applicable(const GemmArgs& a) {
   if (rows % (64 * MF)) return false;
   const int grid = device_cu_count() / 8 * 8;
   if (grid < 8) return false;
-  const long tiles = (long)(rows / (64 * MF)) * a.n_tiles;
-  return tiles / 8 >= grid / 8;   // every workgroup gets at least one tile's worth of K steps
+  // every workgroup gets at least one tile's worth of K steps (XCD blocks are whole row tiles)
+  return (long)(rows / (64 * MF) / 8) * a.n_tiles >= grid / 8;
 }
 
 template <int PREC, int EPI, int MF>
@@ -1173,6 +1179,18 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
     GemmArgs b = a;
     build_groups(&b);
     b.sk_mtiles = a.m_tiles * kBM / (64 * MF);
+    {
+      // column lanes: the largest of 4, 2, 1 that divides the column tiles and the workgroups of an XCD block
+      static int max_lanes = -1;
+      if (max_lanes < 0) {
+        const char* e = getenv("XVEC_SK_LANES");
+        max_lanes = (e && *e) ? atoi(e) : 4;
+        if (max_lanes != 1 && max_lanes != 2 && max_lanes != 4) max_lanes = 4;
+      }
+      int l = max_lanes;
+      while (l > 1 && (a.n_tiles % l || (grid / 8) % l)) l >>= 1;
+      b.sk_lanes = l;
+    }
     {
       static int dbg = -1;
       if (dbg < 0) {

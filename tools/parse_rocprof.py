@@ -12,6 +12,7 @@ half of a wide coalesced streaming read, so reads are doubled (checked here on p
 known); WRITE_SIZE matched the known output bytes of every kernel 1:1.
 """
 import csv
+import re
 import json
 import os
 import shutil
@@ -49,12 +50,12 @@ def main():
         for i, ((k, f, us), (_, w, _)) in enumerate(zip(per["FETCH_SIZE"], per["WRITE_SIZE"])):
             b = (2 * f + w) * 1024
             lines.append("| %d | %s | %.1f | %.1f | %.3e | %.1f |" % (i, k, f, w, b, us))
-            if ("tdnn_gemm_kernel" in k) and (", 0>" in k):
+            if re.search(r"tdnn_gemm_kernel\w*<\d+, 0[,>]", k):   # the activation-producing instantiations (EPI = 0)
                 tot_act += b
                 n_act += 1
         open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
         if n_act:
-            json.dump({"hbm_bytes_per_launch": tot_act / n_act, "kernel": "tdnn_gemm_kernel<prec,act>", "launches": n_act,
+            json.dump({"hbm_bytes_per_launch": tot_act / n_act, "kernel": "tdnn_gemm_kernel*<prec,act>", "launches": n_act,
                        "source": tag + "_pmc_hbm.md"}, open(os.path.join(prof, "pmc_traffic.json"), "w"))
     sq = os.path.join(d, "pmc_sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
