@@ -109,6 +109,23 @@ __device__ __forceinline__ int swap_fields(int rho) {
   return ((p >> 1) << 5) | (g << 3) | ((p & 1) << 2) | r;
 }
 
+// Cross-lane adds of the statistics epilogue on the gfx950 lane-swap instructions (plain VALU) instead of
+// ds_bpermute (LDS crossbar, ~100 cycles each, 128 per wave and 512 x 128 tile).  v_permlane16_swap exchanges the odd
+// 16-lane rows of its first operand with the even rows of the second: with both equal to v the operands become
+// [r0 r0 r2 r2] and [r1 r1 r3 r3], whose sum is the xor-16 butterfly (same operands, hence the same bits, as
+// v + shfl_xor(v, 16)); v_permlane32_swap does the same with the 32-lane halves.  (Inline asm: the builtins of this
+// hipcc mis-assign the second result register.)
+__device__ __forceinline__ float sum_rows16(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float sum_halves32(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
 
 // Per-lane epilogue parameters (bias / scale / offset, and for the statistics epilogue the valid-row table), fetched
@@ -144,6 +161,13 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
       }
     }
   } else if constexpr (EPI == kEpiStats) {
+#ifdef XV_SK_ABLATE
+    if (a.stagger_units & 512) {
+      for (int q = 0; q < 4; ++q) { e.bs[q] = 0.1f; e.sc[q] = 1.1f; e.of[q] = 0.2f; }
+      for (int p = 0; p < 4; ++p) { e.first[p] = 0; e.last[p] = 16; }
+      return;
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = nbase + q * 16 + fr_i;
@@ -169,6 +193,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
   constexpr bool F16 = PrecF16(PREC);
   const int fr_i = lane & 15;
   const int fr_g = lane >> 4;
+  // The per-element work is branch-free: no ReLU = a floor of -inf, no BatchNorm = scale 1 / offset 0 (set by
+  // epilogue_prefetch).  With the flags tested per element the statistics epilogue of a 512 x 128 tile was ~3500
+  // instructions per wave, 15 us, and tdnn5 was bound by it rather than by its MFMAs.
+  const float relu_floor = a.relu ? 0.f : -__builtin_inff();
   // ---- epilogues ---------------------------------------------------------------------------
   if constexpr (EPI == kEpiSplitK) {
     // raw accumulators of this K slice (bias / ReLU / BatchNorm are applied by splitk_reduce_kernel)
@@ -192,9 +220,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float z = acc[p][q][r] + e.bs[p * 4 + r];
-          if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
-          if (a.bn) z = z * e.sc[p * 4 + r] + e.of[p * 4 + r];
-          y[p * 4 + r] = z;
+          z = (z < relu_floor) ? relu_floor : z;   // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
+          y[p * 4 + r] = __builtin_fmaf(z, e.sc[p * 4 + r], e.of[p * 4 + r]);   // scale 1 / offset 0 without BatchNorm
         }
       if constexpr (EPI == kEpiF32) {
         if (row < a.m_valid) {
@@ -233,42 +260,58 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     // instructions per q (4 fragments x 16 columns each) instead of eight 16-lane ones - the epilogue is bound by the
     // number of store instructions a CU can issue, not by their bytes.
     const int grp0 = mbase >> 4;
+    float s1v[4][4], s2v[4][4];   // [q][p]
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      // all 16 rows of the group pooled (every group but the first / last ones of a chunk): no row mask.  first / last
+      // are the same in every lane, so the branch is wave-uniform; the arithmetic is that of the masked path (the
+      // square is rounded on its own there, hence __fmul_rn here).
+      const int first = __builtin_amdgcn_readfirstlane(e.first[p]), last = __builtin_amdgcn_readfirstlane(e.last[p]);
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (first == 0 && last == 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float z = acc[p][q][r] + e.bs[q];
+            z = (z < relu_floor) ? relu_floor : z;
+            z = __builtin_fmaf(z, e.sc[q], e.of[q]);
+            s1[q] += z;
+            s2[q] += __fmul_rn(z, z);
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = fr_g * 4 + r;
+          const bool ok = (rr >= first) && (rr < last);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float z = acc[p][q][r] + e.bs[q];
+            z = (z < relu_floor) ? relu_floor : z;
+            z = __builtin_fmaf(z, e.sc[q], e.of[q]);
+            s1[q] += ok ? z : 0.f;
+            s2[q] += ok ? __fmul_rn(z, z) : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s1v[q][p] = sum_halves32(sum_rows16(s1[q]));
+        s2v[q][p] = sum_halves32(sum_rows16(s2[q]));
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = nbase + q * 16 + fr_i;
-      float s1v[4], s2v[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float s1 = 0.f, s2 = 0.f;
-        // all 16 rows of the group pooled (every group but the first / last ones of a chunk): no row mask.  first / last
-        // are the same in every lane, so the branch is wave-uniform; the arithmetic is that of the masked path (the
-        // square is rounded on its own there, hence __fmul_rn here).
-        const bool whole = __builtin_amdgcn_readfirstlane(e.first[p]) == 0 && __builtin_amdgcn_readfirstlane(e.last[p]) == 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + e.bs[q];
-          if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
-          if (a.bn) z = z * e.sc[q] + e.of[q];
-          if (whole) {
-            s1 += z;
-            s2 += __fmul_rn(z, z);
-          } else {
-            const int rr = fr_g * 4 + r;
-            const bool ok = (rr >= e.first[p]) && (rr < e.last[p]);
-            s1 += ok ? z : 0.f;
-            s2 += ok ? __fmul_rn(z, z) : 0.f;
-          }
-        }
-        s1 += __shfl_xor(s1, 16);
-        s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        s1v[p] = s1;
-        s2v[p] = s2;
-      }
-      const float v1 = fr_g == 0 ? s1v[0] : fr_g == 1 ? s1v[1] : fr_g == 2 ? s1v[2] : s1v[3];
-      const float v2 = fr_g == 0 ? s2v[0] : fr_g == 1 ? s2v[1] : fr_g == 2 ? s2v[2] : s2v[3];
+      const float v1 = fr_g == 0 ? s1v[q][0] : fr_g == 1 ? s1v[q][1] : fr_g == 2 ? s1v[q][2] : s1v[q][3];
+      const float v2 = fr_g == 0 ? s2v[q][0] : fr_g == 1 ? s2v[q][1] : fr_g == 2 ? s2v[q][2] : s2v[q][3];
       float* dst = a.partial + (long)(grp0 + fr_g) * 2 * a.ldp + col;
+#ifdef XV_SK_ABLATE
+      if (a.stagger_units & 256) {
+        if (v1 == 12345.678f) dst[0] = v2;
+        continue;
+      }
+#endif
       dst[0] = v1;
       dst[a.ldp] = v2;
     }
@@ -1284,7 +1327,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
   for (int r = 0; r < 4; ++r) {
     float z = v[r] + b[r];
     if (a.relu) z = (z < 0.f) ? 0.f : z;  // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
-    if (a.bn) z = z * a.scale[col + r] + a.offset[col + r];
+    if (a.bn) z = __builtin_fmaf(z, a.scale[col + r], a.offset[col + r]);   // one rounding, like the GEMM epilogues
     y[r] = z;
   }
   if constexpr (EPI == kEpiF32) {
