@@ -33,7 +33,7 @@ typedef enum {
 } xv_status;
 
 typedef enum {
-  XV_PREC_BF16X3 = 0,  /* split-bf16 MFMA (3 products, fp32 accumulate): the <=1e-4 parity mode, default */
+  XV_PREC_BF16X3 = 0,  /* split-bf16 MFMA (3 products, fp32 accumulate): fp32-grade, the first version's parity mode */
   XV_PREC_BF16 = 1,    /* single-pass bf16 MFMA */
   XV_PREC_FP16 = 2,    /* single-pass fp16 MFMA */
   XV_PREC_FP16X3 = 3,  /* split-fp16 MFMA (3 products of 11+11-bit operands, fp32 accumulate) */

@@ -1,7 +1,7 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle (numpy restatement
 of the nnet3 semantics) on the same seeded inputs.  Floating point; tolerance from BASELINE.json north_star:
-embeddings within 1e-4 relative in the fp32-grade (split-bf16) mode.  Single-pass bf16 / fp16 are opt-in
-modes whose measured error is bounded loosely here and reported by bench.py."""
+embeddings within 1e-4 relative in the split-precision modes (bf16x3, fp16x3, fp16x2 for long chunks, auto = the
+default).  Single-pass bf16 / fp16 are opt-in modes whose measured error is bounded loosely here and reported by bench.py."""
 import numpy as np
 import pytest
 
