@@ -19,7 +19,12 @@
 //     read the activation tile displaced by their time offsets; brute-forced over all 16 displacements).  Because
 //     LDS-DMA writes are lane-linear the swizzle is applied to the per-lane *global source* address;
 //   * the splice (Append of time offsets) is a row shift of the activation tile per K segment;
-//   * split-bf16 (hi, lo planes) gives fp32-grade products from three bf16 MFMAs;
+//   * split precision (hi, lo planes): three MFMAs per product give fp32-grade results (bf16x3, fp16x3); fp16
+//     activations x split-fp16 weights (fp16x2, two MFMAs) remove the weight rounding error, which the statistics
+//     pooling cannot average out, and are what long chunks run by default;
+//   * three variants of the same pipeline: tdnn_gemm_kernel (128x128, small / odd launches and split-K slices),
+//     tdnn_gemm_kernel_v2 (256x128, ping-pong wave groups), tdnn_gemm_kernel_sk (persistent stream-K grid, 512x128
+//     tiles, two-pass mode) - bit-identical results, chosen per launch;
 //   * kEpiAct / kEpiF32 feed the weight tile as the MFMA *A* operand, with the weight rows of a
 //     wave permuted at load time, so each lane ends up owning 16 contiguous output columns of
 //     one frame (32-byte stores per plane); kEpiStats feeds activations as A so the 16-row
@@ -31,6 +36,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -756,6 +762,15 @@ static int sk_max_mf() {
   return v;
 }
 
+// The dynamic-LDS attribute of a kernel is per device: one bit per device index, so that a process driving several
+// GPUs (xv_ctx_create_broadcast) sets it on each of them.
+static bool lds_attr_needed(std::atomic<unsigned long long>* done_mask, int* dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  *dev_out = dev;
+  return !((done_mask->load(std::memory_order_acquire) >> (dev & 63)) & 1ull);
+}
+
 // Groups consecutive K segments that read the same source at uniformly spaced time offsets (see the v2 kernel).
 static void build_groups(GemmArgs* g) {
   g->ngrp = 0;
@@ -1211,12 +1226,13 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
   if constexpr (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int attr_dev = 0;
+    if (lds_attr_needed(&attr_done, &attr_dev)) {
       hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel_sk<PREC, EPI, MF>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
-      attr_done = true;
+      attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
     }
     const int grid = device_cu_count() / 8 * 8;
     GemmArgs b = a;
@@ -1255,12 +1271,13 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<unsigned long long> attr_done{0};
+  int attr_dev = 0;
+  if (lds_attr_needed(&attr_done, &attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel_v2<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
   }
   const int mt = a.m_tiles >> 1;
   const int mt8 = (mt + 7) / 8 * 8;
@@ -1292,12 +1309,13 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   if (variant != 1 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
   constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<unsigned long long> attr_done{0};
+  int attr_dev = 0;
+  if (lds_attr_needed(&attr_done, &attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
   }
   const int mt8 = (a.m_tiles + 7) / 8 * 8;
   dim3 grid(mt8 * a.n_tiles), block(256);
@@ -1350,12 +1368,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 template <int PREC, int EPI>
 static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<unsigned long long> attr_done{0};
+  int attr_dev = 0;
+  if (lds_attr_needed(&attr_done, &attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, kEpiSplitK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
   }
   const int mt8 = (a.m_tiles + 7) / 8 * 8;
   dim3 grid(mt8 * a.n_tiles, a.ksplit), block(256);
