@@ -65,6 +65,34 @@ def test_binary_and_text_models_pack_identically():
     assert len(c) < len(a)        # single plane instead of hi+lo
 
 
+def test_split_fp16_modes_share_one_weight_image_scaled_by_a_power_of_two():
+    """fp16x3 / fp16x2 / auto are kernel policies over the same packed weights: fp16 hi + lo planes of W * 2^S, S chosen so
+    that max |w| * 2^S lies in [2^13, 2^14) (the residual plane then holds fp16 normals); the exact inverse sits in the
+    epilogue parameters (bias * 2^S, scale * 2^-S)."""
+    net = H.nm.synthesize(H.tiny_config(), seed=3)
+    m = P.Model(raw=net.to_bytes(True))
+    blobs = [m.pack(p) for p in (P.PREC_FP16X3, P.PREC_FP16X2, P.PREC_AUTO)]
+    assert len(set(len(b) for b in blobs)) == 1
+    # identical up to the precision field of the header
+    diff = [i for i in range(len(blobs[0])) if blobs[0][i] != blobs[2][i]]
+    assert 0 < len(diff) <= 4
+    w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12 x 12
+    scale = 2.0 ** (14 - np.frexp(np.abs(w).max())[1])
+    assert 2 ** 13 <= np.abs(w).max() * scale < 2 ** 14
+    u16 = np.frombuffer(blobs[0], dtype=np.uint16)
+    row_hi = (w[0] * scale).astype(np.float16)
+    first_row = row_hi.view(np.uint16)
+    pos = [i for i in range(len(u16) - 12) if np.array_equal(u16[i:i + 12], first_row)]
+    assert pos, "fp16(hi) image of tdnn4's first scaled weight row not found in the blob"
+    n_pad, k_pad = 128, 32
+    hi = u16[pos[0]:pos[0] + n_pad * k_pad].view(np.float16).reshape(n_pad, k_pad)[:12, :12].astype(np.float64)
+    lo_all = u16[pos[0] + n_pad * k_pad:pos[0] + 2 * n_pad * k_pad].view(np.float16).reshape(n_pad, k_pad)
+    lo = lo_all[:12, :12].astype(np.float64)
+    rec = (hi + lo) / scale
+    assert np.max(np.abs(rec - w) / np.abs(w).max()) < 2.0 ** -20
+    assert np.all(np.abs(lo[lo != 0]) >= 2.0 ** -14) or np.mean(np.abs(lo[lo != 0]) >= 2.0 ** -14) > 0.9   # normals
+
+
 def test_packed_weights_are_the_split_of_the_fp32_weights():
     net = H.nm.synthesize(H.tiny_config(), seed=3)
     blob = P.Model(raw=net.to_bytes(True)).pack(P.PREC_BF16X3)
