@@ -104,6 +104,26 @@ def test_v2_auto_mode_parity_and_batch_invariance(v2):
     assert not np.array_equal(x3.forward_batch(utts[0], [0, 400])[0], out[0])
 
 
+@pytest.mark.parametrize("seed", [123, 7, 2024])
+def test_auto_mode_error_over_models_and_utterances(seed):
+    """The two-pass arithmetic's error comes from rounding activations to fp16 and shrinks with the pooled frames; its
+    size depends on the model and the data.  Three independently drawn synthetic models x 12 utterances at the headline
+    length (T = 400, two-pass) and at the threshold (T = 314): every embedding within the 1e-4 bar, the worst one
+    recorded in the assertion message."""
+    P = H.pkg()
+    net, line = H.synth_model("v2_xvector", seed=seed)
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    ctx = P.Context(model, precision=P.PREC_AUTO)
+    ev64 = _oracle(net, line, np.float64)
+    utts = [H.features(9000 + seed + i, 400 if i % 2 == 0 else 314) for i in range(12)]
+    feats, offs = H.pack(utts)
+    out = ctx.forward_batch(feats, offs)
+    errs = [H.rel_err(out[i:i + 1], ev64.compute(u)) for i, u in enumerate(utts)]
+    assert max(errs) < TOL_PARITY, errs
+    assert max(errs) > 5e-6      # these chunks really ran the two-pass kernels
+    print("seed %d: max %.3e  mean %.3e" % (seed, max(errs), float(np.mean(errs))))
+
+
 @pytest.mark.parametrize("topology", ["v5_cvector", "v3_multitask"])
 def test_other_topologies_auto_mode(topology):
     P = H.pkg()
