@@ -1,0 +1,64 @@
+"""GPU box: soak test of the stream-K exchange (partial tiles handed from workgroup to workgroup through the coherent
+workspace, flags keyed by a per-launch epoch).  Thousands of forward passes over several batch shapes, two engine lanes
+in flight, every result compared bit for bit with the first one of its shape; the same again with a second context on
+the same GPU running concurrently from another thread.  usage: stress_streamk.py [iterations]"""
+import importlib
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+
+P = importlib.import_module("speaker-embedding-with-phonetic-information_amd")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+os.environ["XVEC_LANES"] = "2"
+net, line = H.synth_model("v2_xvector")
+model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+dev = torch.device("cuda:0")
+D = 23
+shapes = [np.full(256, 400), np.full(100, 400), np.random.default_rng(3).integers(200, 700, 180), np.full(331, 400)]
+bad = []
+
+
+def worker(tag):
+    ctx = P.Context(model, device=0)
+    data = []
+    for lens in shapes:
+        rows = int(np.sum(lens))
+        g = torch.Generator(device=dev).manual_seed(rows)
+        f = torch.randn(rows, D, generator=g, device=dev) * (8.0 * 0.9 ** torch.arange(D, device=dev))
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        outs = [torch.empty(len(lens), 512, device=dev) for _ in range(3)]
+        data.append((f, offs, outs, None))
+    refs = [None] * len(shapes)
+    for it in range(N):
+        k = it % len(shapes)
+        f, offs, outs, _ = data[k]
+        o = outs[(it // len(shapes)) % 3]
+        ctx.forward_batch_device(f.data_ptr(), offs, o.data_ptr(), 512, None)
+        if it % 7 == 0 or it < 2 * len(shapes):
+            torch.cuda.synchronize()
+            r = o.cpu().numpy().copy()
+            if refs[k] is None:
+                refs[k] = r
+                assert np.isfinite(r).all()
+            elif not np.array_equal(refs[k], r):
+                bad.append((tag, it, k, float(np.abs(refs[k] - r).max())))
+    torch.cuda.synchronize()
+
+
+worker("solo")
+print("solo: %d iterations, mismatches: %d" % (N, len(bad)))
+ts = [threading.Thread(target=worker, args=("t%d" % i,)) for i in range(2)]
+for t in ts:
+    t.start()
+for t in ts:
+    t.join()
+print("two contexts concurrently: mismatches in total: %d %s" % (len(bad), bad[:5]))
+sys.exit(1 if bad else 0)
