@@ -151,7 +151,7 @@ class Model:
             _check(L.xv_model_load_rxfilename(rxfilename.encode(), cfg, node, ctypes.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and lib is not None:   # lib is None while the interpreter shuts down
             lib().xv_model_free(self._h)
             self._h = ctypes.c_void_p()
 
@@ -195,7 +195,7 @@ class Context:
         self.info, self.precision, self.device = mi, p.value, d.value
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and lib is not None:
             lib().xv_ctx_free(self._h)
             self._h = ctypes.c_void_p()
 
