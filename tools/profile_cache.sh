@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box: L2 (TCC) and L1 / texture-addresser (TCP, TA) counters of one bench step, two separate --pmc passes, no tracing.
+# Output under gpurun_out/prof2/; summarised into profiles/<tag>_pmc_cache.md.
 R=$GRAFT_REPO_ROOT; P=$R/gpurun_out/prof2; rm -rf $P; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --no-cpu-baseline --no-extra-modes --steps 3 --warmup 1"
