@@ -72,6 +72,8 @@ const char* kUsage =
     "                                   arithmetic of the MFMA GEMMs (default auto = fp16x2, i.e. fp16 activations x\n"
     "                                   split-fp16 weights, for chunks that pool >= 300 frames, fp16x3 for shorter\n"
     "                                   ones and for frame-level outputs; bf16x3 / fp16x3: fp32-grade everywhere)\n"
+    "  --fast-min-pooled=<int>          --precision=auto: chunks that pool at least this many frames take the two-pass\n"
+    "                                   kernels (default 300, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
@@ -92,6 +94,7 @@ struct Options {
   std::string nnet_config;
   std::string precision = "auto";
   int batch_frames = 1 << 17;
+  int fast_min_pooled = -1;
   int device = -1;
   bool print_args = true;
   int cmn_window = 0;
@@ -161,6 +164,7 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   } else if (name == "chunk-size") return need_int(&o->chunk_size);
   else if (name == "min-chunk-size") return need_int(&o->min_chunk_size);
   else if (name == "batch-frames") return need_int(&o->batch_frames);
+  else if (name == "fast-min-pooled") return need_int(&o->fast_min_pooled);
   else if (name == "device") return need_int(&o->device);
   else if (name == "cmn-window") return need_int(&o->cmn_window);
   else if (name == "vad-rspecifier") o->vad_rspecifier = value;
@@ -314,6 +318,7 @@ int main(int argc, char** argv) {
       device = job > 0 ? (job - 1) % ndev : 0;
     }
     if (device >= ndev) device %= ndev;
+    if (opt.fast_min_pooled >= 0) setenv("XVEC_FAST_MIN_POOLED", std::to_string(opt.fast_min_pooled).c_str(), 1);   // read by the engine
     std::vector<uint8_t> blob = xv::PackModel(prog, precision);
     xv::Engine engine(blob.data(), blob.size(), device);
     XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
