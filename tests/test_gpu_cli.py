@@ -173,3 +173,35 @@ def test_cli_profile_json(job):
     assert names[0] == "prep_input" and "tdnn_gemm<stats>:tdnn5.batchnorm" in names and "tdnn_gemm<f32>:tdnn6.affine" in names
     assert all(k["launches"] == p["kernels"][0]["launches"] >= 3 and k["total_ms"] > 0 for k in p["kernels"])
     assert p["utterances"] == 7 and p["failed"] == 1 and p["frames"] > 0 and p["seconds"] > 0
+
+
+def test_cli_precision_modes(job):
+    """--precision: auto (default) = two-pass kernels for the chunks that pool >= 300 frames, fp16x3 for the others;
+    --fast-min-pooled moves the threshold; every mode within the parity tolerance, and the switch really switches."""
+    d, utts, ev = job
+    n2 = ev.net
+    ev64 = H.xo.GraphEvaluator(n2, np.float64)
+    res = {}
+    for tag, extra in (("auto", []), ("fp16x3", ["--precision=fp16x3"]), ("bf16x3", ["--precision=bf16x3"]),
+                       ("auto_all_slow", ["--fast-min-pooled=100000"]), ("auto_low", ["--fast-min-pooled=100"])):
+        ark = d / ("xp_%s.ark" % tag)
+        r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--chunk-size=10000",
+                  "--output-node=tdnn6.affine"] + extra + [str(d / "final.raw"), "ark:%s/feats.ark" % d, "ark:%s" % ark])
+        assert r.returncode == 0, r.stderr.decode()
+        res[tag] = dict(kio.read_ark(str(ark), "vector"))
+    for k, x in utts:
+        ref = H.xo.extract_xvector(ev64, x, 10000, 25, True)
+        if ref is None:
+            continue
+        for tag in ("auto", "fp16x3", "bf16x3"):
+            assert H.rel_err(res[tag][k][None], ref[None]) < TOL, (tag, k)
+    long_k = [k for k, x in utts if x.shape[0] >= 330]          # 400, 1000, 333 frames: two-pass in auto
+    short_k = [k for k, x in utts if 25 <= x.shape[0] < 300]    # 137, 25 frames: three-pass in auto
+    assert long_k and short_k
+    for k in long_k:
+        assert not np.array_equal(res["auto"][k], res["fp16x3"][k])
+        assert np.array_equal(res["auto_all_slow"][k], res["fp16x3"][k])
+    for k in short_k:
+        assert np.array_equal(res["auto"][k], res["fp16x3"][k])
+    k137 = [k for k, x in utts if x.shape[0] == 137][0]
+    assert not np.array_equal(res["auto_low"][k137], res["fp16x3"][k137])     # 123 pooled frames >= 100: two-pass now
