@@ -737,10 +737,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
 }
 
 // Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring, 4 = stream-K (persistent; falls
-// back to 2 / 1 when the launch has too few tiles or an odd shape), 0 = by precision (default): stream-K for the
-// two-pass mode, where its 512-row tiles fit the LDS and pay (+12 % on the 256 x 400 workload, +14 % on the c-vector
-// net), variant 2 for the others (measured: three-pass -3 % with stream-K's 256-row tiles, single-pass fp16 with the
-// fp32 frame-level epilogue -7 %).  XVEC_GEMM_VARIANT overrides.
+// back to 2 / 1 when the launch has too few tiles or an odd shape), 0 = by precision and K length (default, see
+// launch_one).  XVEC_GEMM_VARIANT overrides.
 static int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -1303,9 +1301,13 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   const int variant = gemm_variant();
-  if (variant == 4 || (variant == 0 && PREC == kPrecFp16x2)) {
+  // default policy (same box, 256 x 400 workload): two-pass mode - stream-K for every layer; three-pass and single-pass
+  // modes - stream-K only for the long-K layers (tdnn2 / tdnn3, 48 K steps: -5 % / -9 %), the short-K ones are faster
+  // on the per-tile kernel there (tdnn5 single-pass: 0.190 vs 0.229 ms)
+  const bool sk_default = PREC == kPrecFp16x2 || a.total_ksteps >= 32;
+  if (variant == 4 || (variant == 0 && sk_default)) {
     if (sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
-    if (variant == 4 && sk_applicable<PREC, 4>(a)) return launch_one_sk<PREC, EPI, 4>(a, s);
+    if ((variant == 4 || PrecXPlanes(PREC) == 2) && sk_applicable<PREC, 4>(a)) return launch_one_sk<PREC, EPI, 4>(a, s);
   }
   if (variant != 1 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
   constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
