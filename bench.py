@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # precision mode -> MFMAs executed per algorithmic product in the frame-level GEMMs
-PRECISION_NOTES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "auto": None, "bf16": 1, "fp16": 1}
+PRECISION_NOTES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "auto": None, "bf16": 1, "fp16": 1}
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
@@ -246,11 +246,11 @@ def main():
         mfma_passes = PRECISION_NOTES[args.precision]
         if mfma_passes is None:   # auto: two-pass kernels for chunks that pool >= the engine's threshold, else three
             thr = int(os.environ.get("XVEC_FAST_MIN_POOLED", "300"))
-            mfma_passes = 2 if pool_frames >= thr and not frame_level and not args.ragged else 3
+            mfma_passes = 1.25 if pool_frames >= thr and not frame_level and not args.ragged else 3
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
-                    "kernel": "tdnn_gemm_kernel_%s<%s,act>" % ("sk" if mfma_passes == 2 and not os.environ.get("XVEC_GEMM_VARIANT") else "v2",
-                                                                 {3: "fp16x3", 2: "fp16x2"}[mfma_passes] if args.precision == "auto" else args.precision), "launches_per_step": n_act_per_step,
+                    "kernel": "tdnn_gemm_kernel_%s<%s,act>" % ("sk" if mfma_passes < 3 and not os.environ.get("XVEC_GEMM_VARIANT") else "v2",
+                                                                 {3: "fp16x3", 1.25: "fp16mx"}[mfma_passes] if args.precision == "auto" else args.precision), "launches_per_step": n_act_per_step,
                     "avg_launch_ms": avg_launch_ms, "alg_flops_per_launch": flops_per_launch,
                     "mfma_per_alg_mac": mfma_passes, "mfma_executed_frac": achieved * mfma_passes / PEAK_TFLOPS,
                     "whole_step_alg_tflops": 2.0 * macs * B * args.steps / dt / 1e12 * 1.0,
@@ -270,7 +270,7 @@ def main():
             "metric": "utterance-embeddings/sec (400-frame chunks)", "value": value, "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {3: "fp16x3", 2: "fp16x2"}[mfma_passes] if args.precision == "auto" else args.precision,
+            "dtype": {3: "fp16x3", 1.25: "fp16mx"}[mfma_passes] if args.precision == "auto" else args.precision,
             "data": "synthetic",
             "config": {"workload": "%s TDNN, %d chunks x %d frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
                                    % (args.topology, B, T), "topology": args.topology, "batch_chunks_per_gpu": B,

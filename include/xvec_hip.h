@@ -41,8 +41,12 @@ typedef enum {
                           is coherent over the frames of a chunk; the activation rounding error averages out in the
                           statistics pooling.  Layers after the pooling run XV_PREC_FP16X3.  Not for frame-level
                           outputs (they run XV_PREC_FP16X3) */
-  XV_PREC_AUTO = 5     /* XV_PREC_FP16X2 for chunks that pool >= 300 frames (XVEC_FAST_MIN_POOLED), XV_PREC_FP16X3 for
+  XV_PREC_AUTO = 5,    /* XV_PREC_FP16MX for chunks that pool >= 300 frames (XVEC_FAST_MIN_POOLED), XV_PREC_FP16X3 for
                           shorter ones; the choice depends on the chunk's own length only */
+  XV_PREC_FP16MX = 6   /* XV_PREC_FP16X2 with the second product (activations x weight residual) done on block-scaled
+                          4-bit operands at four times the fp16 MFMA rate (v_mfma_scale_f32_16x16x128_f8f6f4): 1.25
+                          passes per product.  The residual term is 2^-11 of the product and only has to be good to
+                          ~4 bits.  Layers whose K length is not a multiple of 128 run XV_PREC_FP16X2 */
 } xv_precision;
 
 typedef struct xv_model xv_model; /* host side: parsed nnet3 model lowered to a TDNN program */
@@ -89,6 +93,9 @@ xv_status xv_model_pack(const xv_model* m, int precision, void* blob, size_t* nb
 /* ---- device context ---------------------------------------------------------------------------- */
 xv_status xv_ctx_create(const xv_model* m, int device, int precision, xv_ctx** out);
 xv_status xv_ctx_create_from_blob(const void* blob, size_t nbytes, int device, xv_ctx** out);
+/* Same, the packed image being DEVICE memory on `device` (what a rank holds after the RCCL broadcast of the weights,
+ * SURVEY.md section 8(e)): the weights go device to device, only the header and layer table are read back. */
+xv_status xv_ctx_create_from_device_blob(const void* blob_dev, size_t nbytes, int device, xv_ctx** out);
 void xv_ctx_free(xv_ctx* c);
 xv_status xv_ctx_info(const xv_ctx* c, xv_model_info_t* info, int32_t* precision, int32_t* device);
 
@@ -151,7 +158,8 @@ xv_status xv_plan_chunks(int32_t num_rows, int32_t chunk_size, int32_t min_chunk
 
 /* ---- multi-GPU: weights read once, broadcast over RCCL/xGMI --------------------------
  * Single-process form: creates one context per device in devices[0..n) from the model, reading/packing once
- * on the host, uploading to devices[0] and broadcasting device-to-device with one ncclBroadcast. */
+ * on the host, uploading to devices[0] and broadcasting device-to-device with one ncclBroadcast (n == 1 included:
+ * a one-rank communicator; every context is built from the bytes its device received, without a host round trip). */
 xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, int precision, xv_ctx** out);
 
 /* ---- speaker-level back-end ----------------------------------------------
@@ -178,6 +186,7 @@ typedef struct {
   int32_t ld;       /* leading dimension in elements */
   int32_t row_shift;
   int32_t k_len;    /* multiple of 32 */
+  const void* gmax; /* XV_PREC_FP16MX: device uint32 [rows/16], float bits of max |x| per 16-row group of this plane */
 } xv_seg_desc;
 typedef struct {
   int32_t precision, epilogue; /* epilogue: 0 planes out, 1 fp32 out, 2 per-16-row (sum, sumsq) partials */
@@ -192,7 +201,18 @@ typedef struct {
   float* out_f32; int32_t ldf; int32_t m_valid;
   float* partial; int32_t ldp; const int8_t* grp_range;
   void* hip_stream;
+  /* XV_PREC_FP16MX: e2m1 residual plane [n_pad][ldw4 bytes] in K-walk order + one E8M0 scale per row (see kernels.h);
+   * gmax_out (epilogue 0, any precision): device uint32 [rows/16], receives the group maxima of the output plane */
+  const void* w4; int32_t ldw4; const void* w4_scale;
+  void* gmax_out;
 } xv_gemm_desc;
+/* Host helper for the test above: packs the e2m1 residual plane of one weight matrix exactly like xv_model_pack does
+ * (w, w_hi_f16: [n_pad][k_len] row-major, k_len = sum of the segments' k_len; seg_src[j] equal = same source plane).
+ * w4 receives n_pad * (k_len / 128 * 64) bytes, w4_scale n_pad bytes.  XV_ERR_ARG when the walk has a group that is
+ * not a multiple of four steps. */
+xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg,
+                              const int32_t* seg_src, const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4,
+                              uint8_t* w4_scale);
 xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d);
 
 #ifdef __cplusplus

@@ -12,15 +12,17 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libxvec_hip.so")
+# XVEC_LIB: an alternative build of the same library (kernel experiments: tools/ab_libs.sh); never set in production
+LIB_PATH = os.environ.get("XVEC_LIB") or os.path.join(_HERE, "libxvec_hip.so")
 BIN_DIR = os.path.join(_HERE, "bin")
 
 XV_OK = 0
 XV_ERR_IO, XV_ERR_MODEL, XV_ERR_DEVICE, XV_ERR_ARG, XV_ERR_INTERNAL = 1, 2, 3, 4, 5
-PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO = 0, 1, 2, 3, 4, 5
+PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO, PREC_FP16MX = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3,
-              "fp16x2": PREC_FP16X2, "auto": PREC_AUTO}
-MFMA_PASSES = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp16x3": 3, "fp16x2": 2}   # MFMAs per algorithmic product
+              "fp16x2": PREC_FP16X2, "auto": PREC_AUTO, "fp16mx": PREC_FP16MX}
+# MFMA issue time per algorithmic product in units of one fp16 16x16x32 pass (fp16mx: + one 4-bit 16x16x128 per four)
+MFMA_PASSES = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25}
 EPI_ACT, EPI_F32, EPI_STATS = 0, 1, 2
 
 
@@ -37,7 +39,7 @@ class ModelInfo(ctypes.Structure):
 
 class SegDesc(ctypes.Structure):
     _fields_ = [("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p), ("ld", ctypes.c_int32),
-                ("row_shift", ctypes.c_int32), ("k_len", ctypes.c_int32)]
+                ("row_shift", ctypes.c_int32), ("k_len", ctypes.c_int32), ("gmax", ctypes.c_void_p)]
 
 
 class GemmDesc(ctypes.Structure):
@@ -50,17 +52,20 @@ class GemmDesc(ctypes.Structure):
                 ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("ldo", ctypes.c_int32),
                 ("out_f32", ctypes.c_void_p), ("ldf", ctypes.c_int32), ("m_valid", ctypes.c_int32),
                 ("partial", ctypes.c_void_p), ("ldp", ctypes.c_int32), ("grp_range", ctypes.c_void_p),
-                ("hip_stream", ctypes.c_void_p)]
+                ("hip_stream", ctypes.c_void_p),
+                ("w4", ctypes.c_void_p), ("ldw4", ctypes.c_int32), ("w4_scale", ctypes.c_void_p),
+                ("gmax_out", ctypes.c_void_p)]
 
 
 # every symbol include/xvec_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [
     "xv_last_error", "xv_version", "xv_model_load", "xv_model_load_rxfilename", "xv_model_free", "xv_model_info",
-    "xv_model_macs", "xv_model_describe", "xv_model_pack", "xv_ctx_create", "xv_ctx_create_from_blob", "xv_ctx_free",
+    "xv_model_macs", "xv_model_describe", "xv_model_pack", "xv_ctx_create", "xv_ctx_create_from_blob",
+    "xv_ctx_create_from_device_blob", "xv_ctx_free",
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
-    "xv_backend_apply", "xv_segment_mean",
+    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual",
 ]
 
 _lib = None
@@ -111,6 +116,10 @@ def lib():
     L.xv_ctx_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     L.xv_ctx_create_from_blob.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_ctx_create_from_device_blob.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                                 ctypes.POINTER(ctypes.c_void_p)]
+    L.xv_pack_mx_residual.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.xv_ctx_free.argtypes = [ctypes.c_void_p]
     L.xv_ctx_free.restype = None
     L.xv_ctx_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo), ctypes.POINTER(ctypes.c_int32),
@@ -181,10 +190,15 @@ class Model:
 class Context:
     """Weights resident on one MI355X + workspaces.  Raises XvError(XV_ERR_DEVICE) without a gfx950 GPU."""
 
-    def __init__(self, model=None, blob=None, device=0, precision=PREC_AUTO):
+    def __init__(self, model=None, blob=None, device=0, precision=PREC_AUTO, device_blob=None):
+        """device_blob = (device pointer as int, nbytes): the packed image already in this GPU's memory (e.g. the
+        buffer a RCCL broadcast filled); the weights then never visit the host."""
         L = lib()
         self._h = ctypes.c_void_p()
-        if blob is not None:
+        if device_blob is not None:
+            _check(L.xv_ctx_create_from_device_blob(ctypes.c_void_p(int(device_blob[0])), int(device_blob[1]), device,
+                                                    ctypes.byref(self._h)))
+        elif blob is not None:
             self._blob = ctypes.create_string_buffer(bytes(blob), len(blob))
             _check(L.xv_ctx_create_from_blob(self._blob, len(blob), device, ctypes.byref(self._h)))
         else:
@@ -337,3 +351,21 @@ def segment_mean(x, segments, acc64=False, device=0):
 
 def kernel_tdnn_gemm(desc):
     _check(lib().xv_kernel_tdnn_gemm(ctypes.byref(desc)))
+
+
+def pack_mx_residual(w, w_hi_f16, segs):
+    """e2m1 residual plane + per-row E8M0 scales of XV_PREC_FP16MX for one weight matrix (host; no GPU).
+    w: float32 [n_pad, K]; w_hi_f16: uint16 [n_pad, K] (fp16 bit patterns); segs: [(source id, row shift, k_len)]."""
+    import numpy as np
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    hi = np.ascontiguousarray(w_hi_f16, dtype=np.uint16)
+    n_pad, K = w.shape
+    src = np.array([s[0] for s in segs], dtype=np.int32)
+    shift = np.array([s[1] for s in segs], dtype=np.int32)
+    klen = np.array([s[2] for s in segs], dtype=np.int32)
+    assert int(klen.sum()) == K and K % 128 == 0
+    w4 = np.zeros((n_pad, K // 128 * 64), dtype=np.uint8)
+    sc = np.zeros(n_pad, dtype=np.uint8)
+    _check(lib().xv_pack_mx_residual(w.ctypes.data, hi.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data,
+                                     klen.ctypes.data, w4.ctypes.data, sc.ctypes.data))
+    return w4, sc

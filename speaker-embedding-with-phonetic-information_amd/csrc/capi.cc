@@ -79,7 +79,7 @@ xv_status LoadCommon(xv::RawNnet& net, const char* nnet_config, const char* outp
 extern "C" {
 
 const char* xv_last_error(void) { return g_err.c_str(); }
-const char* xv_version(void) { return "xvec_hip 0.1 (gfx950)"; }
+const char* xv_version(void) { return "xvec_hip 0.2 (gfx950)"; }
 
 xv_status xv_model_load(const void* raw, size_t n, const char* nnet_config, const char* output_node, xv_model** out) {
   if (!raw || !out) return Fail(XV_ERR_ARG, "xv_model_load: null argument");
@@ -157,6 +157,19 @@ xv_status xv_ctx_create_from_blob(const void* blob, size_t nbytes, int device, x
   return Guard([&] {
     std::unique_ptr<xv_ctx> c(new xv_ctx);
     c->eng.reset(new xv::Engine((const uint8_t*)blob, nbytes, device));
+    *out = c.release();
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_create_from_device_blob(const void* blob_dev, size_t nbytes, int device, xv_ctx** out) {
+  if (!blob_dev || !out) return Fail(XV_ERR_ARG, "xv_ctx_create_from_device_blob: null argument");
+  return Guard([&] {
+    if (hipSetDevice(device) != hipSuccess) return Fail(XV_ERR_DEVICE, "xv_ctx_create_from_device_blob: bad device");
+    // header + layer table come back to the host (a few KB); the weights stay on the device
+    std::vector<uint8_t> head = xv::ReadBlobHead(blob_dev, nbytes);
+    std::unique_ptr<xv_ctx> c(new xv_ctx);
+    c->eng.reset(new xv::Engine(head.data(), nbytes, device, blob_dev));
     *out = c.release();
     return XV_OK;
   });
@@ -343,12 +356,6 @@ xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, 
   if (!m || !devices || !out || n < 1) return Fail(XV_ERR_ARG, "xv_ctx_create_broadcast: bad argument");
   return Guard([&]() -> xv_status {
     std::vector<uint8_t> blob = xv::PackModel(m->prog, precision);
-    if (n == 1) {
-      std::unique_ptr<xv_ctx> c(new xv_ctx);
-      c->eng.reset(new xv::Engine(blob.data(), blob.size(), devices[0]));
-      out[0] = c.release();
-      return XV_OK;
-    }
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!lib) return Fail(XV_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
@@ -388,14 +395,23 @@ xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, 
       }
       gend();
     }
-    std::vector<std::vector<uint8_t>> host(n);
+    // every rank builds its context from the bytes *its device received* (device to device), so a bad broadcast
+    // cannot go unnoticed: header and layer table are read back from that copy and validated like any blob
+    std::vector<std::unique_ptr<xv_ctx>> ctxs;
     for (int i = 0; i < n && rc == XV_OK; ++i) {
       (void)hipSetDevice(devices[i]);
-      (void)hipStreamSynchronize(st[i]);
-      // every rank builds its context from the bytes *it received*, so a bad broadcast cannot go unnoticed
-      host[i].resize(blob.size());
-      if (hipMemcpy(host[i].data(), dbuf[i], blob.size(), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = Fail(XV_ERR_DEVICE, "readback of the broadcast blob failed");
+      if (hipStreamSynchronize(st[i]) != hipSuccess) {
+        rc = Fail(XV_ERR_DEVICE, "the weight broadcast did not complete");
+        break;
+      }
+      try {
+        std::vector<uint8_t> head = xv::ReadBlobHead(dbuf[i], blob.size());
+        std::unique_ptr<xv_ctx> c(new xv_ctx);
+        c->eng.reset(new xv::Engine(head.data(), blob.size(), devices[i], dbuf[i]));
+        ctxs.push_back(std::move(c));
+      } catch (const std::exception& e) {
+        rc = Fail(XV_ERR_DEVICE, std::string("context from the broadcast image: ") + e.what());
+      }
     }
     for (int i = 0; i < n; ++i) {
       (void)hipSetDevice(devices[i]);
@@ -404,12 +420,6 @@ xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, 
       if (comms[i]) cdestroy(comms[i]);
     }
     if (rc != XV_OK) return rc;
-    std::vector<std::unique_ptr<xv_ctx>> ctxs;
-    for (int i = 0; i < n; ++i) {
-      std::unique_ptr<xv_ctx> c(new xv_ctx);
-      c->eng.reset(new xv::Engine(host[i].data(), host[i].size(), devices[i]));
-      ctxs.push_back(std::move(c));
-    }
     for (int i = 0; i < n; ++i) out[i] = ctxs[i].release();
     return XV_OK;
   });
@@ -430,6 +440,7 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
       a.seg[j].ld = d->seg[j].ld;
       a.seg[j].row_shift = d->seg[j].row_shift;
       a.seg[j].ksteps = d->seg[j].k_len / xv::kBK;
+      a.seg[j].gmax = (const unsigned*)d->seg[j].gmax;
       a.total_ksteps += a.seg[j].ksteps;
     }
     a.w_hi = (const uint16_t*)d->w_hi;
@@ -451,8 +462,45 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
     a.partial = d->partial;
     a.ldp = d->ldp;
     a.grp_range = d->grp_range;
+    a.w4 = (const uint8_t*)d->w4;
+    a.ldw4 = d->ldw4;
+    a.w4_scale = (const uint8_t*)d->w4_scale;
+    a.gmax_out = (unsigned*)d->gmax_out;
+    if (d->precision == xv::kPrecFp16Mx && !xv::gemm_mx_applicable(a))
+      return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX needs the residual plane, a group-max table per source, "
+                              "K groups of whole 128-column blocks and an even number of 128-row tiles");
     hipError_t e = xv::launch_tdnn_gemm(a, d->precision, d->epilogue, (hipStream_t)d->hip_stream);
     if (e != hipSuccess) return Fail(XV_ERR_DEVICE, std::string("tdnn_gemm launch: ") + hipGetErrorString(e));
+    return XV_OK;
+  });
+}
+
+xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg, const int32_t* seg_src,
+                              const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4, uint8_t* w4_scale) {
+  if (!w || !w_hi_f16 || !seg_src || !seg_shift || !seg_klen || !w4 || !w4_scale || nseg < 1 || nseg > xv::kMaxSeg || n_pad < 1)
+    return Fail(XV_ERR_ARG, "xv_pack_mx_residual: bad argument");
+  return Guard([&] {
+    long key[xv::kMaxSeg];
+    int shift[xv::kMaxSeg], ksteps[xv::kMaxSeg], k_pad = 0;
+    for (int j = 0; j < nseg; ++j) {
+      if (seg_klen[j] % xv::kBK) return Fail(XV_ERR_ARG, "xv_pack_mx_residual: k_len must be a multiple of 32");
+      key[j] = seg_src[j];
+      shift[j] = seg_shift[j];
+      ksteps[j] = seg_klen[j] / xv::kBK;
+      k_pad += seg_klen[j];
+    }
+    xv::WalkGroup wg[xv::kMaxSeg];
+    const int ng = xv::PlanWalkGroups(nseg, key, shift, ksteps, wg);
+    std::vector<int> step_wcol(k_pad / xv::kBK);
+    bool ok = false;
+    xv::PlanWalkSteps(ng, wg, step_wcol.data(), (int)step_wcol.size(), &ok);
+    if (!ok) return Fail(XV_ERR_ARG, "xv_pack_mx_residual: a K group is not a multiple of four steps");
+    const int ldw4 = k_pad / xv::kBK / 4 * 64;
+    std::vector<float> res(k_pad);
+    for (int n = 0; n < n_pad; ++n) {
+      for (int k = 0; k < k_pad; ++k) res[k] = w[(size_t)n * k_pad + k] - xv::host_f16_to_f32(w_hi_f16[(size_t)n * k_pad + k]);
+      w4_scale[n] = xv::PackMxRow(res.data(), k_pad, step_wcol.data(), w4 + (size_t)n * ldw4);
+    }
     return XV_OK;
   });
 }

@@ -13,7 +13,7 @@ namespace xv {
 namespace {
 
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;
 constexpr uint64_t kNone = ~0ull;
 
 struct BlobHeader {
@@ -34,15 +34,56 @@ struct BlobLayer {
   int32_t src_layer[kMaxSeg], src_offset[kMaxSeg], src_dim[kMaxSeg];
   int32_t in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
   uint64_t w_hi, w_lo, bias, scale, offset;  // relative to data_offset
+  uint64_t w4, w4_scale;                     // kPrecFp16Mx residual plane + per-row E8M0 scales, or kNone
+  int32_t ldw4, reserved;
 };
+
+// Round-to-nearest-even onto the e2m1 grid {0, .5, 1, 1.5, 2, 3, 4, 6} (saturating), like v_cvt_scalef32_pk_fp4_*.
+inline uint8_t ToE2M1(float x) {
+  static const float grid[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+  const float a = std::fabs(x);
+  int best = 7;
+  if (!(a >= 6.f)) {
+    best = 0;
+    for (int i = 1; i < 8; ++i) {
+      const float dl = a - grid[best], dh = grid[i] - a;
+      if (dh < dl || (dh == dl && (i & 1) == 0)) best = i;
+      if (grid[i] >= a) break;
+    }
+  }
+  return (uint8_t)(best | (std::signbit(x) ? 8 : 0));
+}
 
 inline int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
 inline uint64_t Align256(uint64_t x) { return (x + 255) & ~255ull; }
 
 }  // namespace
 
+uint8_t PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row) {
+  float mx = 0.f;
+  for (int k = 0; k < k_pad; ++k) mx = std::max(mx, std::fabs(res[k]));
+  int e8 = 127;
+  if (mx > 0.f && std::isfinite(mx)) {
+    // smallest power of two 2^E with max |r| / 2^E <= 6 (the largest e2m1 value)
+    int ex;
+    const float m = frexpf(mx / 6.f, &ex);   // mx / 6 = m * 2^ex, m in [0.5, 1)
+    const int E = (m == 0.5f) ? ex - 1 : ex;
+    e8 = std::min(std::max(127 + E, 1), 254);
+  }
+  const float inv_s = ldexpf(1.f, 127 - e8);
+  const int nblk = k_pad / kBK / 4;
+  memset(row, 0, (size_t)nblk * 64);
+  for (int blk = 0; blk < nblk; ++blk)
+    for (int g = 0; g < 4; ++g)
+      for (int e = 0; e < 32; ++e) {
+        const int col = step_wcol[4 * blk + e / 8] + 8 * g + e % 8;
+        row[blk * 64 + g * 16 + e / 2] |= (uint8_t)(ToE2M1(res[col] * inv_s) << (4 * (e & 1)));
+      }
+  return (uint8_t)e8;
+}
+
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
-  if (precision < kPrecBf16x3 || precision > kPrecAuto) throw EngineError("unknown precision mode");
+  if (precision < kPrecBf16x3 || precision > kPrecFp16Mx) throw EngineError("unknown precision mode");
   const bool split = PrecWPlanes(precision) == 2;
   const bool f16 = PrecF16(precision);
   const int nl = (int)prog.layers.size();
@@ -87,6 +128,29 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     cur = Align256(cur + (uint64_t)b.n_pad * 4);
     b.offset = cur;
     cur = Align256(cur + (uint64_t)b.n_pad * 4);
+    // kPrecFp16Mx residual plane (frame-level layers whose K walk consists of whole blocks of four steps)
+    b.w4 = b.w4_scale = kNone;
+    b.ldw4 = 0;
+    if ((precision == kPrecAuto || precision == kPrecFp16Mx) && !L.segment_level) {
+      long key[kMaxSeg];
+      int shift[kMaxSeg], ksteps[kMaxSeg];
+      for (int j = 0; j < b.nsrc; ++j) {
+        key[j] = b.src_layer[j];
+        shift[j] = b.src_offset[j];
+        ksteps[j] = RoundUp(b.src_dim[j], kBK) / kBK;
+      }
+      WalkGroup wg[kMaxSeg];
+      const int ng = PlanWalkGroups(b.nsrc, key, shift, ksteps, wg);
+      bool ok = false;
+      const int nsteps = PlanWalkSteps(ng, wg, nullptr, 0, &ok);
+      if (ok && nsteps == kp / kBK) {
+        b.ldw4 = nsteps / 4 * 64;
+        b.w4 = cur;
+        cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4);
+        b.w4_scale = cur;
+        cur = Align256(cur + (uint64_t)b.n_pad);
+      }
+    }
   }
   BlobHeader h;
   memset(&h, 0, sizeof h);
@@ -149,6 +213,47 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         kpad += RoundUp(b.src_dim[j], kBK);
       }
     }
+    if (b.w4 != kNone) {
+      // e2m1 image of the residual w * 2^S - w_hi, in the order the kernels walk the K steps (kernels.h): block b of
+      // four steps, lane group g, element e  <-  weight column step_wcol[4 b + e / 8] + 8 g + e % 8
+      long key[kMaxSeg];
+      int shift[kMaxSeg], ksteps[kMaxSeg];
+      for (int j = 0; j < b.nsrc; ++j) {
+        key[j] = b.src_layer[j];
+        shift[j] = b.src_offset[j];
+        ksteps[j] = RoundUp(b.src_dim[j], kBK) / kBK;
+      }
+      WalkGroup wg[kMaxSeg];
+      const int ng = PlanWalkGroups(b.nsrc, key, shift, ksteps, wg);
+      std::vector<int> step_wcol(b.k_pad / kBK);
+      PlanWalkSteps(ng, wg, step_wcol.data(), (int)step_wcol.size(), nullptr);
+      // padded column -> source column of L.w (or -1)
+      std::vector<int> src_col(b.k_pad, -1);
+      {
+        int kcol = 0, kpad = 0;
+        for (int j = 0; j < b.nsrc; ++j) {
+          for (int d = 0; d < b.src_dim[j]; ++d) src_col[kpad + d] = kcol + d;
+          kcol += b.src_dim[j];
+          kpad += RoundUp(b.src_dim[j], kBK);
+        }
+      }
+      uint8_t* w4 = data + b.w4;
+      uint8_t* w4s = data + b.w4_scale;
+      std::vector<float> res(b.k_pad);
+      for (int n = 0; n < b.n_pad; ++n) {
+        w4s[n] = 127;
+        if (n >= L.out_dim) continue;
+        for (int k = 0; k < b.k_pad; ++k) {
+          float r = 0.f;
+          if (src_col[k] >= 0) {
+            const float w = L.w[(size_t)n * L.in_dim + src_col[k]] * wscale;
+            r = w - host_f16_to_f32(whi[(size_t)n * b.k_pad + k]);
+          }
+          res[k] = r;
+        }
+        w4s[n] = PackMxRow(res.data(), b.k_pad, step_wcol.data(), w4 + (size_t)n * b.ldw4);
+      }
+    }
     float* bias = (float*)(data + b.bias);
     float* scale = (float*)(data + b.scale);
     float* offset = (float*)(data + b.offset);
@@ -163,12 +268,33 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
   return blob;
 }
 
+std::vector<uint8_t> ReadBlobHead(const void* device_blob, size_t n) {
+  if (n < sizeof(BlobHeader)) throw EngineError("model blob too small");
+  BlobHeader h;
+  if (hipMemcpy(&h, device_blob, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
+    throw EngineError("cannot read the header of the device-resident model blob");
+  if (memcmp(h.magic, "XVHIPBLB", 8) != 0 || h.version != kBlobVersion || h.total_bytes != n || h.data_offset > n ||
+      h.data_offset < sizeof h)
+    throw EngineError("bad model blob header (device image)");
+  std::vector<uint8_t> head((size_t)h.data_offset);
+  if (hipMemcpy(head.data(), device_blob, head.size(), hipMemcpyDeviceToHost) != hipSuccess)
+    throw EngineError("cannot read the layer table of the device-resident model blob");
+  return head;
+}
+
 BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
   if (n < sizeof(BlobHeader)) throw EngineError("model blob too small");
   BlobHeader h;
   memcpy(&h, blob, sizeof h);
   if (memcmp(h.magic, "XVHIPBLB", 8) != 0 || h.version != kBlobVersion) throw EngineError("bad model blob header");
   if (h.total_bytes != n) throw EngineError("model blob size mismatch");
+  if (h.n_layers < 1 || h.n_layers > 4096 || h.data_offset > n ||
+      sizeof(BlobHeader) + (uint64_t)h.n_layers * sizeof(BlobLayer) > h.data_offset)
+    throw EngineError("model blob: layer table does not fit the header");
+  if (h.precision < kPrecBf16x3 || h.precision > kPrecFp16Mx) throw EngineError("model blob: unknown precision mode");
+  if (h.output_layer < 0 || h.output_layer >= h.n_layers || h.pooled_layer >= h.n_layers)
+    throw EngineError("model blob: layer index out of range");
+  const uint64_t data_bytes = n - h.data_offset;
   BlobInfo info;
   info.precision = h.precision;
   info.input_dim = h.input_dim;
@@ -186,6 +312,25 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
   for (int i = 0; i < h.n_layers; ++i) {
     BlobLayer b;
     memcpy(&b, blob + sizeof h + (size_t)i * sizeof(BlobLayer), sizeof b);
+    {
+      // everything the engine later turns into device pointers or loop bounds
+      auto inside = [&](uint64_t off, uint64_t bytes) { return off <= data_bytes && bytes <= data_bytes - off; };
+      bool ok = b.nsrc >= 1 && b.nsrc <= kMaxSeg && b.n_pad > 0 && b.n_pad % kBN == 0 && b.k_pad > 0 && b.k_pad % kBK == 0 &&
+                b.out_dim >= 1 && b.out_dim <= b.n_pad && b.in_dim >= 1;
+      int kp = 0;
+      for (int j = 0; ok && j < b.nsrc; ++j) {
+        ok = b.src_layer[j] >= kSrcPooled && b.src_layer[j] < i && b.src_dim[j] >= 1 && std::abs(b.src_offset[j]) <= 15;
+        kp += RoundUp(b.src_dim[j], kBK);
+      }
+      ok = ok && kp == b.k_pad;
+      const uint64_t wbytes = (uint64_t)b.n_pad * b.k_pad * 2;
+      ok = ok && inside(b.w_hi, wbytes) && (b.w_lo == kNone || inside(b.w_lo, wbytes)) && inside(b.bias, (uint64_t)b.n_pad * 4) &&
+           inside(b.scale, (uint64_t)b.n_pad * 4) && inside(b.offset, (uint64_t)b.n_pad * 4);
+      if (b.w4 != kNone)
+        ok = ok && b.ldw4 == b.k_pad / kBK / 4 * 64 && (b.k_pad / kBK) % 4 == 0 && inside(b.w4, (uint64_t)b.n_pad * b.ldw4) &&
+             b.w4_scale != kNone && inside(b.w4_scale, (uint64_t)b.n_pad);
+      if (!ok) throw EngineError("model blob: layer " + std::to_string(i) + " is inconsistent");
+    }
     BlobLayerInfo li;
     li.name = b.name;
     li.in_dim = b.in_dim;
@@ -198,6 +343,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
     li.segment_level = b.segment_level;
     li.left = b.left;
     li.right = b.right;
+    li.has_w4 = b.w4 != kNone;
     for (int j = 0; j < b.nsrc; ++j) {
       LayerSource s;
       s.layer = b.src_layer[j];
@@ -241,7 +387,7 @@ void Engine::Check(hipError_t e, const char* what) const {
   }
 }
 
-Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
+Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_image) : device_(device) {
   info_ = ParseBlobInfo(blob, n);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -270,8 +416,12 @@ Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
   nplanes_ = PrecWPlanes(info_.precision);   // residual planes exist for every split mode
   // Kernel modes.  slow_prec_ runs everything that is not a frame-level GEMM of a "fast" chunk; fast chunks (only
   // kPrecFp16x2 / kPrecAuto have them) are those that pool at least fast_min_pooled_ frames, see FillPlan.
-  slow_prec_ = (info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto) ? (int)kPrecFp16x3 : info_.precision;
-  has_fast_ = !frame_mode_ && (info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto);
+  const bool fast_family = info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx;
+  slow_prec_ = fast_family ? (int)kPrecFp16x3 : info_.precision;
+  has_fast_ = !frame_mode_ && fast_family;
+  // fast chunks run kPrecFp16Mx on the layers that allow it (packed residual plane, sources with a group-max table)
+  // and kPrecFp16x2 on the others
+  fast_mx_ = has_fast_ && (info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx);
   fast_min_pooled_ = 0;
   if (info_.precision == kPrecAuto) {
     const char* e = getenv("XVEC_FAST_MIN_POOLED");
@@ -295,7 +445,11 @@ Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
   memcpy(&h, blob, sizeof h);
   blob_data_bytes_ = (size_t)(h.total_bytes - h.data_offset);
   Check(hipMalloc(&d_blob_, blob_data_bytes_), "hipMalloc(weights)");
-  Check(hipMemcpy(d_blob_, blob + h.data_offset, blob_data_bytes_, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+  if (device_image)   // the image is already on this device (e.g. it arrived by RCCL broadcast): no host round trip
+    Check(hipMemcpy(d_blob_, (const uint8_t*)device_image + h.data_offset, blob_data_bytes_, hipMemcpyDeviceToDevice),
+          "hipMemcpy(weights, device to device)");
+  else
+    Check(hipMemcpy(d_blob_, blob + h.data_offset, blob_data_bytes_, hipMemcpyHostToDevice), "hipMemcpy(weights)");
   layers_.resize(info_.layers.size());
   for (size_t i = 0; i < layers_.size(); ++i) {
     BlobLayer b;
@@ -306,6 +460,9 @@ Engine::Engine(const uint8_t* blob, size_t n, int device) : device_(device) {
     layers_[i].bias = (const float*)(base + b.bias);
     layers_[i].scale = (const float*)(base + b.scale);
     layers_[i].offset = (const float*)(base + b.offset);
+    layers_[i].w4 = b.w4 == kNone ? nullptr : base + b.w4;
+    layers_[i].w4_scale = b.w4_scale == kNone ? nullptr : base + b.w4_scale;
+    layers_[i].ldw4 = b.ldw4;
   }
   in_ld_ = RoundUp(info_.input_dim, kBK);
   stats_ld_ = RoundUp(2 * info_.pool_dim, kBK);
@@ -319,8 +476,11 @@ Engine::~Engine() {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
   };
+  if (stream_) release_stream_workspace(stream_);
   for (Lane& L : lanes_) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
+    if (L.stream) release_stream_workspace(L.stream);
+    fr(L.gmax);
     for (ActBuf& a : L.act) {
       fr(a.act_hi);
       fr(a.act_lo);
@@ -394,6 +554,9 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
       Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
       if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true);
     }
+    // per layer: max |activation| of every 16-row group (what a kPrecFp16Mx consumer scales its 4-bit copy by)
+    if (fast_mx_) Ensure(&L.gmax, layers_.size() * (size_t)(rows / kRowAlign) * 4, true);
+    L.gmax_stride = rows / kRowAlign;
     L.cap_rows = rows;
   }
   if (!frame_mode_ && b_pad > L.cap_b) {
@@ -494,6 +657,26 @@ void Engine::FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector
       grp_range[2 * g + 1] = (int8_t)std::min(std::max(last + 1 - t0, 0), kRowAlign);
     }
   }
+  // per layer: the rows of every 16-row group that are computable frames of that layer (kPrecFp16Mx group maxima)
+  const int nlay = (int)info_.layers.size();
+  std::vector<int8_t> act_range;
+  if (fast_mx_ && !frame_mode_) {
+    act_range.assign((size_t)nlay * ngrp * 2, 0);
+    for (int i = 0; i < nlay; ++i) {
+      const BlobLayerInfo& li = info_.layers[i];
+      if (li.segment_level) continue;
+      int8_t* t = act_range.data() + (size_t)i * ngrp * 2;
+      for (int b = 0; b < B; ++b) {
+        const int lo = li.left, hi = key[b] - li.right;   // computable frames [lo, hi)
+        for (int g = g0[b]; g < g1[b]; ++g) {
+          const int t0 = (g - g0[b]) * kRowAlign;
+          t[2 * g] = (int8_t)std::min(std::max(lo - t0, 0), kRowAlign);
+          t[2 * g + 1] = (int8_t)std::min(std::max(hi - t0, 0), kRowAlign);
+        }
+      }
+    }
+  }
+  plan->ngrp = ngrp;
   // one table image, 256-B aligned sections
   plan->o_src = 0;
   plan->o_dev = Align256(plan->o_src + (size_t)(B + 1) * 4);
@@ -503,9 +686,11 @@ void Engine::FillPlan(const int32_t* row_offsets, int B, Plan* plan, std::vector
   plan->o_g1 = Align256(plan->o_g0 + (size_t)B * 4);
   plan->o_cn = Align256(plan->o_g1 + (size_t)B * 4);
   plan->o_or = Align256(plan->o_cn + (size_t)B * 4);
-  const size_t total = Align256(plan->o_or + out_row.size() * 4);
+  plan->o_ar = Align256(plan->o_or + out_row.size() * 4);
+  const size_t total = Align256(plan->o_ar + act_range.size());
   std::vector<uint8_t>& host = *tables;
   host.assign(total, 0);
+  if (!act_range.empty()) memcpy(host.data() + plan->o_ar, act_range.data(), act_range.size());
   if (!out_row.empty()) memcpy(host.data() + plan->o_or, out_row.data(), out_row.size() * 4);
   memcpy(host.data() + plan->o_src, plan->src_off.data(), (size_t)(B + 1) * 4);
   memcpy(host.data() + plan->o_dev, dev_off.data(), (size_t)B * 4);
@@ -526,6 +711,7 @@ void Engine::BindPlan(Plan* plan, const void* device_tables) {
   plan->d_utt_grp1 = (const int32_t*)(d + plan->o_g1);
   plan->d_utt_count = (const int32_t*)(d + plan->o_cn);
   plan->d_out_row = (const int32_t*)(d + plan->o_or);
+  plan->d_act_range = (const int8_t*)(d + plan->o_ar);
 }
 
 std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B) {
@@ -575,6 +761,10 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
   pa.out_lo = ActBase(L.in_lo, in_ld_);
   pa.pad_left = pad_left_;
   pa.pad_right = pad_right_;
+  const bool mx_pass = fast_mx_ && plan.rows_fast > 0;
+  pa.zero_words = mx_pass ? (unsigned*)L.gmax.p : nullptr;
+  pa.n_zero_words = mx_pass ? (int)(layers_.size() * (size_t)L.gmax_stride) : 0;
+  auto gmax_of = [&](int layer) { return (unsigned*)L.gmax.p + (size_t)layer * L.gmax_stride; };
   // profiling: every launch_* call below is bracketed by its own (start, stop) event pair, stamped by the dispatch
   // itself (kernels.hip: set_launch_events) - no extra packets between the kernels of the timed region
   std::vector<hipEvent_t> prof_run;
@@ -628,12 +818,17 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       }
       sg.row_shift = li.segment_level ? 0 : src.offset;
       sg.ksteps = RoundUp(src.dim, kBK) / kBK;
+      sg.gmax = (mx_pass && !li.segment_level && src.layer >= 0 && !info_.layers[src.layer].segment_level) ? gmax_of(src.layer)
+                                                                                                      : nullptr;
       ksteps += sg.ksteps;
     }
     ga.total_ksteps = ksteps;
     ga.w_hi = dl.w_hi;
     ga.w_lo = dl.w_lo;
     ga.ldw = li.k_pad;
+    ga.w4 = dl.w4;
+    ga.w4_scale = dl.w4_scale;
+    ga.ldw4 = dl.ldw4;
     ga.n_tiles = li.n_pad / kBN;
     ga.relu = li.relu;
     ga.bn = li.bn;
@@ -702,11 +897,21 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         }
         if (gr.out_hi) gr.out_hi += r0 * gr.ldo;
         if (gr.out_lo) gr.out_lo += r0 * gr.ldo;
+        // the fast region records the group maxima of the planes it writes and, where the layer allows, runs the
+        // 1.25-pass mode on them (region 0 starts at row 0: the tables need no offset)
+        if (region == 0 && mx_pass && epi == kEpiAct) {
+          gr.gmax_out = gmax_of((int)i);
+          gr.out_range = plan.d_act_range + (size_t)i * plan.ngrp * 2;
+        }
+        if (region != 0)
+          for (int j = 0; j < gr.nseg; ++j) gr.seg[j].gmax = nullptr;
         if (gr.out_f32) gr.out_f32 += r0 * gr.ldf;
         if (gr.partial) gr.partial += (r0 / kRowAlign) * 2 * gr.ldp;
         if (gr.grp_range) gr.grp_range += (r0 / kRowAlign) * 2;
         gr.m_valid = (int)(r1 - r0);
-        Check(launch_tdnn_gemm(gr, region == 0 ? (int)kPrecFp16x2 : prec, epi, s), "tdnn_gemm launch");
+        int rprec = prec;
+        if (region == 0) rprec = (mx_pass && gemm_mx_applicable(gr)) ? (int)kPrecFp16Mx : (int)kPrecFp16x2;
+        Check(launch_tdnn_gemm(gr, rprec, epi, s), "tdnn_gemm launch");
       }
     }
     disarm();

@@ -27,9 +27,14 @@ struct EngineError : public std::runtime_error {
 // rank broadcasts to the others over RCCL and what an Engine is built from.
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision);
 
+// kPrecFp16Mx: e2m1 image of one row of weight residuals res[k_pad] (K-contiguous, padded like the fp16 planes) in the
+// order the kernels walk the K steps (step_wcol from PlanWalkSteps, kernels.h); returns the row's E8M0 scale.
+uint8_t PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row);
+
 struct BlobLayerInfo {
   std::string name;
   int in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
+  bool has_w4 = false;   // carries the 4-bit residual plane of kPrecFp16Mx
   std::vector<LayerSource> src;
 };
 
@@ -41,12 +46,16 @@ struct BlobInfo {
   double Macs(int T) const;
 };
 BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n);
+// Header + layer table (the first data_offset bytes) of a packed image that lives in device memory.
+std::vector<uint8_t> ReadBlobHead(const void* device_blob, size_t n);
 
 class Engine {
  public:
   struct Plan;
   // Throws EngineError when no usable HIP device exists - there is no CPU fallback in the product.
-  Engine(const uint8_t* blob, size_t n, int device);
+  // device_image (optional): the same n bytes already resident on `device` (e.g. received by RCCL broadcast); the
+  // weights are then copied device to device and `blob` only has to hold the header and the layer table.
+  Engine(const uint8_t* blob, size_t n, int device, const void* device_image = nullptr);
   ~Engine();
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -113,6 +122,9 @@ class Engine {
     const float* bias;
     const float* scale;
     const float* offset;
+    const uint8_t* w4;
+    const uint8_t* w4_scale;
+    int ldw4;
   };
   struct ActBuf {
     Buf act_hi, act_lo;   // frame-level: [halo + rows + halo][n_pad]; segment-level: [b_pad][n_pad]
@@ -126,6 +138,8 @@ class Engine {
     bool busy = false;
     std::vector<ActBuf> act;     // per layer
     Buf in_hi, in_lo, partial, stats_hi, stats_lo, out_f32, splitk_ws, frame_f32;
+    Buf gmax;              // [layer][gmax_stride] group maxima of the activation planes (kPrecFp16Mx)
+    int gmax_stride = 0;
     int cap_rows = 0, cap_b = 0;
   };
   struct HostSlot {
@@ -165,6 +179,7 @@ class Engine {
   static constexpr int kDefaultFastMinPooled = 300;
   int slow_prec_ = 0;
   bool has_fast_ = false;
+  bool fast_mx_ = false;
   int fast_min_pooled_ = 0;
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;   // host-slot uploads (SubmitHost)
@@ -189,7 +204,9 @@ struct Engine::Plan {
   std::vector<int32_t> src_off;  // [B+1]
   void* d_tables = nullptr;      // one device allocation holding all tables below (owned unless borrowed)
   bool borrowed_tables = false;  // tables live in a host slot's buffer
-  size_t o_src = 0, o_dev = 0, o_gu = 0, o_gr = 0, o_g0 = 0, o_g1 = 0, o_cn = 0, o_or = 0;  // table offsets
+  size_t o_src = 0, o_dev = 0, o_gu = 0, o_gr = 0, o_g0 = 0, o_g1 = 0, o_cn = 0, o_or = 0, o_ar = 0;  // table offsets
+  int ngrp = 0;                  // 16-row groups of the batch
+  const int8_t* d_act_range = nullptr;   // [layer][ngrp][2] computable rows of each group, per layer (kPrecFp16Mx)
   const int32_t* d_src_off = nullptr;
   const int32_t* d_dev_off = nullptr;
   const int32_t* d_grp_utt = nullptr;

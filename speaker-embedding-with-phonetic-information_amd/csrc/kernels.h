@@ -33,13 +33,23 @@ enum Precision : int {
                     // rounding error - coherent over the frames of a chunk, so the pooling does not average it - is
                     // removed; the activation rounding error is independent per frame and averages out in the
                     // statistics pooling (measured: DESIGN.md section 3.1).  Frame-level layers only.
-  kPrecAuto = 5,    // engine policy, not a kernel mode: kPrecFp16x2 for chunks that pool >= a threshold of frames,
-                    // kPrecFp16x3 for the others (same packed weights)
+  kPrecAuto = 5,    // engine policy, not a kernel mode: the fast mode (kPrecFp16Mx where a layer's K walk allows it,
+                    // else kPrecFp16x2) for chunks that pool >= a threshold of frames, kPrecFp16x3 for the others (same
+                    // packed weights)
+  kPrecFp16Mx = 6,  // kPrecFp16x2 with the second pass (x . w_lo) done at 4x the fp16 rate on block-scaled fp4 operands:
+                    //   x . w_hi  (v_mfma_f32_16x16x32_f16, every 32-column K step)
+                    // + q4(x) . q4(w - w_hi)  (v_mfma_scale_f32_16x16x128_f8f6f4, once per four K steps),
+                    // q4(x) = the fp16 fragments converted in registers (v_cvt_scalef32_pk_fp4_f16) with one power-of-two
+                    // scale per 16-row group (from the max |x| the producing epilogue recorded), q4(w - w_hi) = a packed
+                    // e2m1 plane with one scale per output row.  1.25 MFMA passes per product; the residual term only has
+                    // to be good to ~4 bits (it is 2^-11 of the product), DESIGN.md section 3.0.  Frame-level layers only.
 };
-constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto; }
+constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx; }
+constexpr bool PrecMx(int p) { return p == kPrecFp16Mx; }
 constexpr int PrecXPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3) ? 2 : 1; }   // kernel modes only
-constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto) ? 2 : 1; }
-constexpr int PrecPasses(int p) { return PrecXPlanes(p) + PrecWPlanes(p) - 1; }   // MFMAs per algorithmic product
+// weight planes staged per K step (the 4-bit residual plane of kPrecFp16Mx uses the slot of the fp16 residual plane)
+constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx) ? 2 : 1; }
+constexpr int PrecPasses(int p) { return PrecXPlanes(p) + PrecWPlanes(p) - 1; }   // MFMAs per algorithmic product (Mx: 1.25)
 
 enum Epilogue : int {
   kEpiAct = 0,    // bias -> ReLU? -> BatchNorm? -> split to 16-bit planes
@@ -55,6 +65,7 @@ struct Seg {
   int row_shift;       // time offset of this Append() term
   int ksteps;          // K length of the segment / kBK
   int pad_;
+  const unsigned* gmax;  // kPrecFp16Mx: [rows/16] max |x| (float bits) of the 16-row groups of this plane, or null
 };
 
 // A group of K segments that share one LDS activation tile (filled by the launcher, see kernels.hip).
@@ -69,7 +80,58 @@ struct Grp {
   int wcol0;    // weight column of (offset 0, chunk 0)
   int wstride;  // weight columns between consecutive offsets
   int pad_;
+  const unsigned* gmax;   // see Seg
 };
+
+// The order in which the GEMM kernels walk the K steps of a layer: consecutive Append() terms that read the same
+// source at uniformly spaced, increasing time offsets (total span <= 16 rows) form a group whose activation tile is
+// staged once per 32-column chunk; inside a group the walk is chunk -> offset.  Shared by the launcher (build_groups)
+// and by the host code that packs the 4-bit residual plane of kPrecFp16Mx in walk order (engine.cc).
+struct WalkGroup {
+  int first_seg, nshift, ksteps, shift0, dstep, wcol0, wstride;
+};
+// src_key[j] equal <=> segments read the same plane (and leading dimension).  Returns the number of groups.
+inline int PlanWalkGroups(int nseg, const long* src_key, const int* row_shift, const int* ksteps, WalkGroup* out) {
+  int ng = 0, wcol = 0;
+  for (int j = 0; j < nseg;) {
+    WalkGroup& G = out[ng++];
+    G.first_seg = j;
+    G.ksteps = ksteps[j];
+    G.nshift = 1;
+    G.shift0 = row_shift[j];
+    G.dstep = 0;
+    G.wcol0 = wcol;
+    G.wstride = ksteps[j] * kBK;
+    int k = j + 1;
+    while (k < nseg && src_key[k] == src_key[j] && ksteps[k] == ksteps[j]) {
+      const int d = row_shift[k] - row_shift[k - 1];
+      if (d <= 0 || (G.nshift > 1 && d != G.dstep) || row_shift[k] - row_shift[j] > 16) break;
+      G.dstep = d;
+      ++G.nshift;
+      ++k;
+    }
+    wcol += G.nshift * G.wstride;
+    j = k;
+  }
+  return ng;
+}
+// Weight column (element index into the K-contiguous fp16 planes) of every K step in walk order; returns the number
+// of steps.  mx_ok (optional) = every group has a multiple of four steps, i.e. no 128-deep block of the walk
+// straddles two sources.
+inline int PlanWalkSteps(int ng, const WalkGroup* g, int* step_wcol, int cap, bool* mx_ok) {
+  int n = 0;
+  bool ok = true;
+  for (int i = 0; i < ng; ++i) {
+    if ((g[i].ksteps * g[i].nshift) % 4) ok = false;
+    for (int kk = 0; kk < g[i].ksteps; ++kk)
+      for (int ij = 0; ij < g[i].nshift; ++ij) {
+        if (n < cap) step_wcol[n] = g[i].wcol0 + ij * g[i].wstride + kk * kBK;
+        ++n;
+      }
+  }
+  if (mx_ok) *mx_ok = ok;
+  return n;
+}
 
 struct GemmArgs {
   Seg seg[kMaxSeg];
@@ -80,6 +142,12 @@ struct GemmArgs {
   const uint16_t* w_hi;  // [n_pad][ldw] row-major (Kaldi <LinearParams> orientation)
   const uint16_t* w_lo;
   int ldw;
+  // kPrecFp16Mx: e2m1 residual plane [n_pad][ldw4 bytes]: 64 bytes per (row, block of four K steps in walk order) =
+  // four 16-byte lane-group chunks g; nibble e of chunk g = weight column step_wcol[4 b + e / 8] + 8 g + e % 8;
+  // value = (w - w_hi) / 2^(w4_scale[row] - 127)
+  const uint8_t* w4;
+  int ldw4;
+  const uint8_t* w4_scale;   // [n_pad] E8M0
   int m_tiles;           // rows / kBM
   int n_tiles;           // n_pad / kBN
   int relu;
@@ -91,6 +159,13 @@ struct GemmArgs {
   uint16_t* out_hi;
   uint16_t* out_lo;
   int ldo;
+  unsigned* gmax_out;    // [rows/16] atomic max of |y| (float bits) per 16-row group over all columns (zeroed by the
+                         // caller; prep_input does it), or null - what a kPrecFp16Mx consumer scales its fp4 copy by
+  const int8_t* out_range;  // with gmax_out: [rows/16][2] first / last (exclusive) row of each group that is a computable
+                            // frame of this layer; the others (chunk edges, computed from the neighbouring chunk's
+                            // frames; alignment padding) must not enter the maximum, or a chunk's scales - and with
+                            // them the last bits of its embedding - would depend on its neighbours in the batch.
+                            // null: every row counts
   // kEpiF32
   float* out_f32;
   int ldf;
@@ -114,6 +189,7 @@ struct GemmArgs {
   float* sk_ws;
   unsigned* sk_flags;
   unsigned sk_epoch;
+  unsigned* sk_error;    // host-mapped word: receives sk_epoch when a flag wait timed out (see sk_last_error)
 };
 
 // Arms a (start, stop) event pair for the kernels of the NEXT launch_* call of this thread (profiling; see kernels.hip).
@@ -122,6 +198,14 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop);
 
 // Launches the spliced-affine GEMM. Returns hipSuccess or the launch error.
 hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipStream_t s);
+// True when kPrecFp16Mx can run this launch (residual plane + scales present, every K group a multiple of four steps
+// with a group-max table, even tile count); otherwise the caller launches kPrecFp16x2 on the same operands.
+bool gemm_mx_applicable(const GemmArgs& a);
+// Stream-K workspace (partial-tile exchange) of a stream: allocated on first use, released by the owner of the
+// stream before it destroys it (Engine::~Engine).  sk_last_error: non-zero once any stream-K launch of this process
+// timed out waiting for another workgroup's partial tile (checked by the engine after it synchronises).
+void release_stream_workspace(hipStream_t s);
+unsigned sk_last_error();
 
 // fp32 packed features [src rows][dim] -> 16-bit planes [dev rows][ld] (zero padded columns,
 // zero rows for alignment padding).  grp_utt[g] = utterance of 16-row group g or -1.
@@ -138,6 +222,8 @@ struct PrepArgs {
   // frame-level outputs (nnet3-compute semantics): the chunk is extended by pad_left copies of its first frame and
   // pad_right copies of its last one, so that every input frame gets an output row (0/0 for x-vector extraction)
   int pad_left, pad_right;
+  unsigned* zero_words;     // cleared by the same launch (the group-max tables of the pass), or null
+  int n_zero_words;
 };
 hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s);
 

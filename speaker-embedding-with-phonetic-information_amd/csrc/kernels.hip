@@ -39,6 +39,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace xv {
@@ -132,7 +133,87 @@ __device__ __forceinline__ float sum_halves32(float v) {
   return a + b;
 }
 
+// Maximum over the 64 lanes of a wave, in every lane: four DPP steps inside the 16-lane rows, then the lane-swap
+// instructions across rows (as in sum_rows16 / sum_halves32).
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+  unsigned a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = max(a, b);
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return max(a, b);
+}
+
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
+
+#ifdef XV_PROBE_TIMING
+// Experiment builds only (tools/kbench.sh): s_memtime stamps of the segments of the stream-K K loop, waves 0 and 4 of
+// workgroup 0, read back through xv_probe_dump().
+__device__ unsigned long long g_probe[2][512];
+__device__ int g_probe_n[2];
+#define XV_STAMP(tag)                                                                         \
+  do {                                                                                        \
+    if (probe_on && probe_i < 510) {                                                          \
+      g_probe[probe_w][probe_i++] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull); \
+      g_probe_n[probe_w] = probe_i;                                                           \
+    }                                                                                         \
+  } while (0)
+#else
+#define XV_STAMP(tag) do {} while (0)
+#endif
+
+// ---- kPrecFp16Mx helpers ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// 8 fp16 values -> 8 e2m1 codes (x / scale, round to nearest even, saturating at +-6), element j in nibble j.
+// `old` only provides the destination register (every byte is rewritten).
+__device__ __forceinline__ int cvt8_fp4(s16x8 x, float scale, int old) {
+  const f16x8 h = __builtin_bit_cast(f16x8, x);
+  unsigned r = (unsigned)old;
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(r, f16x2{h[0], h[1]}, scale, 0);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(r, f16x2{h[2], h[3]}, scale, 1);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(r, f16x2{h[4], h[5]}, scale, 2);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(r, f16x2{h[6], h[7]}, scale, 3);
+  return (int)r;
+}
+__device__ __forceinline__ i32x8 w4_frag(s16x8 w) {
+  const u32x4 u = __builtin_bit_cast(u32x4, w);
+  return i32x8{(int)u[0], (int)u[1], (int)u[2], (int)u[3], 0, 0, 0, 0};
+}
+__device__ __forceinline__ i32x8 x4_frag(const int (&x)[4]) { return i32x8{x[0], x[1], x[2], x[3], 0, 0, 0, 0}; }
+// D = A . B (16x16x128, both operands e2m1) * 2^(byte OA of sa - 127) * 2^(byte OB of sb - 127) + C
+template <int OA, int OB>
+__device__ __forceinline__ f32x4 mfma_mx4(i32x8 a, i32x8 b, f32x4 c, int sa, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 4, OA, sa, OB, sb);
+}
+// The same and the fp16 MFMA with the accumulator tied in place (see the stream-K kernel for why).  A and B are any
+// 128-bit register tuples (fp16 fragments or e2m1 fragments).  Byte selector of a scale word = op_sel bit + 2 *
+// op_sel_hi bit of the operand (what hipcc emits for the builtin above).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int OA, int OB, class TA, class TB>
+__device__ __forceinline__ void mfma_mx4_inplace(const TA& a, const TB& b, f32x4& c, int sa, int sb) {
+  static_assert(sizeof(TA) == 16 && sizeof(TB) == 16, "e2m1 16x16x128 operands are four dwords per lane");
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,%6,0] op_sel_hi:[%7,%8,0] cbsz:4 blgp:4"
+      : "+v"(c)
+      : "v"(a), "v"(b), "v"(sa), "v"(sb), "n"(OA & 1), "n"(OB & 1), "n"(OA >> 1), "n"(OB >> 1));
+}
+__device__ __forceinline__ void mfma16_f16_inplace(s16x8 a, s16x8 b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 
 // Per-lane epilogue parameters (bias / scale / offset, and for the statistics epilogue the valid-row table), fetched
 // by epilogue_prefetch: before the K loop where the registers are affordable (see variant 2), else right before use.
@@ -166,14 +247,16 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
         e.of[p * 4 + r] = o4[r];
       }
     }
-  } else if constexpr (EPI == kEpiStats) {
-#ifdef XV_SK_ABLATE
-    if (a.stagger_units & 512) {
-      for (int q = 0; q < 4; ++q) { e.bs[q] = 0.1f; e.sc[q] = 1.1f; e.of[q] = 0.2f; }
-      for (int p = 0; p < 4; ++p) { e.first[p] = 0; e.last[p] = 16; }
-      return;
+    if (EPI == kEpiAct && a.gmax_out) {
+      // rows of the four 16-row groups q that count for the group maxima
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int grp = (mbase + q * 16) >> 4;
+        e.first[q] = a.out_range ? a.out_range[2 * grp] : 0;
+        e.last[q] = a.out_range ? a.out_range[2 * grp + 1] : 16;
+      }
     }
-#endif
+  } else if constexpr (EPI == kEpiStats) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = nbase + q * 16 + fr_i;
@@ -192,9 +275,12 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
 
 // Shared epilogue of the GEMM kernels.  acc[p][q] is the 16x16 fragment (P-tile fragment p) x (Q-tile fragment q)
 // of one wave's 64x64 tile whose first frame is mbase and first output column nbase.
+// gm / gm_phase (planes epilogue with a.gmax_out): lane-local maxima of |y| per 16-row group q carried between calls that
+// cover the same rows - phase 0: this call stands alone; 1: first of two (accumulate only); 2: second (accumulate, then
+// reduce over the wave and publish).
 template <int PREC, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], const int mbase, const int nbase,
-                                              const int lane, const EpiRegs& e) {
+                                              const int lane, const EpiRegs& e, float (&gm)[4], const int gm_phase) {
   constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
   constexpr bool F16 = PrecF16(PREC);
   const int fr_i = lane & 15;
@@ -247,6 +333,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             const uint16_t l0 = to16<F16>(y[2 * v] - from16<F16>(h0));
             const uint16_t l1 = to16<F16>(y[2 * v + 1] - from16<F16>(h1));
             lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+          }
+        }
+        if (a.gmax_out) {
+          // max |y| of this 16-row group (a NaN is skipped by fmaxf, the main product carries it anyway; rows that are
+          // not computable frames of the layer do not count) -> one atomic max per wave: non-negative floats order
+          // like their bit patterns
+          float m = gm[q];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) m = fmaxf(m, fabsf(y[v]));
+          gm[q] = m;
+          if (gm_phase != 1) {
+            if (fr_i < e.first[q] || fr_i >= e.last[q]) m = 0.f;
+            const unsigned u = wave_max_u32(__builtin_bit_cast(unsigned, m));
+            if (lane == 0)
+              (void)__hip_atomic_fetch_max(a.gmax_out + ((mbase + q * 16) >> 4), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         // y[0..7] = columns ncol..ncol+7, y[8..15] = columns ncol+32..ncol+39
@@ -312,12 +413,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       const float v1 = fr_g == 0 ? s1v[q][0] : fr_g == 1 ? s1v[q][1] : fr_g == 2 ? s1v[q][2] : s1v[q][3];
       const float v2 = fr_g == 0 ? s2v[q][0] : fr_g == 1 ? s2v[q][1] : fr_g == 2 ? s2v[q][2] : s2v[q][3];
       float* dst = a.partial + (long)(grp0 + fr_g) * 2 * a.ldp + col;
-#ifdef XV_SK_ABLATE
-      if (a.stagger_units & 256) {
-        if (v1 == 12345.678f) dst[0] = v2;
-        continue;
-      }
-#endif
       dst[0] = v1;
       dst[a.ldp] = v2;
     }
@@ -473,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
 
   EpiRegs er;
   epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
-  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
+  float gm[4] = {0.f, 0.f, 0.f, 0.f};
+  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er, gm, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -523,10 +619,25 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+__device__ __forceinline__ void wait_vm_lgkm0_barrier_n(int n) {   // n wave-uniform, 0..8
+  switch (n) {
+    case 1: wait_vm_lgkm0_barrier<1>(); break;
+    case 2: wait_vm_lgkm0_barrier<2>(); break;
+    case 3: wait_vm_lgkm0_barrier<3>(); break;
+    case 4: wait_vm_lgkm0_barrier<4>(); break;
+    case 5: wait_vm_lgkm0_barrier<5>(); break;
+    case 6: wait_vm_lgkm0_barrier<6>(); break;
+    case 7: wait_vm_lgkm0_barrier<7>(); break;
+    case 8: wait_vm_lgkm0_barrier<8>(); break;
+    default: wait_vm_lgkm0_barrier<0>(); break;
+  }
+}
+
 template <int PREC, int EPI>
 __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
   constexpr bool WSPLIT = PrecWPlanes(PREC) == 2;  // weights carry a residual plane
+  constexpr bool MX = PrecMx(PREC);            // see the stream-K kernel: same arithmetic, same order, MF = 4
   constexpr bool F16 = PrecF16(PREC);
   constexpr bool SWAP = (EPI != kEpiStats);
   constexpr int NPX = SPLIT ? 2 : 1, NPW = WSPLIT ? 2 : 1;
@@ -575,20 +686,23 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   // K column of a step is a wave-uniform offset
   const uint16_t* wrow_hi;
   const uint16_t* wrow_lo;
+  const uint8_t* wrow_4;
   {
     const int rho = wave * 16 + ld_row;
     const int wrow = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
     const long off = (long)(n0 + wrow) * a.ldw + ld_chunk * 8;
     wrow_hi = a.w_hi + off;
-    wrow_lo = WSPLIT ? a.w_lo + off : nullptr;
+    wrow_lo = (WSPLIT && !MX) ? a.w_lo + off : nullptr;
+    wrow_4 = MX ? a.w4 + (long)(n0 + wrow) * a.ldw4 + ld_chunk * 16 : nullptr;
   }
   const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
 
   // ---- issue side: walks the K steps in the order  group -> K chunk -> time offset ------------------------------
   int ig = 0, ikk = 0, ij = 0;        // group, 32-column chunk inside the group, offset index inside the group
   int ixslot = 0, iwslot = 0;         // ring slots the next activation stage / weight stage go to
+  int istep = 0;
   Grp gi = a.grp[0];
-  auto issue_step = [&]() -> int {    // returns the number of DMA instructions this wave issued
+  auto issue_step = [&]() __attribute__((always_inline)) -> int {    // returns the number of DMA instructions this wave issued
     int n = 0;
     if (ij == 0) {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT);
@@ -613,10 +727,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
       const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
       glds16_asm(wrow_hi + wcol, st);
-      if constexpr (WSPLIT) glds16_asm(wrow_lo + wcol, st + WT);
-      n += NPW;
+      n += 1;
+      if constexpr (MX) {
+        if ((istep & 3) == 1) {   // 4-bit residual tile of block istep / 4 -> its own ring (residual halves of the slots)
+          const unsigned st4 = __builtin_amdgcn_readfirstlane(lds_base + WBASE + ((istep >> 2) % 3) * WSLOT + WT + wave * 1024);
+          glds16_asm(wrow_4 + (istep >> 2) * 64, st4);
+          n += 1;
+        }
+      } else if constexpr (WSPLIT) {
+        glds16_asm(wrow_lo + wcol, st + WT);
+        n += 1;
+      }
       iwslot = iwslot == 2 ? 0 : iwslot + 1;
     }
+    ++istep;
     if (++ij == gi.nshift) {
       ij = 0;
       if (++ikk == gi.ksteps) {
@@ -626,6 +750,30 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     }
     return n;
   };
+
+  // kPrecFp16Mx scales (see the stream-K kernel)
+  int xs_b = 0, ws_v = 0;
+  auto load_xscales = [&](const unsigned* gmax) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      typedef __attribute__((ext_vector_type(4))) unsigned uvec;
+      const unsigned* p = gmax + ((m0 + wave_m * 64) >> 4);
+      uvec g;
+      asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g) : "s"(p) : "memory");
+      xs_b = 0;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        unsigned e = (g[f] >> 23) & 255u;
+        e = e < 16u ? 16u : (e > 200u ? 200u : e);
+        xs_b |= (int)((e - 2u) << (8 * f));
+      }
+    }
+  };
+  if constexpr (MX) {
+    load_xscales(gi.gmax);
+    const uint8_t* sp = a.w4_scale + n0 + wave_n * 64;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ws_v |= (int)sp[SWAP ? swap_fields(p * 16 + (lane & 15)) : p * 16 + (lane & 15)] << (8 * p);
+  }
 
   // ---- read side ---------------------------------------------------------------------------------------------
   int rg = 0, rkk = 0, rj = 0;
@@ -637,7 +785,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   struct Frags {
     s16x8 xh[4], xl[4], wh[4], wl[4];
   };
-  auto read_step = [&](Frags& f) {
+  int rblk = 0;
+  bool xs_reload = false;
+  auto read_step = [&](Frags& f) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      if (xs_reload) {
+        load_xscales(a.grp[rg].gmax);
+        xs_reload = false;
+      }
+    }
     const char* xs = smem + rxslot * XSLOT;
     const char* ws = smem + WBASE + rwslot * WSLOT;
     const int row = wave_m * 64 + fr_i + rj * r_dstep;  // displaced by the time offset of this step
@@ -647,7 +803,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       f.xh[i] = *(const s16x8*)(xs + x_rd + i * 1024);
       f.wh[i] = *(const s16x8*)(ws + w_rd + i * 1024);
       if constexpr (SPLIT) f.xl[i] = *(const s16x8*)(xs + x_rd + XT + i * 1024);
-      if constexpr (WSPLIT) f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
+      if constexpr (WSPLIT && !MX) f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
     }
     rwslot = rwslot == 2 ? 0 : rwslot + 1;
     if (++rj == r_nshift) {
@@ -659,6 +815,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
           r_nshift = a.grp[rg].nshift;
           r_ksteps = a.grp[rg].ksteps;
           r_dstep = a.grp[rg].dstep;
+          if constexpr (MX) xs_reload = true;
         }
       }
     }
@@ -669,12 +826,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfmas = [&](const Frags& f) {
+  auto mfmas = [&](const Frags& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (SWAP) {
+        if constexpr (MX) {
+          if constexpr (SWAP) mfma16_f16_inplace(f.wh[p], f.xh[q], acc[p][q]);
+          else mfma16_f16_inplace(f.xh[p], f.wh[q], acc[p][q]);
+        } else if constexpr (SWAP) {
           if constexpr (WSPLIT) acc[p][q] = mfma16<F16>(f.wl[p], f.xh[q], acc[p][q]);
           if constexpr (SPLIT) acc[p][q] = mfma16<F16>(f.wh[p], f.xl[q], acc[p][q]);
           acc[p][q] = mfma16<F16>(f.wh[p], f.xh[q], acc[p][q]);
@@ -684,6 +844,32 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
           acc[p][q] = mfma16<F16>(f.xh[p], f.wh[q], acc[p][q]);
         }
       }
+    }
+  };
+
+  i32x4 x4[MX ? 4 : 1];
+  auto convert = [&](const Frags& f, const int s) __attribute__((always_inline)) {
+    if constexpr (MX) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x4[i][s] = cvt8_fp4(f.xh[i], __builtin_bit_cast(float, ((unsigned)(xs_b >> (8 * i)) & 255u) << 23), x4[i][s]);
+        asm volatile("" : "+v"(x4[i]));
+      }
+    }
+  };
+  auto mx_mfmas = [&](Frags& f) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      const char* w4s = smem + WBASE + (rblk % 3) * WSLOT + WT + w_rd;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) f.wh[w] = *(const s16x8*)(w4s + w * 1024);
+      asm volatile("s_nop 4" ::: "memory");
+      static_for<0, 4>([&](auto P) {
+        static_for<0, 4>([&](auto Q) {
+          constexpr int p = decltype(P)::value, q = decltype(Q)::value;
+          if constexpr (SWAP) mfma_mx4_inplace<p, q>(f.wh[p], x4[q], acc[p][q], ws_v, xs_b);
+          else mfma_mx4_inplace<p, q>(x4[p], f.wh[q], acc[p][q], xs_b, ws_v);
+        });
+      });
     }
   };
 
@@ -698,16 +884,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   //        groups finished those reads (lgkmcnt(0) before their barrier) at least one barrier earlier.
   // n = DMA instructions this wave may leave in flight: NPW (weights only), NPW + 2*NPX (+2 activation chunks),
   // NPW + 3*NPX (wave 0, + halo chunk).
-  auto wait_and_barrier = [&](int n) {
+  auto wait_and_barrier = [&](int n) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) through the builtin: hipcc's scoreboard then knows about it
-    if (n == 0) wait_vm_lgkm0_barrier<0>();
-    else if (n == NPW) wait_vm_lgkm0_barrier<NPW>();
-    else if (n == NPW + 2 * NPX) wait_vm_lgkm0_barrier<NPW + 2 * NPX>();
-    else wait_vm_lgkm0_barrier<NPW + 3 * NPX>();
+    if constexpr (MX) {
+      wait_vm_lgkm0_barrier_n(n);
+    } else {
+      if (n == 0) wait_vm_lgkm0_barrier<0>();
+      else if (n == NPW) wait_vm_lgkm0_barrier<NPW>();
+      else if (n == NPW + 2 * NPX) wait_vm_lgkm0_barrier<NPW + 2 * NPX>();
+      else wait_vm_lgkm0_barrier<NPW + 3 * NPX>();
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto plain_barrier = [&]() {
+  auto plain_barrier = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -717,23 +907,49 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   const int group = wave >> 2;
   issue_step();
   const int n1 = S > 1 ? issue_step() : 0;
-  wait_and_barrier(n1);              // every share of step 0 has landed
+  if constexpr (MX) {
+    // both first steps (and the weight-row scale loads hipcc tracks) complete here: see the stream-K kernel
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    wait_and_barrier(0);
+  } else {
+    wait_and_barrier(n1);            // every share of step 0 has landed
+  }
   if (group == 1) plain_barrier();   // group 1 runs one barrier interval behind group 0
   Frags f;
-  for (int j = 0; j < S; ++j) {
-    // ---- LOAD segment of step j
-    read_step(f);
-    const int n = (j + 2 < S) ? issue_step() : 0;
-    wait_and_barrier(n);
-    // ---- COMPUTE segment of step j
-    __builtin_amdgcn_s_setprio(1);
-    mfmas(f);
-    __builtin_amdgcn_s_setprio(0);
-    plain_barrier();
+  if constexpr (MX) {
+#pragma nounroll
+    for (int j = 0; j < S; j += 4, ++rblk) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        read_step(f);
+        const int n = (j + s + 2 < S) ? issue_step() : 0;
+        wait_and_barrier(n);
+        __builtin_amdgcn_s_setprio(1);
+        mfmas(f);
+        convert(f, s);
+        if (s == 3) mx_mfmas(f);
+        __builtin_amdgcn_s_setprio(0);
+        plain_barrier();
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  } else {
+    for (int j = 0; j < S; ++j) {
+      // ---- LOAD segment of step j
+      read_step(f);
+      const int n = (j + 2 < S) ? issue_step() : 0;
+      wait_and_barrier(n);
+      // ---- COMPUTE segment of step j
+      __builtin_amdgcn_s_setprio(1);
+      mfmas(f);
+      __builtin_amdgcn_s_setprio(0);
+      plain_barrier();
+    }
   }
   if (group == 0) plain_barrier();
   if constexpr (EPI != kEpiStats) epilogue_prefetch<EPI>(a, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
-  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er);
+  float gm[4] = {0.f, 0.f, 0.f, 0.f};
+  gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er, gm, 0);
 }
 
 // Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring, 4 = stream-K (persistent; falls
@@ -769,34 +985,47 @@ static bool lds_attr_needed(std::atomic<unsigned long long>* done_mask, int* dev
   return !((done_mask->load(std::memory_order_acquire) >> (dev & 63)) & 1ull);
 }
 
-// Groups consecutive K segments that read the same source at uniformly spaced time offsets (see the v2 kernel).
+// Groups consecutive K segments that read the same source at uniformly spaced time offsets (see the v2 kernel); the
+// grouping rule itself is PlanWalkGroups (kernels.h), shared with the host code that packs weights in walk order.
 static void build_groups(GemmArgs* g) {
-  g->ngrp = 0;
-  int wcol = 0;
-  for (int j = 0; j < g->nseg;) {
-    const Seg& s0 = g->seg[j];
-    Grp& G = g->grp[g->ngrp++];
+  long key[kMaxSeg];
+  int shift[kMaxSeg], ksteps[kMaxSeg];
+  for (int j = 0; j < g->nseg; ++j) {
+    key[j] = j;
+    for (int k = 0; k < j; ++k)
+      if (g->seg[k].hi == g->seg[j].hi && g->seg[k].lo == g->seg[j].lo && g->seg[k].ld == g->seg[j].ld) {
+        key[j] = key[k];
+        break;
+      }
+    shift[j] = g->seg[j].row_shift;
+    ksteps[j] = g->seg[j].ksteps;
+  }
+  WalkGroup wg[kMaxSeg];
+  g->ngrp = PlanWalkGroups(g->nseg, key, shift, ksteps, wg);
+  for (int i = 0; i < g->ngrp; ++i) {
+    const Seg& s0 = g->seg[wg[i].first_seg];
+    Grp& G = g->grp[i];
     G.hi = s0.hi;
     G.lo = s0.lo;
     G.ld = s0.ld;
-    G.ksteps = s0.ksteps;
-    G.nshift = 1;
-    G.shift0 = s0.row_shift;
-    G.dstep = 0;
-    G.wcol0 = wcol;
-    G.wstride = s0.ksteps * kBK;
-    int k = j + 1;
-    while (k < g->nseg && g->seg[k].hi == s0.hi && g->seg[k].lo == s0.lo && g->seg[k].ld == s0.ld &&
-           g->seg[k].ksteps == s0.ksteps) {
-      const int d = g->seg[k].row_shift - g->seg[k - 1].row_shift;
-      if (d <= 0 || (G.nshift > 1 && d != G.dstep) || g->seg[k].row_shift - s0.row_shift > 16) break;
-      G.dstep = d;
-      ++G.nshift;
-      ++k;
-    }
-    wcol += G.nshift * G.wstride;
-    j = k;
+    G.ksteps = wg[i].ksteps;
+    G.nshift = wg[i].nshift;
+    G.shift0 = wg[i].shift0;
+    G.dstep = wg[i].dstep;
+    G.wcol0 = wg[i].wcol0;
+    G.wstride = wg[i].wstride;
+    G.pad_ = 0;
+    G.gmax = s0.gmax;
   }
+}
+
+bool gemm_mx_applicable(const GemmArgs& a) {
+  if (!a.w4 || !a.w4_scale || a.ldw4 <= 0 || (a.m_tiles & 1) || (a.total_ksteps & 3)) return false;
+  GemmArgs b = a;
+  build_groups(&b);
+  for (int i = 0; i < b.ngrp; ++i)
+    if (!b.grp[i].gmax || (b.grp[i].ksteps * b.grp[i].nshift) % 4) return false;
+  return true;
 }
 
 static int device_cu_count() {
@@ -830,26 +1059,40 @@ template <int PREC, int EPI, int MF>
 __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   constexpr bool SPLIT = PrecXPlanes(PREC) == 2;
   constexpr bool WSPLIT = PrecWPlanes(PREC) == 2;
+  constexpr bool MX = PrecMx(PREC);            // the second weight plane is the 4-bit residual, used once per four K steps
   constexpr bool F16 = PrecF16(PREC);
   constexpr bool SWAP = (EPI != kEpiStats);
   constexpr int NPX = SPLIT ? 2 : 1, NPW = WSPLIT ? 2 : 1;
   constexpr int TM = 64 * MF;                  // rows of a workgroup tile (4 waves x MF fragments x 16)
   constexpr int CH = MF / 2;                   // 16-row activation chunks each wave stages per tile (TM / 16 / 8)
-  constexpr int NH = MF / 4;                   // 64-row halves of a wave's rows (the epilogues work on 64 x 64)
+  constexpr int NH = MF / 4;                   // 64 x 64 blocks of a wave's tile (the epilogues work on 64 x 64)
+  // Wave tile.  MF = 4: 64 rows x 64 columns (waves 4 x 2).  MF = 8 ("wide"): 64 rows x all 128 columns (waves 8 x 1):
+  // 4 activation fragments against 8 weight fragments per step - the same 12 fragment reads and 32 products as
+  // 128 x 64, but every activation fragment is read, and in kPrecFp16Mx converted to 4 bits, by ONE wave instead of
+  // two (the conversions, 48 VALU instructions per wave and step with 128 x 64, cost 14 % of tdnn2 and 30 % of tdnn5).
+  constexpr bool WIDE = (MF == 8);
+  constexpr int XF = WIDE ? 4 : MF;            // activation fragments per wave
+  constexpr int WF = WIDE ? 8 : 4;             // weight fragments per wave
   constexpr int XT = (TM + 16) * kBK * 2;      // one activation plane slot (tile rows + halo of a time-offset group)
   constexpr int WT = kTileBytes;
   constexpr int XSLOT = NPX * XT;
   constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;
+  constexpr int KQ = MX ? 4 : 1;               // K steps are dealt out in units of KQ (a 128-deep block is never cut)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave & 3;
-  const int wave_n = wave >> 2;
+  const int row_w = WIDE ? wave * 64 : (wave & 3) * (16 * MF);   // first row / column of the wave's tile inside the
+  const int col_w = WIDE ? 0 : (wave >> 2) * 64;                 // workgroup tile
   const int group = wave >> 2;
   const int bid = blockIdx.x;
+#ifdef XV_PROBE_TIMING
+  const bool probe_on = (bid == 0) && (wave == 0 || wave == 4) && (tid & 63) == 0 && EPI == kEpiAct && a.total_ksteps == 48;
+  const int probe_w = wave >> 2;
+  int probe_i = 0;
+#endif
 
   // ---- this workgroup's share of the K steps ---------------------------------------------------------------------
   // XCD block `xcd` owns a contiguous range of whole ROW tiles.  Its G/8 workgroups form G/8/L groups of L "column
@@ -859,13 +1102,14 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // range of whole tiles per workgroup had 32 workgroups stream 32 different row tiles through a 4 MB L2: 1.3 GB of
   // fabric reads per tdnn2 launch against 0.38 GB for the per-tile kernel).
   const int S = a.total_ksteps;
+  const int SQ = S / KQ;
   const int G8 = gridDim.x >> 3;
   const int xcd = bid & 7, jb = bid >> 3;
   const int L = a.sk_lanes, cpl = a.n_tiles / L, Ng = G8 / L;
   const int col_lane = jb % L, grp_j = jb / L;
   const int tb0 = (int)((long)a.sk_mtiles * xcd / 8), tb1 = (int)((long)a.sk_mtiles * (xcd + 1) / 8);   // row tiles
-  const long steps_b = (long)(tb1 - tb0) * cpl * S;
-  const long s0 = steps_b * grp_j / Ng, s1 = steps_b * (grp_j + 1) / Ng;
+  const long steps_b = (long)(tb1 - tb0) * cpl * SQ;
+  const long s0 = steps_b * grp_j / Ng * KQ, s1 = steps_b * (grp_j + 1) / Ng * KQ;
   const int k_head = (int)(s0 % S), k_tail = (int)(s1 % S);
   const int t_first = (int)((s0 + S - 1) / S), t_end = (int)(s1 / S);   // whole tiles [t_first, t_end) of the block
   const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
@@ -875,93 +1119,151 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
   const int fr_i = lane & 15;
   const int fr_g = lane >> 4;
-  const int w_rd = (wave_n * 64 + fr_i) * 64 + (fr_g ^ ((fr_i >> 1) & 3)) * 16;
+  const int w_rd = (col_w + fr_i) * 64 + (fr_g ^ ((fr_i >> 1) & 3)) * 16;
   int w_rho;
   {
     const int rho = wave * 16 + ld_row;
     w_rho = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
   }
 
-  // ablation switches (timing experiments only, results are garbage): 1 no MFMAs, 2 no fragment
-  // reads, 4 no LDS-DMA, 8 no epilogue, 16 no activation DMA, 32 no weight DMA
-#ifdef XV_SK_ABLATE
-  const int dbg = a.stagger_units;
-#else
-  constexpr int dbg = 0;
-#endif
   // per-part state (set at the top of the part loop)
   int m0 = 0, n0 = 0;
   const uint16_t* wtile_hi = nullptr;   // weight row n0, wave-uniform
   const uint16_t* wtile_lo = nullptr;
+  const uint8_t* wtile_4 = nullptr;
   const unsigned woff = (unsigned)(w_rho * a.ldw + ld_chunk * 8) * 2u;   // this lane's row / chunk inside the tile
-  int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0;
+  const unsigned woff4 = MX ? (unsigned)(w_rho * a.ldw4 + ld_chunk * 16) : 0u;
+  int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0, istep = 0;
   bool force_x = true;
   Grp gi = a.grp[0];
-  auto issue_step = [&]() -> int {
+  // Address state of the activation DMA of the current (part, group), kept incremental: the 16-row chunks a wave stages
+  // are 128 rows apart (x128 bytes), a K chunk is 64 bytes further along the rows.  (Computed per instruction from
+  // scratch - 64-bit multiplies - the scalar code of a step's issue was longer than the issue itself; with the
+  // 1.25-pass arithmetic the LOAD segment, not the MFMA segment, sets the step time.)
+  const char* xrow_hi = nullptr;   // plane row m0 + shift0 + wave * 16, wave-uniform
+  const char* xrow_lo = nullptr;
+  int x128 = 0, xhalo = 0;         // bytes: 128 rows; from this wave's first chunk to the halo rows
+  unsigned xoff = 0;               // lane part of the address: (ld_row * ld + ld_chunk * 8) elements
+  auto bind_group = [&]() __attribute__((always_inline)) {
+    const long row0 = (long)(m0 + gi.shift0 + wave * 16) * gi.ld * 2;
+    xrow_hi = (const char*)gi.hi + row0;
+    xrow_lo = SPLIT ? (const char*)gi.lo + row0 : nullptr;
+    x128 = gi.ld * 256;
+    xhalo = (TM - wave * 16) * gi.ld * 2;
+    xoff = (unsigned)(ld_row * gi.ld + ld_chunk * 8) * 2u;
+  };
+  auto issue_step = [&]() __attribute__((always_inline)) -> int {
     int n = 0;
     if (ij == 0 || force_x) {
       force_x = false;
-      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT);
-      // lane part of the address: (ld_row * ld + ld_chunk * 8) elements; everything else is wave-uniform
-      const unsigned xoff = (unsigned)(ld_row * gi.ld + ld_chunk * 8) * 2u;
-      const long ubase = (long)(m0 + gi.shift0) * gi.ld + (long)ikk * kBK;
-      if (!(dbg & 16)) {
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int c = wave + 8 * u;
-        const long off = ubase + (long)(c * 16) * gi.ld;
-        glds16_sbase(gi.hi + off, xoff, st + c * 1024);
-        if constexpr (SPLIT) glds16_sbase(gi.lo + off, xoff, st + XT + c * 1024);
-      }
-      n += CH * NPX;
-      }
+      const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT + wave * 1024);
+      const char* xh = xrow_hi + ikk * (kBK * 2);
+      const char* xl = SPLIT ? xrow_lo + ikk * (kBK * 2) : nullptr;
       if (wave == 0 && gi.nshift > 1) {  // halo rows TM..TM+15 (only read by displaced offsets)
-        const long off = ubase + (long)TM * gi.ld;
-        glds16_sbase(gi.hi + off, xoff, st + (TM / 16) * 1024);
-        if constexpr (SPLIT) glds16_sbase(gi.lo + off, xoff, st + XT + (TM / 16) * 1024);
+        glds16_sbase(xh + xhalo, xoff, st + (TM / 16) * 1024);
+        if constexpr (SPLIT) glds16_sbase(xl + xhalo, xoff, st + XT + (TM / 16) * 1024);
         n += NPX;
       }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        glds16_sbase(xh, xoff, st + u * 8192);
+        if constexpr (SPLIT) glds16_sbase(xl, xoff, st + XT + u * 8192);
+        xh += x128;
+        if constexpr (SPLIT) xl += x128;
+      }
+      n += CH * NPX;
       ixslot = ixslot == 2 ? 0 : ixslot + 1;
     }
     {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
       const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
-      if (!(dbg & 32)) {
       glds16_sbase(wtile_hi + wcol, woff, st);
-      if constexpr (WSPLIT) glds16_sbase(wtile_lo + wcol, woff, st + WT);
-      n += NPW;
+      n += 1;
+      if constexpr (MX) {
+        // The 4-bit residual tile of block b = istep / 4 (8 KiB) travels with the block's second step into the
+        // residual half of weight slot b % 3: a ring of its own, three blocks deep.  It is read in the COMPUTE segment
+        // of the block's last step (after that step's fp16 MFMAs, into the registers of the fp16 weight fragments),
+        // which the step ring could not allow - the other wave group refills a step's slot one barrier interval
+        // after its LOAD segment.
+        if ((istep & 3) == 1) {
+          const unsigned st4 = __builtin_amdgcn_readfirstlane(lds_base + WBASE + ((istep >> 2) % 3) * WSLOT + WT + wave * 1024);
+          glds16_sbase(wtile_4 + (istep >> 2) * 64, woff4, st4);
+          n += 1;
+        }
+      } else if constexpr (WSPLIT) {
+        glds16_sbase(wtile_lo + wcol, woff, st + WT);
+        n += 1;
       }
       iwslot = iwslot == 2 ? 0 : iwslot + 1;
     }
+    ++istep;
     if (++ij == gi.nshift) {
       ij = 0;
       if (++ikk == gi.ksteps) {
         ikk = 0;
-        if (++ig < a.ngrp) gi = a.grp[ig];
+        if (++ig < a.ngrp) {
+          gi = a.grp[ig];
+          bind_group();
+        }
       }
     }
     return n;
   };
 
+  // kPrecFp16Mx: scales of the 4-bit copies.  Activations: one power of two per 16-row group of the OUTPUT rows (the
+  // producing epilogue recorded max |x| of every 16-row group of the source plane; rows displaced by a time offset
+  // belong to the same chunk wherever the output row is valid, and saturate mildly at worst - the term they feed
+  // is 2^-11 of the product).  max |x| = 1.m x 2^e  ->  x / 2^(e-2) in [4, 8): the top binade of e2m1 ([4, 6]).
+  constexpr int XW = (XF + 3) / 4, WW = WF / 4;
+  int xs_b[MX ? XW : 1];          // 2^(e-2) as E8M0 bytes, fragment f in byte f & 3 of word f >> 2
+  float xs_f[MX ? XF : 1];        // the same as floats: the divisor of the conversions
+  int ws_v[MX ? WW : 1];          // E8M0 scales of this lane's weight-fragment rows, fragment w in byte w & 3 of word w >> 2
+  auto load_xscales = [&](const unsigned* gmax) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      typedef __attribute__((ext_vector_type(XF))) unsigned uvec;
+      const unsigned* p = gmax + ((m0 + row_w) >> 4);
+      uvec g;
+      if constexpr (XF == 8) asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g) : "s"(p) : "memory");
+      else asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g) : "s"(p) : "memory");
+#pragma unroll
+      for (int h = 0; h < XW; ++h) xs_b[h] = 0;
+#pragma unroll
+      for (int f = 0; f < XF; ++f) {
+        unsigned e = (g[f] >> 23) & 255u;
+        e = e < 16u ? 16u : (e > 200u ? 200u : e);   // empty / all-zero groups, Inf / NaN maxima
+        xs_b[f >> 2] |= (int)((e - 2u) << (8 * (f & 3)));
+        xs_f[f] = __builtin_bit_cast(float, (e - 2u) << 23);
+      }
+    }
+  };
+
   int rg = 0, rkk = 0, rj = 0, rxslot = 0, rwslot = 0;
   int r_nshift = 1, r_ksteps = 1, r_dstep = 0;
   struct Frags {
-    s16x8 xh[MF], xl[SPLIT ? MF : 1], wh[4], wl[WSPLIT ? 4 : 1];
+    s16x8 xh[XF], xl[SPLIT ? XF : 1], wh[WF], wl[(WSPLIT && !MX) ? WF : 1];
   };
-  auto read_step = [&](Frags& f) {
+  int rblk = 0;   // kPrecFp16Mx: block (of four steps) the read side is in
+  bool xs_reload = false;   // the previous step was the last one of its group: fetch the next group's scales
+  auto read_step = [&](Frags& f) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      if (xs_reload) {   // a block of four steps never straddles two groups
+        load_xscales(a.grp[rg].gmax);
+        xs_reload = false;
+      }
+    }
     const char* xs = smem + rxslot * XSLOT;
     const char* ws = smem + WBASE + rwslot * WSLOT;
-    const int row = wave_m * (16 * MF) + fr_i + rj * r_dstep;  // displaced by the time offset of this step
+    const int row = row_w + fr_i + rj * r_dstep;  // displaced by the time offset of this step
     const int x_rd = row * 64 + (fr_g ^ ((row >> 1) & 3)) * 16;
 #pragma unroll
-    for (int i = 0; i < MF; ++i) {
+    for (int i = 0; i < XF; ++i) {
       f.xh[i] = *(const s16x8*)(xs + x_rd + i * 1024);
       if constexpr (SPLIT) f.xl[i] = *(const s16x8*)(xs + x_rd + XT + i * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WF; ++i) {
       f.wh[i] = *(const s16x8*)(ws + w_rd + i * 1024);
-      if constexpr (WSPLIT) f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
+      if constexpr (WSPLIT && !MX) f.wl[i] = *(const s16x8*)(ws + w_rd + WT + i * 1024);
     }
     rwslot = rwslot == 2 ? 0 : rwslot + 1;
     if (++rj == r_nshift) {
@@ -973,48 +1275,95 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           r_nshift = a.grp[rg].nshift;
           r_ksteps = a.grp[rg].ksteps;
           r_dstep = a.grp[rg].dstep;
+          if constexpr (MX) xs_reload = true;   // the COMPUTE segment of THIS step still converts with the old group's scales
         }
       }
     }
   };
 
-  f32x4 acc[NH][4][4];   // [64-row half][p][q] as in the other variants
-  auto mfmas = [&](const Frags& f) {
+  // [64 x 64 block][p][q] as in the other variants; block h = rows h * 64.. of a 128 x 64 wave tile, or columns h * 64..
+  // of a wide one.  XI / WI: activation / weight fragment behind index (h, v)
+  f32x4 acc[NH][4][4];
+  auto XI = [](int h, int v) __attribute__((always_inline)) { return WIDE ? v : h * 4 + v; };
+  auto WI = [](int h, int v) __attribute__((always_inline)) { return WIDE ? h * 4 + v : v; };
+  // The MFMAs of a step.  kPrecFp16Mx issues them from inline asm with the accumulator tied in place: left to itself
+  // hipcc (ROCm 7.2) un-ties destination and addend once the residual MFMAs sit in a branch of the loop, rotates the
+  // 128 accumulator registers through copies and spills 150-400 dwords per lane.  The asm is volatile, so the MFMAs stay
+  // in program order inside their COMPUTE segment (plain VALU work, the conversions, may still be scheduled between
+  // them); what the compiler no longer does for these
+  // instructions - wait states between an MFMA and a VALU instruction that reads its result or writes its operands - is
+  // done by hand where it can occur: before the residual MFMAs (their operands come from v_cvt) and after the K loop.
+  auto mfmas = [&](const Frags& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          if constexpr (SWAP) {
-            if constexpr (WSPLIT) acc[h][p][q] = mfma16<F16>(f.wl[p], f.xh[h * 4 + q], acc[h][p][q]);
-            if constexpr (SPLIT) acc[h][p][q] = mfma16<F16>(f.wh[p], f.xl[h * 4 + q], acc[h][p][q]);
-            acc[h][p][q] = mfma16<F16>(f.wh[p], f.xh[h * 4 + q], acc[h][p][q]);
+          if constexpr (MX) {
+            if constexpr (SWAP) mfma16_f16_inplace(f.wh[WI(h, p)], f.xh[XI(h, q)], acc[h][p][q]);
+            else mfma16_f16_inplace(f.xh[XI(h, p)], f.wh[WI(h, q)], acc[h][p][q]);
+          } else if constexpr (SWAP) {
+            if constexpr (WSPLIT) acc[h][p][q] = mfma16<F16>(f.wl[WI(h, p)], f.xh[XI(h, q)], acc[h][p][q]);
+            if constexpr (SPLIT) acc[h][p][q] = mfma16<F16>(f.wh[WI(h, p)], f.xl[XI(h, q)], acc[h][p][q]);
+            acc[h][p][q] = mfma16<F16>(f.wh[WI(h, p)], f.xh[XI(h, q)], acc[h][p][q]);
           } else {
-            if constexpr (SPLIT) acc[h][p][q] = mfma16<F16>(f.xl[h * 4 + p], f.wh[q], acc[h][p][q]);
-            if constexpr (WSPLIT) acc[h][p][q] = mfma16<F16>(f.xh[h * 4 + p], f.wl[q], acc[h][p][q]);
-            acc[h][p][q] = mfma16<F16>(f.xh[h * 4 + p], f.wh[q], acc[h][p][q]);
+            if constexpr (SPLIT) acc[h][p][q] = mfma16<F16>(f.xl[XI(h, p)], f.wh[WI(h, q)], acc[h][p][q]);
+            if constexpr (WSPLIT) acc[h][p][q] = mfma16<F16>(f.xh[XI(h, p)], f.wl[WI(h, q)], acc[h][p][q]);
+            acc[h][p][q] = mfma16<F16>(f.xh[XI(h, p)], f.wh[WI(h, q)], acc[h][p][q]);
           }
         }
       }
     }
   };
-  auto wait_and_barrier = [&](int n) {
+  // kPrecFp16Mx: 4-bit copies of the activation fragments of the four steps of a block (dword s = step s), and the
+  // block's residual MFMAs.  Lane (i, g) of a 16x16x128 operand holds K = 32 g .. 32 g + 31 of row i; here these are
+  // the columns 8 g .. 8 g + 7 of each of the four steps - the residual plane is packed to match (kernels.h).
+  i32x4 x4[MX ? XF : 1];
+  auto convert = [&](const Frags& f, const int s) __attribute__((always_inline)) {   // s is a constant at every call site
+    if constexpr (MX) {
+#pragma unroll
+      for (int i = 0; i < XF; ++i) {
+        x4[i][s] = cvt8_fp4(f.xh[i], xs_f[i], x4[i][s]);
+        // pin the conversion to its own step: hipcc otherwise sinks the conversions of a whole block in front of the
+        // residual MFMAs and keeps the fp16 fragments of four steps (96 registers) alive for it
+        asm volatile("" : "+v"(x4[i]));
+      }
+    }
+  };
+  auto mx_mfmas = [&](Frags& f) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      // the 4-bit weight fragments of the block go into the registers of the fp16 weight fragments (dead by now)
+      const char* w4s = smem + WBASE + (rblk % 3) * WSLOT + WT + w_rd;
+#pragma unroll
+      for (int w = 0; w < WF; ++w) f.wh[w] = *(const s16x8*)(w4s + w * 1024);
+      asm volatile("s_nop 4" ::: "memory");   // v_cvt results -> MFMA operands
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        static_for<0, 4>([&](auto P) {
+          static_for<0, 4>([&](auto Q) {
+            constexpr int p = decltype(P)::value, q = decltype(Q)::value;
+            // operand A of the instruction = first argument; its selector picks the byte of the scale word
+            if constexpr (SWAP) mfma_mx4_inplace<p, q>(f.wh[WI(h, p)], x4[XI(h, q)], acc[h][p][q], ws_v[WIDE ? h : 0], xs_b[WIDE ? 0 : h]);
+            else mfma_mx4_inplace<p, q>(x4[XI(h, p)], f.wh[WI(h, q)], acc[h][p][q], xs_b[WIDE ? 0 : h], ws_v[WIDE ? h : 0]);
+          });
+        });
+      }
+    }
+  };
+  auto wait_and_barrier = [&](int n) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    if (n == 0) wait_vm_lgkm0_barrier<0>();
-    else if (n == NPW) wait_vm_lgkm0_barrier<NPW>();
-    else if (n == NPW + CH * NPX) wait_vm_lgkm0_barrier<NPW + CH * NPX>();
-    else wait_vm_lgkm0_barrier<NPW + (CH + 1) * NPX>();
+    wait_vm_lgkm0_barrier_n(n);
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto plain_barrier = [&]() {
+  auto plain_barrier = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
   // position of K step k in the (group, chunk, offset) walk
-  auto seek = [&](int k, int& g, int& kk, int& jj) {
+  auto seek = [&](int k, int& g, int& kk, int& jj) __attribute__((always_inline)) {
     g = 0;
     for (;;) {
       const int n = a.grp[g].ksteps * a.grp[g].nshift;
@@ -1035,7 +1384,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // previous part's epilogue; the first wait of a part therefore drains everything (vmcnt(0): the epilogue's stores were
   // issued after these DMA instructions and the counter does not tell them apart).
   int kind = 0, n_steps = 0;   // kind 0: whole tile, 1: tail part (accumulators -> workspace), 2: head part
-  auto open_part = [&](int part) {
+  auto open_part = [&](int part) __attribute__((always_inline)) {
     // part order: tail (first K steps of the range's last tile), whole tiles, head (last K steps of its first tile)
     int tile, kb, ke;
     if (k_tail && part == 0) {
@@ -1052,18 +1401,32 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     m0 = mt * TM;
     n0 = nt * kBN;
     wtile_hi = a.w_hi + (long)n0 * a.ldw;
-    wtile_lo = WSPLIT ? a.w_lo + (long)n0 * a.ldw : nullptr;
+    wtile_lo = (WSPLIT && !MX) ? a.w_lo + (long)n0 * a.ldw : nullptr;
     seek(kb, ig, ikk, ij);
     gi = a.grp[ig];
+    bind_group();
     rg = ig; rkk = ikk; rj = ij;
     r_nshift = gi.nshift; r_ksteps = gi.ksteps; r_dstep = gi.dstep;
     ixslot = iwslot = rxslot = rwslot = 0;
+    istep = kb;
+    rblk = kb >> 2;
+    xs_reload = false;
     force_x = true;
     n_steps = ke - kb;
-    if (!(dbg & 4)) {
-      issue_step();
-      if (n_steps > 1) issue_step();
+    if constexpr (MX) {
+      wtile_4 = a.w4 + (long)n0 * a.ldw4;
+      load_xscales(gi.gmax);
+      // E8M0 scales of the weight rows behind this lane's four fragments (LDS row p * 16 + fr_i of the wave's slice)
+#pragma unroll
+      for (int h = 0; h < WW; ++h) {
+        const uint8_t* sp = a.w4_scale + n0 + col_w + h * 64;
+        ws_v[h] = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ws_v[h] |= (int)sp[SWAP ? swap_fields(p * 16 + fr_i) : p * 16 + fr_i] << (8 * p);
+      }
     }
+    issue_step();
+    if (n_steps > 1) issue_step();
   };
 
   open_part(0);
@@ -1073,11 +1436,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       // accumulators the previous workgroup of this block left for this tile (its first action).  The workspace is
       // fine-grained (coherent) device memory accessed with cache-bypassing loads / stores, the flag a relaxed
       // agent-scope atomic: acquire / release FENCES at agent scope would write back and invalidate the whole L2 of
-      // the XCD once per wave (measured ~70 us per launch).
+      // the XCD once per wave (measured ~70 us per launch).  The wait is bounded: a flag that does not arrive
+      // within ~2 s (a lost predecessor: the protocol only ever waits for a lower-numbered workgroup whose first
+      // action is the store waited for) raises the launch's error word, which the host checks (sk_check_error), and
+      // the workgroup goes on with whatever the slot holds instead of hanging the GPU.
       const int prev = bid - 8 * L;   // same lane, previous group
       if (tid == 0) {
-        while (__hip_atomic_load(a.sk_flags + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch)
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__hip_atomic_load(a.sk_flags + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
           __builtin_amdgcn_s_sleep(8);
+          if (__builtin_readcyclecounter() - t0 > 4000000000ull) {
+            __hip_atomic_store(a.sk_error, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
       }
       __syncthreads();
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1102,23 +1474,56 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     // Ping-pong schedule of v2 (two barrier intervals per K step; group 1 runs one interval behind group 0).  A
     // one-barrier-per-step form (group 0: LOAD_j, COMPUTE_j; group 1: COMPUTE_{j-1}, LOAD_j) was measured 6 % slower:
     // without the second barrier the groups drift into loading at the same time.
-    const bool do_dma = !(dbg & 4);
+    // The compiler-tracked loads of open_part (weight-row scales) are complete after this wait; saying so through the
+    // builtin keeps hipcc from putting its own vmcnt(0) in front of their first use INSIDE the K loop, where it
+    // would drain the LDS-DMA queue on every pass.
+    if constexpr (MX) __builtin_amdgcn_s_waitcnt(0x0f70);
     wait_and_barrier(0);               // the first two steps have landed (and the previous epilogue's stores are out)
     if (group == 1) plain_barrier();
     Frags f;
-    if (dbg & 2) read_step(f);
     const int ns = n_steps;
+    if constexpr (MX) {
+      // Blocks of four steps: three plain ones, then one whose COMPUTE segment also converts its fragments, fetches the
+      // block's 4-bit weight fragments and issues the MF x 4 residual MFMAs.  The loop is NOT unrolled by four (the
+      // copies cost ~50 registers of duplicated address state): the position inside the block only selects, through a
+      // wave-uniform switch, which dword of the 4-bit fragments the conversions write.
 #pragma nounroll
-    for (int j = 0; j < ns; ++j) {
-      if (dbg & 128) __builtin_amdgcn_s_setprio(2);
-      if (!(dbg & 2)) read_step(f);
-      const int n = (j + 2 < ns && do_dma) ? issue_step() : 0;
-      wait_and_barrier(n);
-      if (dbg & 128) __builtin_amdgcn_s_setprio(0);
-      if (!(dbg & 64)) __builtin_amdgcn_s_setprio(1);
-      if (!(dbg & 1)) mfmas(f);
-      if (!(dbg & 64)) __builtin_amdgcn_s_setprio(0);
-      plain_barrier();
+      for (int j = 0; j < ns; j += 4, ++rblk) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          XV_STAMP(1);
+          // the LOAD segment is the longer one in this mode (see the stamps in DESIGN.md): it gets the issue priority
+          __builtin_amdgcn_s_setprio(1);
+          read_step(f);
+          XV_STAMP(2);
+          const int n = (j + s + 2 < ns) ? issue_step() : 0;
+          XV_STAMP(3);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          XV_STAMP(4);
+          wait_and_barrier(n);
+          XV_STAMP(5);
+          __builtin_amdgcn_s_setprio(0);
+          mfmas(f);
+          convert(f, s);
+          if (s == 3) mx_mfmas(f);
+          XV_STAMP(6);
+          plain_barrier();
+          XV_STAMP(7);
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
+    } else {
+#pragma nounroll
+      for (int j = 0; j < ns; ++j) {
+        read_step(f);
+        const int n = (j + 2 < ns) ? issue_step() : 0;
+        wait_and_barrier(n);
+        __builtin_amdgcn_s_setprio(1);
+        mfmas(f);
+        __builtin_amdgcn_s_setprio(0);
+        plain_barrier();
+      }
     }
     if (group == 0) plain_barrier();
     // every wave is past its last LDS read: the rings may be refilled for the next part while this one's results go out
@@ -1141,68 +1546,109 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(a.sk_flags + bid, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (!(dbg & 8)) {
-      EpiRegs er;
-      epilogue_prefetch<EPI>(a, e_m0 + wave_m * (16 * MF), e_n0 + wave_n * 64, lane, er);
-      int first2[4], last2[4];   // statistics epilogue: valid-row table of the second 64-row half, fetched with the first
-      if constexpr (EPI == kEpiStats && NH == 2) {
+    } else {
+      if constexpr (WIDE) {
+        // two 64 x 64 blocks side by side: same rows, columns e_n0 and e_n0 + 64.  The group maxima of the planes
+        // epilogue are carried across both (one reduction and one atomic per 16-row group and wave).
+        float gm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int grp = (e_m0 + wave_m * (16 * MF) + 64 + p * 16) >> 4;
-          first2[p] = a.grp_range[2 * grp];
-          last2[p] = a.grp_range[2 * grp + 1];
+        for (int h = 0; h < NH; ++h) {
+          EpiRegs er;
+          epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + h * 64, lane, er);
+          gemm_epilogue<PREC, EPI>(a, acc[h], e_m0 + row_w, e_n0 + h * 64, lane, er, gm, h == 0 ? 1 : 2);
         }
-      }
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if constexpr (EPI == kEpiStats && NH == 2) {
-          if (h == 1) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-              er.first[p] = first2[p];
-              er.last[p] = last2[p];
-            }
-          }
-        }
-        gemm_epilogue<PREC, EPI>(a, acc[h], e_m0 + wave_m * (16 * MF) + h * 64, e_n0 + wave_n * 64, lane, er);
+      } else {
+        EpiRegs er;
+        epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + col_w, lane, er);
+        float gm[4] = {0.f, 0.f, 0.f, 0.f};
+        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0 + col_w, lane, er, gm, 0);
       }
     }
   }
 }
 
 // Workspace of the stream-K variant (one slot of raw accumulators + one flag per workgroup), per stream: launches on
-// different streams may overlap.  The epoch makes flags of earlier launches stale without clearing them.
+// different streams may overlap.  The epoch makes flags of earlier launches stale without clearing them.  Entries
+// belong to whoever owns the stream and are released through release_stream_workspace before the stream is destroyed.
 struct SkWorkspace {
   float* ws = nullptr;
   unsigned* flags = nullptr;
   size_t ws_bytes = 0;
   int grid = 0;
 };
-static hipError_t sk_workspace(hipStream_t s, int grid, size_t ws_bytes, SkWorkspace* out, unsigned* epoch) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SkWorkspace> table;
-  static unsigned next_epoch = 0;
-  std::lock_guard<std::mutex> lock(mu);
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk_table;
+static unsigned g_sk_epoch = 0;
+static unsigned* g_sk_error = nullptr;   // pinned host word, device-visible: written by a kernel whose flag wait timed out
+
+static void sk_free(SkWorkspace* w) {
+  if (w->ws) (void)hipFree(w->ws);
+  if (w->flags) (void)hipFree(w->flags);
+  *w = SkWorkspace();
+}
+
+static hipError_t sk_workspace(hipStream_t s, int grid, size_t ws_bytes, SkWorkspace* out, unsigned* epoch, unsigned** err) {
+  std::lock_guard<std::mutex> lock(g_sk_mu);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  SkWorkspace& w = table[std::make_pair(dev, s)];
+  if (!g_sk_error) {
+    if ((e = hipHostMalloc((void**)&g_sk_error, 64, hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess) return e;
+    *g_sk_error = 0;
+  }
+  SkWorkspace& w = g_sk_table[std::make_pair(dev, s)];
   if (w.ws_bytes < ws_bytes || w.grid < grid) {
     // (re)allocation: only ever on the first launches of a stream; hipFree synchronises the device
-    if (w.ws) (void)hipFree(w.ws);
-    if (w.flags) (void)hipFree(w.flags);
-    w = SkWorkspace();
+    sk_free(&w);
     // fine-grained = coherent across the XCDs' L2s without cache maintenance (the exchange happens inside a kernel)
-    if ((e = hipExtMallocWithFlags((void**)&w.ws, ws_bytes, hipDeviceMallocFinegrained)) != hipSuccess) return e;
-    if ((e = hipExtMallocWithFlags((void**)&w.flags, (size_t)grid * sizeof(unsigned), hipDeviceMallocFinegrained)) != hipSuccess) return e;
-    if ((e = hipMemset(w.flags, 0, (size_t)grid * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipExtMallocWithFlags((void**)&w.ws, ws_bytes, hipDeviceMallocFinegrained)) != hipSuccess) {
+      sk_free(&w);
+      return e;
+    }
+    if ((e = hipExtMallocWithFlags((void**)&w.flags, (size_t)grid * sizeof(unsigned), hipDeviceMallocFinegrained)) != hipSuccess ||
+        (e = hipMemset(w.flags, 0, (size_t)grid * sizeof(unsigned))) != hipSuccess) {
+      sk_free(&w);
+      return e;
+    }
     w.ws_bytes = ws_bytes;
     w.grid = grid;
   }
-  if (++next_epoch == 0) ++next_epoch;   // 0 is the cleared state
-  *epoch = next_epoch;
+  if (++g_sk_epoch == 0) ++g_sk_epoch;   // 0 is the cleared state
+  *epoch = g_sk_epoch;
+  *err = g_sk_error;
   *out = w;
   return hipSuccess;
+}
+
+void release_stream_workspace(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  auto it = g_sk_table.find(std::make_pair(dev, s));
+  if (it == g_sk_table.end()) return;
+  sk_free(&it->second);
+  g_sk_table.erase(it);
+}
+
+#ifdef XV_PROBE_TIMING
+extern "C" int xv_probe_dump(unsigned long long* out, int cap) {
+  unsigned long long h[2][512];
+  int n[2];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof h) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_probe_n), sizeof n) != hipSuccess) return -1;
+  int k = 0;
+  for (int w = 0; w < 2; ++w)
+    for (int i = 0; i < n[w] && k + 2 <= cap; ++i) {
+      out[k++] = (unsigned long long)w;
+      out[k++] = h[w][i];
+    }
+  return k;
+}
+#endif
+
+unsigned sk_last_error() {
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  return g_sk_error ? *(volatile unsigned*)g_sk_error : 0u;
 }
 
 // True when the stream-K variant with MF fragments per wave can run this launch.
@@ -1248,16 +1694,8 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
       while (l > 1 && (a.n_tiles % l || (grid / 8) % l)) l >>= 1;
       b.sk_lanes = l;
     }
-    {
-      static int dbg = -1;
-      if (dbg < 0) {
-        const char* e = getenv("XVEC_SK_ABLATE");
-        dbg = (e && *e) ? atoi(e) : 0;
-      }
-      b.stagger_units = dbg;
-    }
     SkWorkspace w;
-    hipError_t e = sk_workspace(s, grid, (size_t)grid * 64 * MF * kBN * sizeof(float), &w, &b.sk_epoch);
+    hipError_t e = sk_workspace(s, grid, (size_t)grid * 64 * MF * kBN * sizeof(float), &w, &b.sk_epoch, &b.sk_error);
     if (e != hipSuccess) return e;
     b.sk_ws = w.ws;
     b.sk_flags = w.flags;
@@ -1304,7 +1742,13 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   // default policy (same box, 256 x 400 workload): two-pass mode - stream-K for every layer; three-pass and single-pass
   // modes - stream-K only for the long-K layers (tdnn2 / tdnn3, 48 K steps: -5 % / -9 %), the short-K ones are faster
   // on the per-tile kernel there (tdnn5 single-pass: 0.190 vs 0.229 ms)
-  const bool sk_default = PREC == kPrecFp16x2 || a.total_ksteps >= 32;
+  const bool sk_default = PREC == kPrecFp16x2 || PREC == kPrecFp16Mx || a.total_ksteps >= 32;
+  if constexpr (PrecMx(PREC)) {
+    // 512-row stream-K tiles or the 256-row per-tile kernel (bit-identical); nothing else implements the mode
+    if (!gemm_mx_applicable(a)) return hipErrorInvalidValue;
+    if (variant != 2 && variant != 1 && sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
+    return launch_one_v2<PREC, EPI>(a, s);
+  }
   if (variant == 4 || (variant == 0 && sk_default)) {
     if (sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
     if ((variant == 4 || PrecXPlanes(PREC) == 2) && sk_applicable<PREC, 4>(a)) return launch_one_sk<PREC, EPI, 4>(a, s);
@@ -1390,6 +1834,12 @@ static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC>
 static hipError_t launch_prec(const GemmArgs& a, int epi, hipStream_t s) {
+  if constexpr (PrecMx(PREC)) {   // frame-level layers only: planes out or pooled statistics
+    if (a.ksplit > 1) return hipErrorInvalidValue;
+    if (epi == kEpiAct) return launch_one<PREC, kEpiAct>(a, s);
+    if (epi == kEpiStats) return launch_one<PREC, kEpiStats>(a, s);
+    return hipErrorInvalidValue;
+  }
   if (a.ksplit > 1 && a.splitk_ws) {
     if (epi == kEpiAct) return launch_splitk<PREC, kEpiAct>(a, s);
     if (epi == kEpiF32) return launch_splitk<PREC, kEpiF32>(a, s);
@@ -1411,6 +1861,7 @@ hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipS
     case kPrecFp16: return launch_prec<kPrecFp16>(a, epilogue, s);
     case kPrecFp16x3: return launch_prec<kPrecFp16x3>(a, epilogue, s);
     case kPrecFp16x2: return launch_prec<kPrecFp16x2>(a, epilogue, s);
+    case kPrecFp16Mx: return launch_prec<kPrecFp16Mx>(a, epilogue, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1424,6 +1875,8 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
   const int per_row = a.ld >> 3;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)a.rows * per_row;
+  // the group-max tables of this pass (kPrecFp16Mx) are cleared by the first kernel of the pass
+  for (long z = idx; z < a.n_zero_words; z += (long)gridDim.x * blockDim.x) a.zero_words[z] = 0u;
   if (idx >= total) return;
   const int row = (int)(idx / per_row);
   const int c8 = (int)(idx - (long)row * per_row) * 8;

@@ -281,6 +281,7 @@ int main(int argc, char** argv) {
     else if (opt.precision == "fp16x3") precision = xv::kPrecFp16x3;
     else if (opt.precision == "fp16x2") precision = xv::kPrecFp16x2;
     else if (opt.precision == "auto") precision = xv::kPrecAuto;
+    else if (opt.precision == "fp16mx") precision = xv::kPrecFp16Mx;
     else {
       fprintf(stderr, "%s: invalid --precision=%s\n", kProg, opt.precision.c_str());
       return 1;

@@ -72,8 +72,8 @@ def test_v2_fp16x3_parity(v2):
 
 
 def test_v2_auto_mode_parity_and_batch_invariance(v2):
-    """XV_PREC_AUTO: chunks that pool >= 300 frames take the two-pass kernels (fp16 activations x split-fp16 weights),
-    shorter ones the three-pass ones.  Every chunk stays within the parity tolerance, and which arithmetic a chunk
+    """XV_PREC_AUTO: chunks that pool >= 300 frames take the fast kernels (fp16 activations x fp16 weights + the
+    block-scaled 4-bit residual product, XV_PREC_FP16MX), shorter ones the three-pass ones.  Every chunk stays within the parity tolerance, and which arithmetic a chunk
     gets depends on its own length only: solo == batched == permuted, bit for bit."""
     P, net, line, model = v2
     ctx = P.Context(model, precision=P.PREC_AUTO)
@@ -96,9 +96,9 @@ def test_v2_auto_mode_parity_and_batch_invariance(v2):
     for sel in ([0, 4, 5, 11], [2, 3, 6, 10]):
         f3, o3 = H.pack([utts[i] for i in sel])
         assert np.array_equal(ctx.forward_batch(f3, o3), out[sel])
-    # the long chunks really took the two-pass arithmetic, the short ones the three-pass one
+    # the long chunks really took the fast arithmetic, the short ones the three-pass one
     x3 = P.Context(model, precision=P.PREC_FP16X3)
-    x2 = P.Context(model, precision=P.PREC_FP16X2)
+    x2 = P.Context(model, precision=P.PREC_FP16MX)
     assert np.array_equal(x2.forward_batch(utts[0], [0, 400])[0], out[0])
     assert np.array_equal(x3.forward_batch(utts[1], [0, 215])[0], out[1])
     assert not np.array_equal(x3.forward_batch(utts[0], [0, 400])[0], out[0])

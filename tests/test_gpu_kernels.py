@@ -194,3 +194,152 @@ def test_gemm_stream_k_variant(prec, epi):
         assert (np.abs(out - ref) / scale).max() < 3e-5
     else:
         assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[prec] + (OUT_Q[prec] if epi == 0 else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# XV_PREC_FP16MX: fp16 product + block-scaled 4-bit residual product.  The reference below restates the arithmetic
+# exactly (what is quantised how, with which scale), so the tolerance is again fp32 accumulation order only.
+E2M1 = [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]
+
+
+def _q_e2m1(t, torch):
+    """round to nearest (ties to even code) onto the e2m1 grid, saturating at 6 - v_cvt_scalef32_pk_fp4_f16"""
+    a = t.abs()
+    idx = ((a > 0.25).long() + (a >= 0.75).long() + (a > 1.25).long() + (a >= 1.75).long() + (a > 2.5).long() +
+           (a >= 3.5).long() + (a > 5.0).long())
+    grid = torch.tensor(E2M1, dtype=t.dtype, device=t.device)
+    return torch.sign(t) * grid[idx]
+
+
+def _gmax_bits(plane_abs_max, torch):
+    """float32 bit patterns of the group maxima, as the producing epilogue records them"""
+    return plane_abs_max.float().view(torch.int32)
+
+
+def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
+    torch = _torch()
+    P = _pkg()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dev = torch.device("cuda:0")
+    nsrc = max(s[0] for s in segs) + 1
+    src_ld = {}
+    for s in segs:
+        src_ld[s[0]] = max(src_ld.get(s[0], 0), s[1])
+    amp = 16.0
+    # activations with a different magnitude in every 16-row group (the per-group scales matter), all of ld columns
+    X = []
+    for i in range(nsrc):
+        x = torch.randn(rows + 2 * HALO, src_ld[i], generator=g) * amp
+        gs = torch.exp(torch.randn((rows + 2 * HALO) // 16, generator=g).clamp(-2, 2) * 1.5).repeat_interleave(16)[:, None]
+        X.append((x * gs).to(dev))
+    K = sum(s[3] for s in segs)
+    W = (torch.randn(n_pad, K, generator=g) * (amp * amp / np.sqrt(K))).to(dev)
+    bias = (torch.randn(n_pad, generator=g) * 0.1).to(dev)
+    scale = ((torch.rand(n_pad, generator=g) + 0.5) / 256).to(dev)   # keeps the fp16 output plane far from its range limit
+    offset = (torch.randn(n_pad, generator=g) * 0.1).to(dev)
+    Xh = [x.to(torch.float16) for x in X]
+    Wh = W.to(torch.float16)
+    # residual plane + row scales from the library's own packer (the same code xv_model_pack runs)
+    w4, w4s = P.pack_mx_residual(W.cpu().numpy(), Wh.cpu().view(torch.int16).numpy().view(np.uint16),
+                                 [(s[0], s[2], s[3]) for s in segs])
+    w4_d, w4s_d = torch.from_numpy(w4).to(dev), torch.from_numpy(w4s).to(dev)
+    # group maxima of the source planes (rows relative to logical row 0)
+    gmax = []
+    for i in range(nsrc):
+        body = Xh[i][HALO:HALO + rows].float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))
+        gmax.append(_gmax_bits(body, torch).contiguous())
+
+    d = P.GemmDesc()
+    d.precision, d.epilogue, d.nseg = P.PREC_FP16MX, epi, len(segs)
+    for j, (si, ld, shift, klen) in enumerate(segs):
+        d.seg[j].hi = Xh[si].data_ptr() + HALO * src_ld[si] * 2
+        d.seg[j].lo = None
+        d.seg[j].ld, d.seg[j].row_shift, d.seg[j].k_len = src_ld[si], shift, klen
+        d.seg[j].gmax = gmax[si].data_ptr()
+    d.w_hi, d.w_lo, d.ldw = Wh.data_ptr(), None, K
+    d.w4, d.ldw4, d.w4_scale = w4_d.data_ptr(), K // 128 * 64, w4s_d.data_ptr()
+    d.rows, d.n_pad = rows, n_pad
+    d.bias, d.scale, d.offset = bias.data_ptr(), scale.data_ptr(), offset.data_ptr()
+    d.relu, d.bn = 1, 1
+    d.hip_stream = None
+
+    # ---- reference: fp16 x . fp16 w_hi + q4(x / sx) sx . q4((w - w_hi) / sw) sw, in fp64
+    Whd = Wh.double()
+    R = W.double() - Whd
+    e8 = w4s_d.double()
+    sw = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev), e8 - 127)[:, None]
+    Rq = _q_e2m1(R / sw, torch) * sw
+    z = torch.zeros(rows, n_pad, dtype=torch.float64, device=dev)
+    k0 = 0
+    for (si, ld, shift, klen) in segs:
+        xs = Xh[si][HALO + shift: HALO + shift + rows, :klen].double()
+        # scale of OUTPUT row r = 2^(e - 2 - 127), e = exponent field of the maximum of r's 16-row group of the source plane
+        ebits = ((gmax[si] >> 23) & 255).clamp(16, 200).double().repeat_interleave(16)[:, None]
+        sx = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev), ebits - 2 - 127)
+        x4 = _q_e2m1(xs / sx, torch) * sx
+        z += xs @ Whd[:, k0:k0 + klen].T + x4 @ Rq[:, k0:k0 + klen].T
+        k0 += klen
+    z = torch.clamp(z + bias.double(), min=0) * scale.double() + offset.double()
+
+    torch.cuda.synchronize()
+    if epi == P.EPI_ACT:
+        oh = torch.zeros(rows, n_pad, dtype=torch.float16, device=dev)
+        gm_out = torch.zeros(rows // 16, dtype=torch.int32, device=dev)
+        d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), None, n_pad
+        d.gmax_out = gm_out.data_ptr()
+        P.kernel_tdnn_gemm(d)
+        torch.cuda.synchronize()
+        # the recorded group maxima are those of the fp32 results before the fp16 rounding of the plane
+        want = z.float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))
+        got = gm_out.view(torch.float32)
+        assert torch.allclose(got, want, rtol=1e-4, atol=0), (got[:4], want[:4])
+        return oh.double().cpu().numpy(), z.cpu().numpy()
+    ngrp = rows // 16
+    rng = np.random.default_rng(seed)
+    first = rng.integers(0, 10, ngrp).astype(np.int8)
+    last = np.minimum(16, first + rng.integers(0, 17, ngrp)).astype(np.int8)
+    gr = torch.from_numpy(np.stack([first, last], 1).copy()).to(dev)
+    part = torch.zeros(ngrp, 2, n_pad, dtype=torch.float32, device=dev)
+    d.partial, d.ldp, d.grp_range = part.data_ptr(), n_pad, gr.data_ptr()
+    P.kernel_tdnn_gemm(d)
+    torch.cuda.synchronize()
+    zz = z.cpu().numpy().reshape(ngrp, 16, n_pad)
+    mask = (np.arange(16)[None, :] >= first[:, None]) & (np.arange(16)[None, :] < last[:, None])
+    ref = np.stack([(zz * mask[:, :, None]).sum(1), (zz * zz * mask[:, :, None]).sum(1)], 1)
+    return part.double().cpu().numpy(), ref
+
+
+TDNN3 = [(0, 512, -3, 512), (0, 512, 0, 512), (0, 512, 3, 512)]
+CVEC5_MX = [(0, 512, 0, 512), (1, 128, 0, 128)]      # two sources, each a whole number of 128-column blocks
+
+
+@pytest.mark.parametrize("segs", [TDNN2, TDNN3, [(0, 512, 0, 512)], CVEC5_MX], ids=["tdnn2", "tdnn3", "tdnn4", "cvec5"])
+def test_gemm_mx_act_per_tile_kernel(segs):
+    # 3 x 256 rows: too few tiles for the persistent grid -> the 256-row per-tile kernel
+    out, ref = _run_mx_case(0, 768, 512, segs, seed=11)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + OUT_Q[4]
+
+
+def test_gemm_mx_stats_per_tile_kernel():
+    out, ref = _run_mx_case(2, 512, 1536, [(0, 512, 0, 512)], seed=12)
+    scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+    assert (np.abs(out - ref) / scale).max() < 3e-5
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX], ids=["tdnn3", "cvec5"])
+def test_gemm_mx_stream_k(epi, segs):
+    # 66 x 512 rows x 4 column tiles on 256 workgroups: heads, whole tiles and tails, cut at multiples of four steps
+    out, ref = _run_mx_case(epi, 66 * 512, 512, segs, seed=13)
+    if epi == 2:
+        scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+        assert (np.abs(out - ref) / scale).max() < 3e-5
+    else:
+        assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + OUT_Q[4]
+
+
+def test_gemm_mx_refuses_unsuitable_launch():
+    P = _pkg()
+    with pytest.raises(P.XvError):
+        # two sources of two K steps each: no 128-column block of the walk lies inside one source
+        _run_mx_case(0, 768, 512, [(0, 64, 0, 64), (1, 64, 0, 64)], seed=1)

@@ -1,0 +1,169 @@
+"""CPU study (fp64 graph evaluator of the test oracle, no GPU, no product code) of arithmetic schemes that cost LESS
+than two fp16 MFMA passes per product - the question VERDICT r01 item 1 asks to settle by simulation first:
+
+  anti<k>   k single-plane fp16 weight images w_1..w_k with w_j = fp16(j*w - sum_{i<j} w_i) ("sigma-delta" / antithetic
+            rounding), image (t // 16) % k used for frame t: one pass, the weight rounding error alternates over the
+            frames of a chunk instead of being the same in all of them.
+  mx<a><w>  fp16 x . fp16 w_hi  +  q_a(x) . q_w(w - w_hi): the second pass of fp16x2 replaced by a block-scaled
+            v_mfma_scale_f32_16x16x128_f8f6f4 on narrow operands (fp4 e2m1 / fp6 e2m3 / fp8 e4m3), i.e. 1.25 passes
+            (fp4 / fp6 operands, 4x the fp16 rate) or 1.5 passes (an fp8 operand, 2x).  The weight residual uses one
+            power-of-two scale per (output row, 32-element K block) like the MX formats; the activations one fixed scale.
+
+usage: sim_precision2.py [topology] [T ...]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+
+
+def q16(x):
+    return x.astype(np.float16).astype(np.float64)
+
+
+def _grid(ebits, mbits, bias, emax_code=None):
+    """positive values of a small float format (no inf / nan codes), ascending"""
+    vals = [0.0]
+    for e in range(0, 1 << ebits):
+        for m in range(0, 1 << mbits):
+            if e == 0:
+                v = m / (1 << mbits) * 2.0 ** (1 - bias)
+            else:
+                v = (1 + m / (1 << mbits)) * 2.0 ** (e - bias)
+            vals.append(v)
+    return np.unique(np.array(vals))
+
+
+GRIDS = {"4": _grid(2, 1, 1), "6": _grid(2, 3, 1), "b6": _grid(3, 2, 3),
+         "8": _grid(4, 3, 7)[:-1]}   # e4m3fn: the top mantissa code of the top exponent is NaN -> max 448
+
+
+def qgrid(x, grid):
+    """round to nearest grid value (saturating), sign-symmetric"""
+    a = np.abs(x)
+    i = np.clip(np.searchsorted(grid, a), 1, len(grid) - 1)
+    lo, hi = grid[i - 1], grid[i]
+    r = np.where(a - lo <= hi - a, lo, hi)
+    return np.sign(x) * r
+
+
+def q_block_scaled(w, grid, block=32, axis=0):
+    """MX style: one power-of-two scale per `block` consecutive elements along `axis` (K), chosen so that the block
+    maximum lands in the top binade of the element format"""
+    w = np.moveaxis(w, axis, -1)
+    shp = w.shape
+    k = shp[-1]
+    pad = (-k) % block
+    wp = np.pad(w, [(0, 0)] * (w.ndim - 1) + [(0, pad)])
+    b = wp.reshape(shp[:-1] + ((k + pad) // block, block))
+    m = np.abs(b).max(axis=-1, keepdims=True)
+    gmax = grid[-1]
+    with np.errstate(divide="ignore"):
+        e = np.where(m > 0, np.ceil(np.log2(np.where(m > 0, m, 1) / gmax)), 0.0)
+    s = 2.0 ** e
+    q = qgrid(b / s, grid) * s
+    q = q.reshape(shp[:-1] + (k + pad,))[..., :k]
+    return np.moveaxis(q, -1, axis)
+
+
+class SchemeEval(H.xo.GraphEvaluator):
+    def __init__(self, net, scheme):
+        super().__init__(net, np.float64)
+        self.scheme = scheme
+        self.cache = {}
+
+    def _apply(self, w, x):
+        if w[0] == "affine" and x.shape[0] > 1:
+            W, b = w[1], w[2]           # W: [K, N]
+            key = id(W)
+            sc = self.scheme
+            xq = q16(x)
+            if sc[0] == "fp16":
+                if key not in self.cache:
+                    self.cache[key] = q16(W)
+                return xq @ self.cache[key] + b
+            if sc[0] == "fp16x2":
+                return xq @ W + b
+            if sc[0] == "anti":
+                k, blk = sc[1], sc[2]
+                if key not in self.cache:
+                    imgs, tot = [], np.zeros_like(W)
+                    for j in range(1, k + 1):
+                        wj = q16(j * W - tot)
+                        imgs.append(wj)
+                        tot = tot + wj
+                    self.cache[key] = imgs
+                imgs = self.cache[key]
+                out = np.empty((x.shape[0], W.shape[1]))
+                sel = (np.arange(x.shape[0]) // blk) % k
+                for j in range(k):
+                    out[sel == j] = xq[sel == j] @ imgs[j]
+                return out + b
+            if sc[0] == "mx":
+                fa, fw, sx, refine = sc[1], sc[2], sc[3], sc[4]
+                wblock = sc[5] if len(sc) > 5 else 32
+                if key not in self.cache:
+                    wh = q16(W)
+                    if refine:
+                        # pick w_hi among the two neighbouring fp16 values so that the residual is best representable
+                        up = np.nextafter(wh.astype(np.float16), np.float16(np.inf)).astype(np.float64)
+                        dn = np.nextafter(wh.astype(np.float16), np.float16(-np.inf)).astype(np.float64)
+                        alt = np.where(W >= wh, up, dn)
+                        best_h, best_l = wh, q_block_scaled(W - wh, GRIDS[fw])
+                        # the block scale depends on the whole block; one refinement sweep with the scale of pass one
+                        l_alt = q_block_scaled(W - alt, GRIDS[fw])
+                        better = np.abs(W - alt - l_alt) < np.abs(W - best_h - best_l)
+                        wh = np.where(better, alt, wh)
+                    wl = q_block_scaled(W - wh, GRIDS[fw], block=wblock if wblock else W.shape[0])
+                    self.cache[key] = (wh, wl)
+                wh, wl = self.cache[key]
+                if isinstance(sx, str):     # "auto*f": power-of-two scale that maps this input's max to the format's max, times f
+                    f = float(sx.split("*")[1]) if "*" in sx else 1.0
+                    sx = 2.0 ** np.ceil(np.log2(np.abs(xq).max() / GRIDS[fa][-1])) * f
+                xa = qgrid(xq / sx, GRIDS[fa]) * sx
+                return xq @ wh + xa @ wl + b
+            raise ValueError(sc)
+        return super()._apply(w, x)
+
+
+def main():
+    topo = sys.argv[1] if len(sys.argv) > 1 else "v2_xvector"
+    lens = [int(a) for a in sys.argv[2:]] or [400, 314, 137]
+    schemes = {
+        "fp16 (1 pass)": ("fp16",),
+        "fp16x2 (2 passes)": ("fp16x2",),
+        "mx x4.w4 blk32": ("mx", "4", "4", "auto", False, 32),
+        "mx x4.w4 blk128": ("mx", "4", "4", "auto", False, 128),
+        "mx x4.w4 per-row": ("mx", "4", "4", "auto", False, 0),
+        "mx x4.w4 per-row x*.5": ("mx", "4", "4", "auto*.5", False, 0),
+        "mx x4.w4 per-row x*.25": ("mx", "4", "4", "auto*.25", False, 0),
+        "mx x4.w4 per-row x*2": ("mx", "4", "4", "auto*2", False, 0),
+        "mx x4.w6 blk32": ("mx", "4", "6", "auto", False, 32),
+        "mx x4.w6 per-row": ("mx", "4", "6", "auto", False, 0),
+        "mx x4.w6 per-row x*.5": ("mx", "4", "6", "auto*.5", False, 0),
+    }
+    for seed in (123, 7, 2024):
+        net, line = H.synth_model(topo, seed)
+        n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+        n2.apply_nnet_config(line)
+        ev64 = H.xo.GraphEvaluator(n2, np.float64)
+        evs = {k: SchemeEval(n2, v) for k, v in schemes.items()}
+        for T in lens:
+            errs = {k: [] for k in schemes}
+            for i in range(4):
+                x = H.features(i + 10 * (seed % 7), T)
+                ref = ev64.compute(x)
+                for k, ev in evs.items():
+                    errs[k].append(H.rel_err(ev.compute(x), ref))
+            print("model seed %d  T=%d" % (seed, T))
+            for k in schemes:
+                print("   %-24s max %.2e  mean %.2e" % (k, max(errs[k]), float(np.mean(errs[k]))))
+            sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
