@@ -289,6 +289,26 @@ class Context:
         return out, ok.astype(bool)
 
 
+def create_broadcast(model, devices, precision=PREC_AUTO):
+    """xv_ctx_create_broadcast: one process, one context per listed GPU; the packed weights are uploaded to the first
+    device and broadcast with ONE ncclBroadcast (RCCL), each context is built from the image its device received."""
+    L = lib()
+    n = len(devices)
+    devs = (ctypes.c_int * n)(*devices)
+    handles = (ctypes.c_void_p * n)()
+    _check(L.xv_ctx_create_broadcast(model._h, devs, n, precision, handles))
+    out = []
+    for i in range(n):
+        c = Context.__new__(Context)
+        c._h = ctypes.c_void_p(handles[i])
+        mi = ModelInfo()
+        p, d = ctypes.c_int32(), ctypes.c_int32()
+        _check(L.xv_ctx_info(c._h, ctypes.byref(mi), ctypes.byref(p), ctypes.byref(d)))
+        c.info, c.precision, c.device = mi, p.value, d.value
+        out.append(c)
+    return out
+
+
 def plan_chunks(num_rows, chunk_size, min_chunk_size, pad_input, min_net_frames, cap=4096):
     """[(start, len, left_pad, right_pad)] or None when the utterance counts as failed (host logic, no GPU)."""
     arr = [(ctypes.c_int32 * cap)() for _ in range(4)]

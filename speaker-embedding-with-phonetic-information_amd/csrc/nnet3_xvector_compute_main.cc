@@ -38,7 +38,7 @@ bool g_apply_exp = false;
 int g_verbose = 0;
 
 void LogLine(const char* level, int line, const std::string& msg) {
-  fprintf(stderr, "%s (%s[xvec-hip-0.1]:main():nnet3_xvector_compute_main.cc:%d) %s\n", level, kProg, line, msg.c_str());
+  fprintf(stderr, "%s (%s[xvec-hip-0.2]:main():nnet3_xvector_compute_main.cc:%d) %s\n", level, kProg, line, msg.c_str());
 }
 #define XLOG(msg)                        \
   do {                                   \
@@ -68,11 +68,15 @@ const char* kUsage =
     "  --pad-input=true|false           pad short chunks by edge replication instead of skipping (default true)\n"
     "  --output-node=<name>             compute this node as the output (native form of nnet3-copy --nnet-config)\n"
     "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
-    "  --precision=bf16x3|fp16x3|fp16x2|auto|bf16|fp16\n"
-    "                                   arithmetic of the MFMA GEMMs (default auto = fp16x2, i.e. fp16 activations x\n"
-    "                                   split-fp16 weights, for chunks that pool >= 300 frames, fp16x3 for shorter\n"
-    "                                   ones and for frame-level outputs; bf16x3 / fp16x3: fp32-grade everywhere)\n"
-    "  --fast-min-pooled=<int>          --precision=auto: chunks that pool at least this many frames take the two-pass\n"
+    "  --precision=fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
+    "                                   arithmetic of the MFMA GEMMs.  Default fp16x3 (split fp16, three MFMAs per\n"
+    "                                   product): fp32-grade results on any model.  auto: chunks that pool >= 300 frames\n"
+    "                                   run fp16mx (fp16 activations x fp16 weights + a block-scaled 4-bit residual\n"
+    "                                   product, 1.25 MFMA passes, ~1.8x faster), the others fp16x3; the error of the\n"
+    "                                   fast chunks is the fp16 rounding of the activations averaged by the pooling -\n"
+    "                                   within 1e-4 on models with Kaldi-initialisation-like weights, 1-3e-4 on\n"
+    "                                   heavy-tailed ones (DESIGN.md section 3.0): check it on your model first.\n"
+    "  --fast-min-pooled=<int>          --precision=auto: chunks that pool at least this many frames take the fast\n"
     "                                   kernels (default 300, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
@@ -92,7 +96,7 @@ struct Options {
   bool pad_input = true;
   std::string output_node;
   std::string nnet_config;
-  std::string precision = "auto";
+  std::string precision = "fp16x3";
   int batch_frames = 1 << 17;
   int fast_min_pooled = -1;
   int device = -1;
@@ -388,7 +392,7 @@ int main(int argc, char** argv) {
     write_profile(res);
     return res.num_success != 0 ? 0 : 1;
   } catch (const std::exception& e) {
-    fprintf(stderr, "ERROR (%s[xvec-hip-0.1]:main()) %s\n", kProg, e.what());
+    fprintf(stderr, "ERROR (%s[xvec-hip-0.2]:main()) %s\n", kProg, e.what());
     return -1;
   }
 }

@@ -40,12 +40,19 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   if (!opt.backend_transform.empty() && opt.backend_t_cols != E && opt.backend_t_cols != E + 1)
     throw KioError("Dimension mismatch: the embedding has dimension " + std::to_string(E) + " and --backend-transform has " +
                    std::to_string(opt.backend_t_cols) + " columns");
+  // everything that can fail on a user error (unreadable VAD table, unwritable output) happens BEFORE the reader
+  // thread exists; what can still throw afterwards unwinds through ReaderGuard, which stops and joins the thread
+  // (a joinable std::thread destroyed by unwinding would call std::terminate: SIGABRT instead of "ERROR ..." + 255)
+  const bool use_frontend = opt.cmn_window > 0 || !opt.vad_rspecifier.empty();
+  std::unique_ptr<RandomAccessVectorReader> vad;
+  if (!opt.vad_rspecifier.empty()) vad.reset(new RandomAccessVectorReader(opt.vad_rspecifier));
   TableWriter writer(vec_wspec);
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Batch> queue;
   std::string reader_error;
   long num_fail_read = 0;
+  bool stop = false;   // under mu: the consumer is gone, the reader must not block on a full queue
   auto warn = [&](const std::string& m) { log("WARNING", m); };
 
   std::thread reader([&] {
@@ -58,13 +65,18 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       auto push = [&](bool last) {
         cur.last = last;
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return queue.size() < 2; });
+        cv.wait(lk, [&] { return queue.size() < 2 || stop; });
+        if (stop) return;
         queue.push_back(std::move(cur));
         cur = Batch();
         rows = 0;
         cv.notify_all();
       };
       while (rd.Next(&key, &m, &e)) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          if (stop) break;
+        }
         if (!e.empty()) {
           warn("failed to read features for " + key + ": " + e);
           ++num_fail_read;
@@ -89,6 +101,21 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       cv.notify_all();
     }
   });
+  struct ReaderGuard {
+    std::thread& t;
+    std::mutex& mu;
+    std::condition_variable& cv;
+    bool& stop;
+    ~ReaderGuard() {
+      if (!t.joinable()) return;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        stop = true;
+        cv.notify_all();
+      }
+      t.join();
+    }
+  } reader_guard{reader, mu, cv, stop};
 
   const auto t0 = std::chrono::steady_clock::now();
   const bool has_backend = !opt.backend_mean.empty() || !opt.backend_transform.empty() || opt.backend_normalize;
@@ -97,9 +124,6 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   std::vector<int32_t> ok;
   std::vector<std::string> why;
   std::string fatal;
-  const bool use_frontend = opt.cmn_window > 0 || !opt.vad_rspecifier.empty();
-  std::unique_ptr<RandomAccessVectorReader> vad;
-  if (!opt.vad_rspecifier.empty()) vad.reset(new RandomAccessVectorReader(opt.vad_rspecifier));
 
   // Up to kNumHostSlots batches queued on the device (ExtractJob::Start returns at once): after submitting batch i the
   // thread finalises batch i-2 (average, back-end, write) and packs batch i+1 while i-1 and i keep the GPU busy - with

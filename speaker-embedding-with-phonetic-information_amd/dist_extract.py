@@ -49,7 +49,7 @@ def main(argv=None):
     ap.add_argument("--chunk-size", type=int, default=-1)
     ap.add_argument("--min-chunk-size", type=int, default=100)
     ap.add_argument("--pad-input", default="true")
-    ap.add_argument("--precision", default="auto", choices=["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto"])
+    ap.add_argument("--precision", default="auto", choices=["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "auto"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-run", action="store_true", help="shard + broadcast only (no device; used by CPU tests)")
     args = ap.parse_args(argv)
@@ -66,30 +66,53 @@ def main(argv=None):
     if use_cuda:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
-    if world > 1:
+    # under a launcher (RANK set) the process group exists even for one rank: the broadcast below is then a real
+    # RCCL call on a one-rank communicator, which is how the path is exercised on a single-GPU box
+    grouped = world > 1 or "RANK" in os.environ
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if use_cuda:
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    def finish(code):
+        if grouped:
+            dist.destroy_process_group()
+        return code
 
     # ---- model: read ONCE on rank 0, one broadcast of the packed image ------------------------------------------
+    # A failure on rank 0 (unreadable model, graph outside the grammar) travels as size -1, so that the other ranks
+    # leave with it instead of sitting in the broadcast until the collective times out.
     prec = P.PRECISIONS[args.precision]
+    blob = None
     if rank == 0:
-        cfg = open(args.nnet_config).read() if args.nnet_config else ""
-        if args.output_node:
-            cfg += "\noutput-node name=output input=%s\n" % args.output_node
-        model = P.Model(rxfilename=args.nnet, nnet_config=cfg or None)
-        blob = model.pack(prec)
-        size = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+        try:
+            cfg = open(args.nnet_config).read() if args.nnet_config else ""
+            if args.output_node:
+                cfg += "\noutput-node name=output input=%s\n" % args.output_node
+            model = P.Model(rxfilename=args.nnet, nnet_config=cfg or None)
+            blob = model.pack(prec)
+            size = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+        except Exception as e:   # noqa: BLE001 - reported, then every rank exits non-zero
+            print("ERROR (dist_extract) rank 0 could not load the model: %s" % e, file=sys.stderr, flush=True)
+            size = torch.tensor([-1], dtype=torch.int64, device=dev)
     else:
         size = torch.zeros(1, dtype=torch.int64, device=dev)
-    if world > 1:
+    if grouped:
         dist.broadcast(size, 0)
+    nbytes = int(size.item())
+    if nbytes < 0:
+        return finish(1)
     if rank == 0:
         wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
     else:
-        wt = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-    if world > 1:
-        dist.broadcast(wt, 0)
-    blob = wt.cpu().numpy().tobytes()
+        wt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if grouped:
+        dist.broadcast(wt, 0)       # the ONE data collective of this path: the packed weights, over xGMI with RCCL
+        if use_cuda:
+            torch.cuda.synchronize()
 
     # ---- this rank's contiguous slice of the utterance list -----------------------------------------------------
     lines = [l for l in open(args.feats_scp) if l.strip()]
@@ -102,30 +125,43 @@ def main(argv=None):
     rspec = ("ark:" + args.feat_pipe.replace("SCP", my_scp)) if args.feat_pipe else ("scp:" + my_scp)
     ark = os.path.join(args.out_dir, "xvector_%s.%d.ark" % (args.name, job))
     scp = os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, job))
-    done = failed = 0
-    if args.dry_run:
-        import hashlib
-        print("rank %d/%d: blob %d bytes sha1 %s, utterances [%d, %d)" % (rank, world, len(blob),
-                                                                      hashlib.sha1(blob).hexdigest(), lo, hi), flush=True)
-        open(scp, "w").writelines("%s DRYRUN\n" % l.split()[0] for l in lines[lo:hi])
-    elif hi > lo:
-        ctx = P.Context(blob=blob, device=local_rank)
-        done, failed = ctx.extract_table(rspec, "ark,scp:%s,%s" % (ark, scp), args.chunk_size, args.min_chunk_size,
-                                         args.pad_input.lower() in ("true", "t", "1"))
-    else:
-        open(scp, "w").close()
-    counts = torch.tensor([done, failed], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(counts)          # bookkeeping only (2 integers); no data-path collective exists
-        dist.barrier()
+    done = failed = error = 0
+    try:
+        if args.dry_run:
+            import hashlib
+            host = wt.cpu().numpy().tobytes()
+            print("rank %d/%d: blob %d bytes sha1 %s, utterances [%d, %d)" % (rank, world, len(host),
+                                                                          hashlib.sha1(host).hexdigest(), lo, hi), flush=True)
+            open(scp, "w").writelines("%s DRYRUN\n" % l.split()[0] for l in lines[lo:hi])
+        elif hi > lo:
+            if use_cuda:
+                # the image the broadcast left in this GPU's memory is used where it is: no host round trip
+                ctx = P.Context(device_blob=(wt.data_ptr(), wt.numel()), device=local_rank)
+            else:
+                ctx = P.Context(blob=wt.numpy().tobytes(), device=local_rank)
+            done, failed = ctx.extract_table(rspec, "ark,scp:%s,%s" % (ark, scp), args.chunk_size, args.min_chunk_size,
+                                             args.pad_input.lower() in ("true", "t", "1"))
+        else:
+            open(scp, "w").close()
+    except Exception as e:   # noqa: BLE001 - counted; the other ranks learn of it through the all_reduce below
+        print("ERROR (dist_extract) rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+        error = 1
+    counts = torch.tensor([done, failed, error], dtype=torch.int64, device=dev)
+    if grouped:
+        dist.all_reduce(counts)          # bookkeeping only (3 integers); no data-path collective exists
+    n_err = int(counts[2])
     if rank == 0:
-        with open(os.path.join(args.out_dir, "xvector_%s.scp" % args.name), "w") as out:
-            for j in range(1, world + 1):
-                out.write(open(os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, j))).read())
-        print("Done %d utterances, failed for %d (over %d ranks)" % (int(counts[0]), int(counts[1]), world), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-    return 0 if (args.dry_run or int(counts[0]) > 0) else 1
+        if n_err == 0:
+            with open(os.path.join(args.out_dir, "xvector_%s.scp" % args.name), "w") as out:
+                for j in range(1, world + 1):
+                    out.write(open(os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, j))).read())
+            print("Done %d utterances, failed for %d (over %d ranks)" % (int(counts[0]), int(counts[1]), world), flush=True)
+        else:
+            print("ERROR (dist_extract) %d of %d ranks failed; xvector_%s.scp not written" % (n_err, world, args.name),
+                  file=sys.stderr, flush=True)
+    if n_err:
+        return finish(1)
+    return finish(0 if (args.dry_run or int(counts[0]) > 0) else 1)
 
 
 if __name__ == "__main__":

@@ -62,3 +62,18 @@ def test_world_size_2_gloo_dry_run(tmp_path):
     assert merged == keys
     assert [l.split()[0] for l in open(out / "feats_t.1.scp")] == keys[:6]
     assert [l.split()[0] for l in open(out / "feats_t.2.scp")] == keys[6:]
+
+
+def test_rank0_model_failure_reaches_every_rank(tmp_path):
+    """A model rank 0 cannot load must end the whole job quickly and non-zero (no rank left waiting in the broadcast)."""
+    (tmp_path / "final.raw").write_bytes(b"this is not an nnet3 model")
+    (tmp_path / "feats.scp").write_text("utt0 /data/feats.ark:10\n")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(H.ROOT, H.PKG_NAME, "dist_extract.py"),
+           "--nnet", str(tmp_path / "final.raw"), "--feats-scp", str(tmp_path / "feats.scp"), "--out-dir", str(tmp_path / "o"),
+           "--backend", "gloo", "--dry-run"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode != 0
+    assert "rank 0 could not load the model" in r.stdout

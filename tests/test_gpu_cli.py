@@ -176,14 +176,17 @@ def test_cli_profile_json(job):
 
 
 def test_cli_precision_modes(job):
-    """--precision: auto (default) = two-pass kernels for the chunks that pool >= 300 frames, fp16x3 for the others;
-    --fast-min-pooled moves the threshold; every mode within the parity tolerance, and the switch really switches."""
+    """--precision: the default is fp16x3 (fp32-grade on any model); auto = the fast kernels (fp16mx) for the chunks that
+    pool >= 300 frames, fp16x3 for the others; --fast-min-pooled moves the threshold; every mode within the parity
+    tolerance on this model, and the switch really switches."""
     d, utts, ev = job
     n2 = ev.net
     ev64 = H.xo.GraphEvaluator(n2, np.float64)
     res = {}
-    for tag, extra in (("auto", []), ("fp16x3", ["--precision=fp16x3"]), ("bf16x3", ["--precision=bf16x3"]),
-                       ("auto_all_slow", ["--fast-min-pooled=100000"]), ("auto_low", ["--fast-min-pooled=100"])):
+    for tag, extra in (("default", []), ("auto", ["--precision=auto"]), ("fp16x3", ["--precision=fp16x3"]),
+                       ("bf16x3", ["--precision=bf16x3"]), ("fp16mx", ["--precision=fp16mx"]),
+                       ("auto_all_slow", ["--precision=auto", "--fast-min-pooled=100000"]),
+                       ("auto_low", ["--precision=auto", "--fast-min-pooled=100"])):
         ark = d / ("xp_%s.ark" % tag)
         r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--chunk-size=10000",
                   "--output-node=tdnn6.affine"] + extra + [str(d / "final.raw"), "ark:%s/feats.ark" % d, "ark:%s" % ark])
@@ -195,13 +198,74 @@ def test_cli_precision_modes(job):
             continue
         for tag in ("auto", "fp16x3", "bf16x3"):
             assert H.rel_err(res[tag][k][None], ref[None]) < TOL, (tag, k)
-    long_k = [k for k, x in utts if x.shape[0] >= 330]          # 400, 1000, 333 frames: two-pass in auto
+    for k in res["fp16x3"]:
+        assert np.array_equal(res["default"][k], res["fp16x3"][k])                # the default IS fp16x3
+    long_k = [k for k, x in utts if x.shape[0] >= 330]          # 400, 1000, 333 frames: fast kernels in auto
     short_k = [k for k, x in utts if 25 <= x.shape[0] < 300]    # 137, 25 frames: three-pass in auto
     assert long_k and short_k
     for k in long_k:
         assert not np.array_equal(res["auto"][k], res["fp16x3"][k])
+        assert np.array_equal(res["auto"][k], res["fp16mx"][k])                   # auto's fast mode is fp16mx
         assert np.array_equal(res["auto_all_slow"][k], res["fp16x3"][k])
     for k in short_k:
         assert np.array_equal(res["auto"][k], res["fp16x3"][k])
     k137 = [k for k, x in utts if x.shape[0] == 137][0]
     assert not np.array_equal(res["auto_low"][k137], res["fp16x3"][k137])     # 123 pooled frames >= 100: two-pass now
+
+
+def test_bad_vad_rspecifier_is_an_error_exit_not_an_abort(job):
+    """A user error that surfaces after option parsing (an unreadable --vad-rspecifier) must end like every Kaldi tool:
+    'ERROR ...' on stderr and exit status 255 - not SIGABRT from a std::thread destroyed while joinable (ADVICE r01)."""
+    d, utts, ev = job
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine",
+              "--vad-rspecifier=scp:%s/does_not_exist.scp" % d, str(d / "final.raw"), "ark:%s/feats.ark" % d,
+              "ark:%s/never.ark" % d])
+    assert r.returncode == 255, (r.returncode, r.stderr.decode()[-500:])
+    assert "ERROR" in r.stderr.decode()
+
+
+def test_four_concurrent_processes_share_one_gpu(tmp_path):
+    """The launch mode the recipes use: run.pl JOB=1:nj starts nj independent nnet3-xvector-compute processes
+    (extract_xvectors_new.sh:91-93; nj = 32 on an 8-GPU node = 4 per GPU), each with its own persistent stream-K grids
+    that wait on inter-workgroup flags.  Four concurrent processes on this GPU, >= 200 device batches each, exactly the
+    recipe's argv (--use-gpu=no included): all finish, and every output is byte-identical to a solo run."""
+    import time
+    net, line = H.synth_model("v2_xvector")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    import tempfile
+    d = tempfile.mkdtemp(prefix="xvconc", dir=shm)
+    try:
+        open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
+        open(os.path.join(d, "extract.config"), "w").write(line + "\n")
+        pool = [H.features(3000 + i, 400) for i in range(32)]
+        n_utts, per_batch = 20000, 100          # 200 batches of 100 x 400 frames: large enough for the persistent grid
+        with open(os.path.join(d, "feats.ark"), "wb") as f:
+            for i in range(n_utts):
+                f.write(("utt%06d " % i).encode() + b"\0B")
+                kio.write_matrix(f, pool[(i * 7) % 32])
+
+        def cmd(job):
+            return [os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=10000",
+                    "--precision=auto", "--batch-frames=%d" % (per_batch * 400),
+                    "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), d, d),
+                    "ark:%s/feats.ark" % d, "ark,scp:%s/xvector.%s.ark,%s/xvector.%s.scp" % (d, job, d, job)]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd("solo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        t_solo = time.perf_counter() - t0
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen(cmd(str(j)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for j in (1, 2, 3, 4)]
+        errs = [p.communicate(timeout=1800)[1].decode() for p in procs]
+        t_four = time.perf_counter() - t0
+        for p, e in zip(procs, errs):
+            assert p.returncode == 0, e[-1000:]
+            assert "Done %d utterances, failed for 0" % n_utts in e
+        solo = open(os.path.join(d, "xvector.solo.ark"), "rb").read()
+        for j in (1, 2, 3, 4):
+            assert open(os.path.join(d, "xvector.%d.ark" % j), "rb").read() == solo, j
+        print("solo %.1f s (%.0f utt/s); four concurrent processes %.1f s (%.0f utt/s together)"
+              % (t_solo, n_utts / t_solo, t_four, 4 * n_utts / t_four))
+    finally:
+        for fn in os.listdir(d):
+            os.remove(os.path.join(d, fn))
+        os.rmdir(d)

@@ -124,6 +124,31 @@ def test_auto_mode_error_over_models_and_utterances(seed):
     print("seed %d: max %.3e  mean %.3e" % (seed, max(errs), float(np.mean(errs))))
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_trained_like_model_needs_the_three_pass_mode(seed):
+    """Heavy-tailed weights (Student-t, nu = 3) and BatchNorm statistics that match the activations, with StatsVar
+    spread over 1e-3 .. 10 (helpers.trained_like_model): the error of every mode that keeps activations in ONE fp16
+    plane is set by the activation rounding, and that depends on the model - on this one fp16x2 and auto (fp16mx) land
+    at 1 - 2.5e-4, above the 1e-4 bar that they meet on Kaldi's own initialisation distribution (the other tests and
+    the benchmark model).  fp16x3 keeps fp32-grade results; hence it is the command-line default and the fast modes are
+    opt-in (INTEGRATION.md)."""
+    P = H.pkg()
+    net, line = H.trained_like_model("v2_xvector", seed)
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    ev64 = _oracle(net, line, np.float64)
+    utts = [H.features(50 + i, 400) for i in range(4)]
+    feats, offs = H.pack(utts)
+    ref = np.stack([ev64.compute(u)[0] for u in utts])
+    errs = {}
+    for name in ("fp16x3", "fp16x2", "auto"):
+        out = P.Context(model, precision=P.PRECISIONS[name]).forward_batch(feats, offs)
+        errs[name] = max(H.rel_err(out[i:i + 1], ref[i:i + 1]) for i in range(len(utts)))
+    print("trained-like model seed %d: %s" % (seed, ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert errs["fp16x3"] < 1e-5, errs
+    assert errs["fp16x2"] < 5e-4 and errs["auto"] < 5e-4, errs      # same order as plain fp16: bounded, but not parity-grade
+    assert errs["auto"] > 2e-5                                      # the fast kernels really ran
+
+
 @pytest.mark.parametrize("topology", ["v5_cvector", "v3_multitask"])
 def test_other_topologies_auto_mode(topology):
     P = H.pkg()
