@@ -883,6 +883,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     arm(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
     if (li.segment_level || plan.rows_fast == 0) {
       Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
+      if (first_prof) prof_labels_.back() += std::string(" ") + last_gemm_kernel();
     } else {
       // rows [0, rows_fast): two-pass kernels; the rest: slow_prec_.  Same arguments, row base moved.
       for (int region = 0; region < 2; ++region) {
@@ -912,6 +913,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         int rprec = prec;
         if (region == 0) rprec = (mx_pass && gemm_mx_applicable(gr)) ? (int)kPrecFp16Mx : (int)kPrecFp16x2;
         Check(launch_tdnn_gemm(gr, rprec, epi, s), "tdnn_gemm launch");
+        if (first_prof) prof_labels_.back() += std::string(" ") + last_gemm_kernel();
       }
     }
     disarm();

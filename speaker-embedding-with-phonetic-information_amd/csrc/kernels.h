@@ -198,6 +198,9 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop);
 
 // Launches the spliced-affine GEMM. Returns hipSuccess or the launch error.
 hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipStream_t s);
+// Name of the kernel instantiation the calling thread's last launch_tdnn_gemm call launched, e.g.
+// "tdnn_gemm_kernel_sk<fp16mx,act,8>" (profiling labels; valid until the next launch of this thread).
+const char* last_gemm_kernel();
 // True when kPrecFp16Mx can run this launch (residual plane + scales present, every K group a multiple of four steps
 // with a group-max table, even tile count); otherwise the caller launches kPrecFp16x2 on the same operands.
 bool gemm_mx_applicable(const GemmArgs& a);

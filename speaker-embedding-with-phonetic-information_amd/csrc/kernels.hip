@@ -62,6 +62,17 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop) {
   g_ev_start = start;
   g_ev_stop = stop;
 }
+static thread_local char g_last_kernel[96] = "";
+const char* last_gemm_kernel() { return g_last_kernel; }
+static const char* prec_name(int p) {
+  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx"};
+  return (p >= 0 && p <= 6) ? n[p] : "?";
+}
+static const char* epi_name(int e) { return e == kEpiAct ? "act" : e == kEpiF32 ? "f32" : e == kEpiStats ? "stats" : "splitk"; }
+static void note_kernel(const char* variant, int prec, int epi, int mf) {
+  if (mf) snprintf(g_last_kernel, sizeof g_last_kernel, "tdnn_gemm_kernel%s<%s,%s,%d>", variant, prec_name(prec), epi_name(epi), mf);
+  else snprintf(g_last_kernel, sizeof g_last_kernel, "tdnn_gemm_kernel%s<%s,%s>", variant, prec_name(prec), epi_name(epi));
+}
 #define XV_LAUNCH(kern, grid, block, lds, stream, ...)                                           \
   do {                                                                                           \
     hipEvent_t _st = g_ev_start, _sp = g_ev_stop;                                                \
@@ -1699,6 +1710,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     b.sk_ws = w.ws;
     b.sk_flags = w.flags;
+    note_kernel("_sk", PREC, EPI, MF);
     XV_LAUNCH((tdnn_gemm_kernel_sk<PREC, EPI, MF>), dim3(grid), dim3(512), lds, s, b);
     return hipGetLastError();
   }
@@ -1732,6 +1744,7 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
     b.stagger_wgs = cus;
     b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * (400 + 600 * PrecPasses(PREC)) + 14000) * pct / 100 / 2048) : 0;
   }
+  note_kernel("_v2", PREC, EPI, 0);
   XV_LAUNCH((tdnn_gemm_kernel_v2<PREC, EPI>), grid, block, lds, s, b);
   return hipGetLastError();
 }
@@ -1765,6 +1778,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   const int mt8 = (a.m_tiles + 7) / 8 * 8;
   dim3 grid(mt8 * a.n_tiles), block(256);
+  note_kernel("", PREC, EPI, 0);
   XV_LAUNCH((tdnn_gemm_kernel<PREC, EPI>), grid, block, lds, s, a);
   return hipGetLastError();
 }
@@ -1824,6 +1838,7 @@ static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
   }
   const int mt8 = (a.m_tiles + 7) / 8 * 8;
   dim3 grid(mt8 * a.n_tiles, a.ksplit), block(256);
+  note_kernel("", PREC, kEpiSplitK, 0);
   XV_LAUNCH((tdnn_gemm_kernel<PREC, kEpiSplitK>), grid, block, lds, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -11,7 +11,7 @@ import json
 try:
     d=json.loads(open("$out/$label.json").read().strip().splitlines()[-1])
     k=d["kernels_ms_per_step"]
-    print("%-10s %7.0f utt/s  frac %.3f  err %.2e | "%("$label", d["value"], d["roofline"]["frac"], d["parity_rel_err_vs_oracle_fp32"]) + "  ".join("%s %.4f"%(n.split(":")[-1].replace(".batchnorm","").replace(".affine",""), v) for n,v in k.items()))
+    print("%-10s %7.0f utt/s  frac %.3f  err %.2e | "%("$label", d["value"], d["roofline"]["frac"], d["parity_rel_err_vs_oracle_fp32"]) + "  ".join("%s %.4f"%(n.split(":")[-1].split()[0].replace(".batchnorm","").replace(".affine",""), v) for n,v in k.items()))
 except Exception as e:
     print("$label failed", e, open("$out/$label.err").read()[-300:])
 PY
