@@ -162,22 +162,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 
 constexpr int kTileBytes = kBM * kBK * 2;  // one 128x32 16-bit tile = 8 KiB
 
-#ifdef XV_PROBE_TIMING
-// Experiment builds only (tools/kbench.sh): s_memtime stamps of the segments of the stream-K K loop, waves 0 and 4 of
-// workgroup 0, read back through xv_probe_dump().
-__device__ unsigned long long g_probe[2][512];
-__device__ int g_probe_n[2];
-#define XV_STAMP(tag)                                                                         \
-  do {                                                                                        \
-    if (probe_on && probe_i < 510) {                                                          \
-      g_probe[probe_w][probe_i++] = ((unsigned long long)(tag) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull); \
-      g_probe_n[probe_w] = probe_i;                                                           \
-    }                                                                                         \
-  } while (0)
-#else
-#define XV_STAMP(tag) do {} while (0)
-#endif
-
 // ---- kPrecFp16Mx helpers ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -1099,11 +1083,6 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const int col_w = WIDE ? 0 : (wave >> 2) * 64;                 // workgroup tile
   const int group = wave >> 2;
   const int bid = blockIdx.x;
-#ifdef XV_PROBE_TIMING
-  const bool probe_on = (bid == 0) && (wave == 0 || wave == 4) && (tid & 63) == 0 && EPI == kEpiAct && a.total_ksteps == 48;
-  const int probe_w = wave >> 2;
-  int probe_i = 0;
-#endif
 
   // ---- this workgroup's share of the K steps ---------------------------------------------------------------------
   // XCD block `xcd` owns a contiguous range of whole ROW tiles.  Its G/8 workgroups form G/8/L groups of L "column
@@ -1494,33 +1473,25 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     Frags f;
     const int ns = n_steps;
     if constexpr (MX) {
-      // Blocks of four steps: three plain ones, then one whose COMPUTE segment also converts its fragments, fetches the
-      // block's 4-bit weight fragments and issues the MF x 4 residual MFMAs.  The loop is NOT unrolled by four (the
-      // copies cost ~50 registers of duplicated address state): the position inside the block only selects, through a
-      // wave-uniform switch, which dword of the 4-bit fragments the conversions write.
+      // Blocks of four steps (unrolled: the position inside a block is a compile-time constant): every COMPUTE segment
+      // converts its activation fragments into one dword of the 4-bit fragments, the last one also fetches the block's
+      // 4-bit weight fragments and issues the 32 residual MFMAs.
 #pragma nounroll
       for (int j = 0; j < ns; j += 4, ++rblk) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          XV_STAMP(1);
-          // the LOAD segment is the longer one in this mode (see the stamps in DESIGN.md): it gets the issue priority
+          // with 1.25 passes per product the LOAD segment (12 fragment reads, 3-6 LDS-DMA instructions) is as long as
+          // the COMPUTE segment of the partner wave (s_memtime stamps: ~870 vs ~890 cycles): it gets the issue
+          // priority (measured -4.5 % on tdnn2 against the opposite assignment the two-pass kernels use)
           __builtin_amdgcn_s_setprio(1);
           read_step(f);
-          XV_STAMP(2);
           const int n = (j + s + 2 < ns) ? issue_step() : 0;
-          XV_STAMP(3);
-          __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          XV_STAMP(4);
           wait_and_barrier(n);
-          XV_STAMP(5);
           __builtin_amdgcn_s_setprio(0);
           mfmas(f);
           convert(f, s);
           if (s == 3) mx_mfmas(f);
-          XV_STAMP(6);
           plain_barrier();
-          XV_STAMP(7);
         }
       }
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
@@ -1640,22 +1611,6 @@ void release_stream_workspace(hipStream_t s) {
   sk_free(&it->second);
   g_sk_table.erase(it);
 }
-
-#ifdef XV_PROBE_TIMING
-extern "C" int xv_probe_dump(unsigned long long* out, int cap) {
-  unsigned long long h[2][512];
-  int n[2];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof h) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_probe_n), sizeof n) != hipSuccess) return -1;
-  int k = 0;
-  for (int w = 0; w < 2; ++w)
-    for (int i = 0; i < n[w] && k + 2 <= cap; ++i) {
-      out[k++] = (unsigned long long)w;
-      out[k++] = h[w][i];
-    }
-  return k;
-}
-#endif
 
 unsigned sk_last_error() {
   std::lock_guard<std::mutex> lock(g_sk_mu);

@@ -46,17 +46,22 @@ def main():
                  "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes; reads x2 (gfx950 FETCH_SIZE",
                  "counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM; prep_input reads a known 9.42 MB and reports 4.7 MB).", "",
                  "| # | kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes (2*fetch+write) | duration us |", "|---|---|---|---|---|---|"]
-        tot_act, n_act = 0.0, 0
+        # per kernel instantiation, under the name bench.py's roofline uses (engine profile labels, kernels.hip note_kernel)
+        prec = ["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx"]
+        epi = ["act", "f32", "stats", "splitk"]
+        by = {}
         for i, ((k, f, us), (_, w, _)) in enumerate(zip(per["FETCH_SIZE"], per["WRITE_SIZE"])):
             b = (2 * f + w) * 1024
             lines.append("| %d | %s | %.1f | %.1f | %.3e | %.1f |" % (i, k, f, w, b, us))
-            if re.search(r"tdnn_gemm_kernel\w*<\d+, 0[,>]", k):   # the activation-producing instantiations (EPI = 0)
-                tot_act += b
-                n_act += 1
+            m = re.search(r"(tdnn_gemm_kernel\w*)<(\d+), (\d+)(?:, (\d+))?>", k)
+            if m:
+                name = "%s<%s,%s%s>" % (m.group(1), prec[int(m.group(2))], epi[int(m.group(3))], "," + m.group(4) if m.group(4) else "")
+                by.setdefault(name, []).append(b)
         open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
-        if n_act:
-            json.dump({"hbm_bytes_per_launch": tot_act / n_act, "kernel": "tdnn_gemm_kernel*<prec,act>", "launches": n_act,
-                       "source": tag + "_pmc_hbm.md"}, open(os.path.join(prof, "pmc_traffic.json"), "w"))
+        if by:
+            json.dump({"hbm_bytes_per_launch": {k: sum(v) / len(v) for k, v in by.items()},
+                       "launches_per_step": {k: len(v) for k, v in by.items()}, "source": tag + "_pmc_hbm.md"},
+                      open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     sq = os.path.join(d, "pmc_sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
         import collections
