@@ -215,6 +215,7 @@ xv_status xv_ctx_synchronize(xv_ctx* c) {
   return Guard([&] {
     if (hipSetDevice(c->eng->device()) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
       return Fail(XV_ERR_DEVICE, "hipDeviceSynchronize failed");
+    c->eng->CheckKernelFaults();
     return XV_OK;
   });
 }

@@ -1127,11 +1127,20 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
   S.pending = true;
 }
 
+void Engine::CheckKernelFaults() const {
+  // a stream-K workgroup that gave up waiting for another workgroup's partial tile (bounded spin, kernels.hip) left
+  // this word behind; the results of that launch are not to be trusted
+  if (sk_last_error())
+    throw EngineError("a stream-K GEMM launch timed out waiting for a partial tile of another workgroup (results invalid); "
+                      "XVEC_GEMM_VARIANT=2 selects the per-tile kernels");
+}
+
 const float* Engine::WaitHost(int slot) {
   if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
   HostSlot& S = host_slots_[slot];
   if (!S.pending) throw EngineError("WaitHost: nothing submitted on this slot");
   Check(hipEventSynchronize(S.done), "hipEventSynchronize(slot)");
+  CheckKernelFaults();
   S.pending = false;
   return (const float*)S.h_out;
 }
@@ -1153,6 +1162,7 @@ void Engine::ForwardHost(const float* feats, const int32_t* row_offsets, int B, 
   Forward(*plan, dev_feats, (float*)out_stage_.p, info_.output_dim, stream_);
   Check(hipMemcpyAsync(out, out_stage_.p, obytes, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(out)");
   Check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  CheckKernelFaults();
 }
 
 }  // namespace xv

@@ -165,6 +165,10 @@ class Engine {
   static void BindPlan(Plan* plan, const void* device_tables);
   void ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev, float* out_dev, int out_ld, hipStream_t stream);
   void Check(hipError_t e, const char* what) const;
+ public:
+  // throws when a kernel of this process reported a fault the HIP API cannot see (called after synchronising)
+  void CheckKernelFaults() const;
+ private:
   void Ensure(Buf* b, size_t bytes, bool zero);
   void EnsureCapacity(Lane& L, int rows, int b_pad);
   uint16_t* ActBase(const Buf& b, int ld) const;
