@@ -41,3 +41,26 @@ def test_c_oracle_refuses_short_chunks(tmp_path):
     r = subprocess.run([EXE, str(tmp_path / "prog.bin"), str(tmp_path / "x.f32"), "14", str(tmp_path / "o.f32")],
                        stderr=subprocess.PIPE)
     assert r.returncode == 2 and b"never pads" in r.stderr
+
+
+def test_cpu_baseline_program_matches_numpy_oracle(tmp_path):
+    """oracle/xvec_cpu_baseline (B0 of BASELINE.md section 3: blocked GEMM + OpenMP, ark in / ark out) against the numpy
+    graph evaluator, ragged lengths, one and several threads; utterances shorter than the context count as failed."""
+    from oracle import kaldi_io as kio
+    exe = os.path.join(H.ROOT, "oracle", "_build", "xvec_cpu_baseline")
+    net, line = H.synth_model("v2_xvector")
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    export_program(n2, str(tmp_path / "prog.bin"))
+    utts = [("u%d" % i, H.features(40 + i, T)) for i, T in enumerate((64, 15, 14, 137, 31))]
+    kio.write_ark_matrices(str(tmp_path / "f.ark"), utts)
+    ev = H.xo.GraphEvaluator(n2, np.float64)
+    for threads in (1, 3):
+        r = subprocess.run([exe, str(tmp_path / "prog.bin"), str(tmp_path / "f.ark"), str(tmp_path / "o.ark"), str(threads)],
+                           stdout=subprocess.PIPE, check=True)
+        assert b"4 utterances" in r.stdout and ("threads %d" % threads).encode() in r.stdout
+        got = dict(kio.read_ark(str(tmp_path / "o.ark"), "vector"))
+        assert sorted(got) == ["u0", "u1", "u3", "u4"]          # u2 (14 frames) is shorter than the 15-frame context
+        for k, x in utts:
+            if k in got:
+                assert H.rel_err(got[k][None], ev.compute(x)) < 2e-5, k
