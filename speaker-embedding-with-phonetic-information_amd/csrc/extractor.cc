@@ -160,6 +160,45 @@ void ExtractJob::Start(Engine* eng, const ExtractOptions& opt, int slot, long se
   async_ = true;
 }
 
+void ExtractJob::StartPtrs(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* const* utt,
+                           const int32_t* rows, int n_utts) {
+  eng_ = eng;
+  opt_ = opt;
+  slot_ = slot;
+  n_utts_ = n_utts;
+  feats_ = nullptr;
+  row_offsets_ = nullptr;
+  async_ = false;
+  utt_ptr_.assign(utt, utt + n_utts);
+  utt_rows_.assign(rows, rows + n_utts);
+  chunks_.clear();
+  ok_.assign(n_utts, 0);
+  why_.assign(n_utts, std::string());
+  long total = 0;
+  for (int u = 0; u < n_utts; ++u) {
+    std::string reason;
+    const size_t before = chunks_.size();
+    ok_[u] = PlanChunks(u, rows[u], opt.chunk_size, opt.min_chunk_size, opt.pad_input, eng->info().min_frames, &chunks_, &reason) ? 1 : 0;
+    if (!ok_[u]) why_[u] = reason;
+    for (size_t k = before; k < chunks_.size(); ++k) total += chunks_[k].len + chunks_[k].left_pad + chunks_[k].right_pad;
+  }
+  if (chunks_.empty() || total > opt.max_batch_rows || (int)chunks_.size() > opt.max_batch_chunks) return;  // Finish() does it
+  const int D = eng->info().input_dim;
+  float* pack = eng->HostFeats(slot, (size_t)total);
+  std::vector<int32_t> offs(1, 0);
+  size_t r = 0;
+  for (const Chunk& c : chunks_) {
+    const float* src = utt[c.utt] + (size_t)c.start * D;
+    for (int p = 0; p < c.left_pad; ++p, ++r) memcpy(pack + r * D, src, (size_t)D * 4);
+    memcpy(pack + r * D, src, (size_t)c.len * D * 4);
+    r += c.len;
+    for (int p = 0; p < c.right_pad; ++p, ++r) memcpy(pack + r * D, src + (size_t)(c.len - 1) * D, (size_t)D * 4);
+    offs.push_back((int32_t)r);
+  }
+  eng->SubmitHost(slot, seq, offs.data(), (int)chunks_.size());
+  async_ = true;
+}
+
 bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot, long seq, int n_utts, const float* const* raw,
                                const int32_t* raw_rows, const float* const* vad) {
   const int D = eng->info().input_dim;
@@ -234,6 +273,17 @@ void ExtractJob::Finish(float* out, int32_t* ok, std::vector<std::string>* why) 
   eng_ = nullptr;
   if (!eng) throw EngineError("ExtractJob::Finish without Start");
   if (!async_) {
+    if (!feats_ && !utt_ptr_.empty()) {   // StartPtrs: the synchronous path wants packed rows
+      const int D = eng->info().input_dim;
+      fallback_offs_.assign(1, 0);
+      for (int u = 0; u < n_utts_; ++u) fallback_offs_.push_back(fallback_offs_.back() + utt_rows_[u]);
+      fallback_pack_.resize((size_t)fallback_offs_.back() * D);
+      for (int u = 0; u < n_utts_; ++u)
+        if (utt_rows_[u] > 0)
+          memcpy(&fallback_pack_[(size_t)fallback_offs_[u] * D], utt_ptr_[u], (size_t)utt_rows_[u] * D * 4);
+      feats_ = fallback_pack_.data();
+      row_offsets_ = fallback_offs_.data();
+    }
     ExtractUtterances(eng, opt_, feats_, row_offsets_, n_utts_, out, ok, why);
     return;
   }

@@ -61,6 +61,11 @@ class ExtractJob {
   // seq = running number of the batch (selects the engine lane)
   void Start(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* feats, const int32_t* row_offsets,
              int n_utts);
+  // The same without a packed copy of the features: utterance u = utt[u][0 .. rows[u] * input_dim), copied straight
+  // into the engine's pinned staging buffer (table jobs: one host copy per byte instead of two).  The pointers must
+  // stay valid until Finish() returns.
+  void StartPtrs(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* const* utt, const int32_t* rows,
+                 int n_utts);
   // Table jobs with the device front-end: raw[u] = the utterance's raw rows (raw_rows[u] of them), vad[u] = its VAD
   // decisions (or null: keep every row; every utterance keeps at least one).  When every utterance maps to exactly one
   // unpadded chunk (the normal case) the raw rows are staged, CMN + selection + network run on the device without a
@@ -77,6 +82,10 @@ class ExtractJob {
   const float* feats_ = nullptr;
   const int32_t* row_offsets_ = nullptr;
   bool async_ = false;
+  std::vector<const float*> utt_ptr_;   // StartPtrs: per-utterance rows (packed on demand for the synchronous fallback)
+  std::vector<int32_t> utt_rows_;
+  std::vector<float> fallback_pack_;
+  std::vector<int32_t> fallback_offs_;
   std::vector<Chunk> chunks_;
   std::vector<int32_t> ok_;
   std::vector<std::string> why_;

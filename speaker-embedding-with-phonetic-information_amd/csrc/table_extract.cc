@@ -132,8 +132,10 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   struct Work {
     Batch b;
     std::vector<int> idx;        // utterances of b that entered the device batch
-    std::vector<float> packed;   // their rows (after the optional front-end), back to back
+    std::vector<float> packed;   // front-end path only: the processed rows, back to back
     std::vector<int32_t> offs;
+    std::vector<const float*> uptr;   // plain path: rows of the utterances where the reader left them
+    std::vector<int32_t> urows;
     ExtractJob job;
   };
   Work work[Engine::kNumHostSlots];
@@ -207,10 +209,12 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
         std::vector<int>& idx = w.idx;
         offs.assign(1, 0);
         idx.clear();
-        size_t total = 0;
-        for (const Utt& u : w.b.utts) total += (size_t)u.feats.rows;
-        packed.resize(total * D);
-        size_t r = 0;
+        // the rows stay where the reader put them (w.b keeps the utterances alive until finalize): the chunks are copied
+        // from there straight into the engine's pinned staging buffer (ExtractJob::StartPtrs) - one host copy per byte
+        std::vector<const float*>& uptr = w.uptr;
+        std::vector<int32_t>& urows = w.urows;
+        uptr.clear();
+        urows.clear();
         for (size_t i = 0; i < w.b.utts.size(); ++i) {
           const Utt& u = w.b.utts[i];
           if (u.feats.rows > 0 && u.feats.cols != D) {
@@ -220,9 +224,8 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
             ++res.num_fail;
             continue;
           }
-          if (u.feats.rows > 0) memcpy(&packed[r * D], u.feats.data.data(), (size_t)u.feats.rows * D * 4);
-          r += u.feats.rows;
-          offs.push_back((int32_t)r);
+          uptr.push_back(u.feats.data.data());
+          urows.push_back(u.feats.rows);
           idx.push_back((int)i);
         }
         int n = (int)idx.size();
@@ -297,7 +300,10 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
         const auto tp1 = now();
         t_pack += secs(tp0, tp1);
         if (n) {
-          if (!submitted) w.job.Start(engine, opt, cur, seq++, packed.data(), offs.data(), n);
+          if (!submitted) {
+            if (use_frontend) w.job.Start(engine, opt, cur, seq++, packed.data(), offs.data(), n);   // front-end result (host)
+            else w.job.StartPtrs(engine, opt, cur, seq++, uptr.data(), urows.data(), n);
+          }
           const auto tp2 = now();
           t_start += secs(tp1, tp2);
           cur = (cur + 1) % NS;
