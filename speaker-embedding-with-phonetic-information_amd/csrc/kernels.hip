@@ -128,24 +128,25 @@ __device__ __forceinline__ int swap_fields(int rho) {
 }
 
 // Cross-lane adds of the statistics epilogue on the gfx950 lane-swap instructions (plain VALU) instead of
-// ds_bpermute (LDS crossbar, ~100 cycles each, 128 per wave and 512 x 128 tile).  v_permlane16_swap exchanges the odd
-// 16-lane rows of its first operand with the even rows of the second: with both equal to v the operands become
-// [r0 r0 r2 r2] and [r1 r1 r3 r3], whose sum is the xor-16 butterfly (same operands, hence the same bits, as
-// v + shfl_xor(v, 16)); v_permlane32_swap does the same with the 32-lane halves.  (Inline asm: the builtins of this
-// hipcc mis-assign the second result register.)
-__device__ __forceinline__ float sum_rows16(float v) {
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-__device__ __forceinline__ float sum_halves32(float v) {
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
+// ds_bpermute (LDS crossbar, ~100 cycles each).  v_permlane16_swap a, b exchanges the odd 16-lane rows of a with the
+// even rows of b: a = [a0 b0 a2 b2], b = [a1 b1 a3 b3] (rows of 16 lanes); v_permlane32_swap does the same with the
+// 32-lane halves.  (Inline asm: the builtins of this hipcc mis-assign the second result register.)
+// sum4_rows_scatter: the 16-row sums of FOUR values at once (the fragments p = 0..3 of one column; a lane holds the
+// sum over its four rows, the 16 rows of a fragment are spread over the four 16-lane rows of the wave).  One swap and
+// one add per butterfly level and PAIR of values: after the first level the even rows hold the pair sums of the
+// first value of a pair and the odd rows those of the second; after the second, 16-lane row g holds the total of
+// value g - the distribution the epilogue stores (lane group g writes fragment g).  Per element the additions are
+// (r0 + r1) + (r2 + r3) with the lower row first, as in the xor-16 / xor-32 butterfly this replaces: same bits.
+__device__ __forceinline__ float sum4_rows_scatter(float v0, float v1, float v2, float v3) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v2), "+v"(v3));
+  float u = v0 + v1, w = v2 + v3;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+  return u + w;
 }
 
 // Maximum over the 64 lanes of a wave, in every lane: four DPP steps inside the 16-lane rows, then the lane-swap
-// instructions across rows (as in sum_rows16 / sum_halves32).
+// instructions across rows.
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
@@ -357,12 +358,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       }
     }
   } else {
-    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i.  After the cross-lane adds all four lanes
-    // of a column hold the sums of every fragment p, so lane group fr_g stores fragment p = fr_g: two store
-    // instructions per q (4 fragments x 16 columns each) instead of eight 16-lane ones - the epilogue is bound by the
-    // number of store instructions a CU can issue, not by their bytes.
+    // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i.  The cross-lane adds leave the sums of
+    // fragment p in lane group fr_g = p, which stores them: two store instructions per q (4 fragments x 16 columns
+    // each).
     const int grp0 = mbase >> 4;
-    float s1v[4][4], s2v[4][4];   // [q][p]
+    float s1v[4][4], s2v[4][4];   // [q][p]: this lane's sums over its four rows r of fragment p
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       // all 16 rows of the group pooled (every group but the first / last ones of a chunk): no row mask.  first / last
@@ -398,15 +398,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        s1v[q][p] = sum_halves32(sum_rows16(s1[q]));
-        s2v[q][p] = sum_halves32(sum_rows16(s2[q]));
+        s1v[q][p] = s1[q];
+        s2v[q][p] = s2[q];
       }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = nbase + q * 16 + fr_i;
-      const float v1 = fr_g == 0 ? s1v[q][0] : fr_g == 1 ? s1v[q][1] : fr_g == 2 ? s1v[q][2] : s1v[q][3];
-      const float v2 = fr_g == 0 ? s2v[q][0] : fr_g == 1 ? s2v[q][1] : fr_g == 2 ? s2v[q][2] : s2v[q][3];
+      // cross-lane part of the 16-row sums; lane group fr_g ends up with the totals of fragment p = fr_g
+      const float v1 = sum4_rows_scatter(s1v[q][0], s1v[q][1], s1v[q][2], s1v[q][3]);
+      const float v2 = sum4_rows_scatter(s2v[q][0], s2v[q][1], s2v[q][2], s2v[q][3]);
       float* dst = a.partial + (long)(grp0 + fr_g) * 2 * a.ldp + col;
       dst[0] = v1;
       dst[a.ldp] = v2;
@@ -1510,7 +1511,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     if (group == 0) plain_barrier();
     // every wave is past its last LDS read: the rings may be refilled for the next part while this one's results go out
     const int e_kind = kind, e_m0 = m0, e_n0 = n0;
+    // Statistics epilogue: the parameters of the first 64 x 64 block are requested BEFORE the next part's DMA - memory
+    // loads return in order, and behind the two tile steps open_part puts in flight (first touches of activation rows)
+    // they arrive only after the pipeline fill.  (The planes epilogue has 56 parameter registers per block; held across
+    // open_part they spill 160 dwords and the kernel loses a third: it fetches them afterwards.)
+    constexpr bool EARLY = (EPI == kEpiStats);
+    EpiRegs er0;
+    if (EARLY && e_kind != 1) epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + col_w, lane, er0);
     if (part + 1 < n_parts) open_part(part + 1);
+    if (!EARLY && e_kind != 1) epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + col_w, lane, er0);
 
     if (e_kind == 1) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1533,17 +1542,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
         // two 64 x 64 blocks side by side: same rows, columns e_n0 and e_n0 + 64.  The group maxima of the planes
         // epilogue are carried across both (one reduction and one atomic per 16-row group and wave).
         float gm[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
+        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0, lane, er0, gm, 1);
+        if constexpr (NH > 1) {
           EpiRegs er;
-          epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + h * 64, lane, er);
-          gemm_epilogue<PREC, EPI>(a, acc[h], e_m0 + row_w, e_n0 + h * 64, lane, er, gm, h == 0 ? 1 : 2);
+          epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + 64, lane, er);
+          gemm_epilogue<PREC, EPI>(a, acc[NH - 1], e_m0 + row_w, e_n0 + 64, lane, er, gm, 2);
         }
       } else {
-        EpiRegs er;
-        epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + col_w, lane, er);
         float gm[4] = {0.f, 0.f, 0.f, 0.f};
-        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0 + col_w, lane, er, gm, 0);
+        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0 + col_w, lane, er0, gm, 0);
       }
     }
   }
