@@ -602,6 +602,16 @@ __device__ __forceinline__ void glds16_sbase(const void* sbase, unsigned voff, u
       : "memory");
 }
 
+// 4 bytes per lane (LDS destination = base + lane * 4)
+__device__ __forceinline__ void glds4_sbase(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1074,6 +1084,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   constexpr int XSLOT = NPX * XT;
   constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;
+  constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: the E8M0 scales of the tile's 128 weight rows (256 bytes reserved)
   constexpr int KQ = MX ? 4 : 1;               // K steps are dealt out in units of KQ (a 128-deep block is never cut)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1209,13 +1220,17 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   int xs_b[MX ? XW : 1];          // 2^(e-2) as E8M0 bytes, fragment f in byte f & 3 of word f >> 2
   float xs_f[MX ? XF : 1];        // the same as floats: the divisor of the conversions
   int ws_v[MX ? WW : 1];          // E8M0 scales of this lane's weight-fragment rows, fragment w in byte w & 3 of word w >> 2
-  auto load_xscales = [&](const unsigned* gmax) __attribute__((always_inline)) {
+  typedef __attribute__((ext_vector_type(MX ? XF : 4))) unsigned xs_uvec;
+  auto xs_request = [&](const unsigned* gmax, xs_uvec& g) __attribute__((always_inline)) {   // scalar load, not waited for
     if constexpr (MX) {
-      typedef __attribute__((ext_vector_type(XF))) unsigned uvec;
       const unsigned* p = gmax + ((m0 + row_w) >> 4);
-      uvec g;
-      if constexpr (XF == 8) asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g) : "s"(p) : "memory");
-      else asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g) : "s"(p) : "memory");
+      if constexpr (XF == 8) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(g) : "s"(p) : "memory");
+      else asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(g) : "s"(p) : "memory");
+    }
+  };
+  auto xs_finish = [&](xs_uvec& g) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g) : : "memory");
 #pragma unroll
       for (int h = 0; h < XW; ++h) xs_b[h] = 0;
 #pragma unroll
@@ -1226,6 +1241,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
         xs_f[f] = __builtin_bit_cast(float, (e - 2u) << 23);
       }
     }
+  };
+  auto load_xscales = [&](const unsigned* gmax) __attribute__((always_inline)) {
+    xs_uvec g;
+    xs_request(gmax, g);
+    xs_finish(g);
   };
 
   int rg = 0, rkk = 0, rj = 0, rxslot = 0, rwslot = 0;
@@ -1404,20 +1424,31 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     xs_reload = false;
     force_x = true;
     n_steps = ke - kb;
+    xs_uvec xg;
     if constexpr (MX) {
       wtile_4 = a.w4 + (long)n0 * a.ldw4;
-      load_xscales(gi.gmax);
-      // E8M0 scales of the weight rows behind this lane's four fragments (LDS row p * 16 + fr_i of the wave's slice)
-#pragma unroll
-      for (int h = 0; h < WW; ++h) {
-        const uint8_t* sp = a.w4_scale + n0 + col_w + h * 64;
-        ws_v[h] = 0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) ws_v[h] |= (int)sp[SWAP ? swap_fields(p * 16 + fr_i) : p * 16 + fr_i] << (8 * p);
-      }
+      // the activation scales travel (scalar cache) while the DMA of the first steps is issued; the scales of the
+      // tile's weight rows go to LDS with that DMA and are picked up after the fill (a per-lane byte gather from
+      // global memory here cost a full load latency in front of the first DMA)
+      xs_request(gi.gmax, xg);
+      if (wave == 0) glds4_sbase(a.w4_scale + n0, (unsigned)(lane & 31) * 4u, lds_base + SCB);
     }
     issue_step();
     if (n_steps > 1) issue_step();
+    xs_finish(xg);
+  };
+  // kPrecFp16Mx, after the fill wait of a part: E8M0 scales of the weight rows behind this lane's fragments (LDS row
+  // p * 16 + fr_i of each 64-row slice), fragment p in byte p
+  auto load_wscales = [&]() __attribute__((always_inline)) {
+    if constexpr (MX) {
+      const uint8_t* sc = (const uint8_t*)smem + SCB + col_w;
+#pragma unroll
+      for (int h = 0; h < WW; ++h) {
+        ws_v[h] = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ws_v[h] |= (int)sc[h * 64 + (SWAP ? swap_fields(p * 16 + fr_i) : p * 16 + fr_i)] << (8 * p);
+      }
+    }
   };
 
   open_part(0);
@@ -1465,11 +1496,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     // Ping-pong schedule of v2 (two barrier intervals per K step; group 1 runs one interval behind group 0).  A
     // one-barrier-per-step form (group 0: LOAD_j, COMPUTE_j; group 1: COMPUTE_{j-1}, LOAD_j) was measured 6 % slower:
     // without the second barrier the groups drift into loading at the same time.
-    // The compiler-tracked loads of open_part (weight-row scales) are complete after this wait; saying so through the
-    // builtin keeps hipcc from putting its own vmcnt(0) in front of their first use INSIDE the K loop, where it
-    // would drain the LDS-DMA queue on every pass.
-    if constexpr (MX) __builtin_amdgcn_s_waitcnt(0x0f70);
+    // (open_part leaves no compiler-tracked memory load behind: a vmcnt(0) of hipcc's in front of a first use INSIDE
+    // the K loop would drain the LDS-DMA queue on every pass.)
     wait_and_barrier(0);               // the first two steps have landed (and the previous epilogue's stores are out)
+    load_wscales();
     if (group == 1) plain_barrier();
     Frags f;
     const int ns = n_steps;
@@ -1627,7 +1657,7 @@ unsigned sk_last_error() {
 // True when the stream-K variant with MF fragments per wave can run this launch.
 template <int PREC, int MF>
 static bool sk_applicable(const GemmArgs& a) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 256 : 0);
   if (lds > 160 * 1024) return false;
   const int rows = a.m_tiles * kBM;
   if (rows % (64 * MF)) return false;
@@ -1639,7 +1669,7 @@ static bool sk_applicable(const GemmArgs& a) {
 
 template <int PREC, int EPI, int MF>
 static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 256 : 0);
   if constexpr (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {
