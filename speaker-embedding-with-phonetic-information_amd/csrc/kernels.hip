@@ -269,6 +269,58 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
   }
 }
 
+// The same from a copy of the tile's parameters in LDS (stream-K kernel): par = bias[128] scale[128] offset[128] of the
+// workgroup tile's columns, ncol0 = first column of the 64 x 64 block inside the tile.  (Fetched from global memory
+// right before use - the stream-K kernel has no registers to hold them through the K loop - every block's epilogue
+// started with a full load latency behind the next part's DMA: -6 % on the whole forward pass.)
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const float* par, const int mbase, const int ncol0,
+                                                      const int lane, EpiRegs& e) {
+  const int fr_i = lane & 15;
+  const int fr_g = lane >> 4;
+  if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
+    const int ncol = ncol0 + fr_g * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = ncol + (p >> 1) * 32 + (p & 1) * 4;
+      const f32x4 b4 = *(const f32x4*)(par + c);
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, o4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.bn) {
+        s4 = *(const f32x4*)(par + 128 + c);
+        o4 = *(const f32x4*)(par + 256 + c);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e.bs[p * 4 + r] = b4[r];
+        e.sc[p * 4 + r] = s4[r];
+        e.of[p * 4 + r] = o4[r];
+      }
+    }
+    if (EPI == kEpiAct && a.gmax_out) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int grp = (mbase + q * 16) >> 4;
+        e.first[q] = a.out_range ? a.out_range[2 * grp] : 0;
+        e.last[q] = a.out_range ? a.out_range[2 * grp + 1] : 16;
+      }
+    }
+  } else if constexpr (EPI == kEpiStats) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = ncol0 + q * 16 + fr_i;
+      e.bs[q] = par[c];
+      e.sc[q] = a.bn ? par[128 + c] : 1.f;
+      e.of[q] = a.bn ? par[256 + c] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int grp = (mbase + p * 16) >> 4;
+      e.first[p] = a.grp_range[2 * grp];
+      e.last[p] = a.grp_range[2 * grp + 1];
+    }
+  }
+}
+
 // Shared epilogue of the GEMM kernels.  acc[p][q] is the 16x16 fragment (P-tile fragment p) x (Q-tile fragment q)
 // of one wave's 64x64 tile whose first frame is mbase and first output column nbase.
 // gm / gm_phase (planes epilogue with a.gmax_out): lane-local maxima of |y| per 16-row group q carried between calls that
@@ -1085,6 +1137,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;
   constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: the E8M0 scales of the tile's 128 weight rows (256 bytes reserved)
+  constexpr int PB = SCB + 256;                // epilogue parameters of the tile's columns, two buffers of 3 x 128 floats
   constexpr int KQ = MX ? 4 : 1;               // K steps are dealt out in units of KQ (a 128-deep block is never cut)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1424,6 +1477,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     xs_reload = false;
     force_x = true;
     n_steps = ke - kb;
+    if (EPI != kEpiSplitK && kind != 1 && wave < (a.bn ? 6 : 2)) {
+      // bias / scale / offset of the tile's columns -> LDS buffer part & 1, one 256-byte piece per wave; complete with the
+      // first wait of the part, read by its epilogue (which runs after open_part of the NEXT part: the other buffer)
+      const float* src = (wave < 2 ? a.bias : wave < 4 ? a.scale : a.offset) + n0 + (wave & 1) * 64;
+      glds4_sbase(src, (unsigned)lane * 4u, lds_base + PB + (part & 1) * 1536 + wave * 256);
+    }
     xs_uvec xg;
     if constexpr (MX) {
       wtile_4 = a.w4 + (long)n0 * a.ldw4;
@@ -1541,15 +1600,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     if (group == 0) plain_barrier();
     // every wave is past its last LDS read: the rings may be refilled for the next part while this one's results go out
     const int e_kind = kind, e_m0 = m0, e_n0 = n0;
-    // Statistics epilogue: the parameters of the first 64 x 64 block are requested BEFORE the next part's DMA - memory
-    // loads return in order, and behind the two tile steps open_part puts in flight (first touches of activation rows)
-    // they arrive only after the pipeline fill.  (The planes epilogue has 56 parameter registers per block; held across
-    // open_part they spill 160 dwords and the kernel loses a third: it fetches them afterwards.)
-    constexpr bool EARLY = (EPI == kEpiStats);
-    EpiRegs er0;
-    if (EARLY && e_kind != 1) epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + col_w, lane, er0);
+    const float* e_par = (const float*)(smem + PB + (part & 1) * 1536);
     if (part + 1 < n_parts) open_part(part + 1);
-    if (!EARLY && e_kind != 1) epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + col_w, lane, er0);
 
     if (e_kind == 1) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1572,15 +1624,17 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
         // two 64 x 64 blocks side by side: same rows, columns e_n0 and e_n0 + 64.  The group maxima of the planes
         // epilogue are carried across both (one reduction and one atomic per 16-row group and wave).
         float gm[4] = {0.f, 0.f, 0.f, 0.f};
-        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0, lane, er0, gm, 1);
-        if constexpr (NH > 1) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
           EpiRegs er;
-          epilogue_prefetch<EPI>(a, e_m0 + row_w, e_n0 + 64, lane, er);
-          gemm_epilogue<PREC, EPI>(a, acc[NH - 1], e_m0 + row_w, e_n0 + 64, lane, er, gm, 2);
+          epilogue_prefetch_lds<EPI>(a, e_par, e_m0 + row_w, h * 64, lane, er);
+          gemm_epilogue<PREC, EPI>(a, acc[h], e_m0 + row_w, e_n0 + h * 64, lane, er, gm, h == 0 ? 1 : 2);
         }
       } else {
+        EpiRegs er;
+        epilogue_prefetch_lds<EPI>(a, e_par, e_m0 + row_w, col_w, lane, er);
         float gm[4] = {0.f, 0.f, 0.f, 0.f};
-        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0 + col_w, lane, er0, gm, 0);
+        gemm_epilogue<PREC, EPI>(a, acc[0], e_m0 + row_w, e_n0 + col_w, lane, er, gm, 0);
       }
     }
   }
@@ -1657,7 +1711,7 @@ unsigned sk_last_error() {
 // True when the stream-K variant with MF fragments per wave can run this launch.
 template <int PREC, int MF>
 static bool sk_applicable(const GemmArgs& a) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 256 : 0);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 256 + 2 * 1536;
   if (lds > 160 * 1024) return false;
   const int rows = a.m_tiles * kBM;
   if (rows % (64 * MF)) return false;
@@ -1669,7 +1723,7 @@ static bool sk_applicable(const GemmArgs& a) {
 
 template <int PREC, int EPI, int MF>
 static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 256 : 0);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 256 + 2 * 1536;
   if constexpr (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {
