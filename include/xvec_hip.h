@@ -201,18 +201,22 @@ typedef struct {
   float* out_f32; int32_t ldf; int32_t m_valid;
   float* partial; int32_t ldp; const int8_t* grp_range;
   void* hip_stream;
-  /* XV_PREC_FP16MX: e2m1 residual plane [n_pad][ldw4 bytes] in K-walk order + one E8M0 scale per row (see kernels.h);
+  /* XV_PREC_FP16MX: e2m1 residual plane [n_pad][ldw4 bytes] in K-walk order + its E8M0 scales, one per row, block of four K
+   * steps and lane group, in the staging order of this epilogue (xv_tile_mx_scales; see kernels.h);
    * gmax_out (epilogue 0, any precision): device uint32 [rows/16], receives the group maxima of the output plane */
   const void* w4; int32_t ldw4; const void* w4_scale;
   void* gmax_out;
 } xv_gemm_desc;
 /* Host helper for the test above: packs the e2m1 residual plane of one weight matrix exactly like xv_model_pack does
  * (w, w_hi_f16: [n_pad][k_len] row-major, k_len = sum of the segments' k_len; seg_src[j] equal = same source plane).
- * w4 receives n_pad * (k_len / 128 * 64) bytes, w4_scale n_pad bytes.  XV_ERR_ARG when the walk has a group that is
+ * w4 receives n_pad * (k_len / 128 * 64) bytes, w4_scale n_pad * (k_len / 32) bytes.  XV_ERR_ARG when the walk has a group that is
  * not a multiple of four steps. */
 xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg,
                               const int32_t* seg_src, const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4,
                               uint8_t* w4_scale);
+/* natural[n_pad][k_len / 32] (what xv_pack_mx_residual wrote) -> the order the kernels stage the scales in for the given
+ * epilogue (xv_gemm_desc.epilogue): n_pad * (k_len / 32) bytes.  n_pad must be a multiple of 128. */
+xv_status xv_tile_mx_scales(const uint8_t* natural, int32_t n_pad, int32_t k_len, int32_t epilogue, uint8_t* tiled);
 xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d);
 
 #ifdef __cplusplus

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
-    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual",
+    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_tile_mx_scales",
 ]
 
 _lib = None
@@ -120,6 +120,7 @@ def lib():
                                                  ctypes.POINTER(ctypes.c_void_p)]
     L.xv_pack_mx_residual.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.xv_tile_mx_scales.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     L.xv_ctx_free.argtypes = [ctypes.c_void_p]
     L.xv_ctx_free.restype = None
     L.xv_ctx_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ModelInfo), ctypes.POINTER(ctypes.c_int32),
@@ -374,7 +375,8 @@ def kernel_tdnn_gemm(desc):
 
 
 def pack_mx_residual(w, w_hi_f16, segs):
-    """e2m1 residual plane + per-row E8M0 scales of XV_PREC_FP16MX for one weight matrix (host; no GPU).
+    """e2m1 residual plane + E8M0 scales [n_pad, K / 32] (one per block of four K steps and lane group) of XV_PREC_FP16MX
+    for one weight matrix (host; no GPU).
     w: float32 [n_pad, K]; w_hi_f16: uint16 [n_pad, K] (fp16 bit patterns); segs: [(source id, row shift, k_len)]."""
     import numpy as np
     w = np.ascontiguousarray(w, dtype=np.float32)
@@ -385,7 +387,16 @@ def pack_mx_residual(w, w_hi_f16, segs):
     klen = np.array([s[2] for s in segs], dtype=np.int32)
     assert int(klen.sum()) == K and K % 128 == 0
     w4 = np.zeros((n_pad, K // 128 * 64), dtype=np.uint8)
-    sc = np.zeros(n_pad, dtype=np.uint8)
+    sc = np.zeros((n_pad, K // 32), dtype=np.uint8)
     _check(lib().xv_pack_mx_residual(w.ctypes.data, hi.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data,
                                      klen.ctypes.data, w4.ctypes.data, sc.ctypes.data))
     return w4, sc
+
+
+def tile_mx_scales(scales, epilogue):
+    """natural [n_pad, K / 32] scales of pack_mx_residual -> the staging order GemmDesc.w4_scale wants for `epilogue`."""
+    import numpy as np
+    sc = np.ascontiguousarray(scales, dtype=np.uint8)
+    out = np.zeros(sc.size, dtype=np.uint8)
+    _check(lib().xv_tile_mx_scales(sc.ctypes.data, sc.shape[0], sc.shape[1] * 32, int(epilogue), out.ctypes.data))
+    return out

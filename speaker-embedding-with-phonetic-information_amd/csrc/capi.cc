@@ -500,8 +500,17 @@ xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t 
     std::vector<float> res(k_pad);
     for (int n = 0; n < n_pad; ++n) {
       for (int k = 0; k < k_pad; ++k) res[k] = w[(size_t)n * k_pad + k] - xv::host_f16_to_f32(w_hi_f16[(size_t)n * k_pad + k]);
-      w4_scale[n] = xv::PackMxRow(res.data(), k_pad, step_wcol.data(), w4 + (size_t)n * ldw4);
+      xv::PackMxRow(res.data(), k_pad, step_wcol.data(), w4 + (size_t)n * ldw4, w4_scale + (size_t)n * (k_pad / xv::kBK));
     }
+    return XV_OK;
+  });
+}
+
+xv_status xv_tile_mx_scales(const uint8_t* natural, int32_t n_pad, int32_t k_len, int32_t epilogue, uint8_t* tiled) {
+  if (!natural || !tiled || n_pad < 1 || n_pad % xv::kBN || k_len < 128 || k_len % 128)
+    return Fail(XV_ERR_ARG, "xv_tile_mx_scales: bad argument");
+  return Guard([&] {
+    xv::TileMxScales(natural, n_pad, k_len / xv::kBK, epilogue != xv::kEpiStats, tiled);
     return XV_OK;
   });
 }

@@ -13,7 +13,7 @@ namespace xv {
 namespace {
 
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual plane
 constexpr uint64_t kNone = ~0ull;
 
 struct BlobHeader {
@@ -34,7 +34,7 @@ struct BlobLayer {
   int32_t src_layer[kMaxSeg], src_offset[kMaxSeg], src_dim[kMaxSeg];
   int32_t in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
   uint64_t w_hi, w_lo, bias, scale, offset;  // relative to data_offset
-  uint64_t w4, w4_scale;                     // kPrecFp16Mx residual plane + per-row E8M0 scales, or kNone
+  uint64_t w4, w4_scale;                     // kPrecFp16Mx residual plane + its E8M0 scales in both tile orders, or kNone
   int32_t ldw4, reserved;
 };
 
@@ -59,27 +59,47 @@ inline uint64_t Align256(uint64_t x) { return (x + 255) & ~255ull; }
 
 }  // namespace
 
-uint8_t PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row) {
-  float mx = 0.f;
-  for (int k = 0; k < k_pad; ++k) mx = std::max(mx, std::fabs(res[k]));
-  int e8 = 127;
-  if (mx > 0.f && std::isfinite(mx)) {
-    // smallest power of two 2^E with max |r| / 2^E <= 6 (the largest e2m1 value)
-    int ex;
-    const float m = frexpf(mx / 6.f, &ex);   // mx / 6 = m * 2^ex, m in [0.5, 1)
-    const int E = (m == 0.5f) ? ex - 1 : ex;
-    e8 = std::min(std::max(127 + E, 1), 254);
-  }
-  const float inv_s = ldexpf(1.f, 127 - e8);
+void PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row, uint8_t* scales) {
   const int nblk = k_pad / kBK / 4;
   memset(row, 0, (size_t)nblk * 64);
   for (int blk = 0; blk < nblk; ++blk)
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+      // the 32 values lane group g holds of this block: columns 8 g .. 8 g + 7 of each of its four steps
+      float mx = 0.f;
+      for (int e = 0; e < 32; ++e) mx = std::max(mx, std::fabs(res[step_wcol[4 * blk + e / 8] + 8 * g + e % 8]));
+      int e8 = 127;
+      if (mx > 0.f && std::isfinite(mx)) {
+        // smallest power of two 2^E with max |r| / 2^E <= 6 (the largest e2m1 value)
+        int ex;
+        const float m = frexpf(mx / 6.f, &ex);   // mx / 6 = m * 2^ex, m in [0.5, 1)
+        const int E = (m == 0.5f) ? ex - 1 : ex;
+        e8 = std::min(std::max(127 + E, 1), 254);
+      }
+      scales[4 * blk + g] = (uint8_t)e8;
+      const float inv_s = ldexpf(1.f, 127 - e8);
       for (int e = 0; e < 32; ++e) {
         const int col = step_wcol[4 * blk + e / 8] + 8 * g + e % 8;
         row[blk * 64 + g * 16 + e / 2] |= (uint8_t)(ToE2M1(res[col] * inv_s) << (4 * (e & 1)));
       }
-  return (uint8_t)e8;
+    }
+}
+
+void TileMxScales(const uint8_t* natural, int n_pad, int nsteps, bool weights_are_operand_a, uint8_t* tiled) {
+  const int nblk = nsteps / 4;
+  for (int t = 0; t < n_pad / kBN; ++t)
+    for (int rho = 0; rho < kBN; ++rho) {
+      // LDS row rho of a weight tile holds weight row n0 + perm(rho) (kernels.hip, swap_fields): the fragment rows of
+      // the "weights as MFMA A operand" orientation are permuted inside each 64-row half
+      int prm = rho;
+      if (weights_are_operand_a) {
+        const int p = (rho >> 4) & 3, g = (rho >> 2) & 3, r = rho & 3;
+        prm = (rho & 64) | ((p >> 1) << 5) | (g << 3) | ((p & 1) << 2) | r;
+      }
+      const uint8_t* src = natural + (size_t)(t * kBN + prm) * nsteps;
+      const int h = rho >> 6, w = (rho >> 4) & 3, i = rho & 15;
+      for (int b = 0; b < nblk; ++b)
+        for (int g = 0; g < 4; ++g) tiled[((size_t)t * nblk + b) * 512 + h * 256 + (i * 4 + g) * 4 + w] = src[4 * b + g];
+    }
 }
 
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
@@ -148,7 +168,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         b.w4 = cur;
         cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4);
         b.w4_scale = cur;
-        cur = Align256(cur + (uint64_t)b.n_pad);
+        cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);   // both tile orders (TileMxScales)
       }
     }
   }
@@ -238,11 +258,10 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         }
       }
       uint8_t* w4 = data + b.w4;
-      uint8_t* w4s = data + b.w4_scale;
+      const int nsc = b.k_pad / kBK;   // scales per row
+      std::vector<uint8_t> nat((size_t)b.n_pad * nsc, 127);
       std::vector<float> res(b.k_pad);
-      for (int n = 0; n < b.n_pad; ++n) {
-        w4s[n] = 127;
-        if (n >= L.out_dim) continue;
+      for (int n = 0; n < L.out_dim; ++n) {
         for (int k = 0; k < b.k_pad; ++k) {
           float r = 0.f;
           if (src_col[k] >= 0) {
@@ -251,8 +270,10 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           }
           res[k] = r;
         }
-        w4s[n] = PackMxRow(res.data(), b.k_pad, step_wcol.data(), w4 + (size_t)n * b.ldw4);
+        PackMxRow(res.data(), b.k_pad, step_wcol.data(), w4 + (size_t)n * b.ldw4, nat.data() + (size_t)n * nsc);
       }
+      TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4_scale);
+      TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4_scale + (size_t)b.n_pad * nsc);
     }
     float* bias = (float*)(data + b.bias);
     float* scale = (float*)(data + b.scale);
@@ -328,7 +349,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
            inside(b.scale, (uint64_t)b.n_pad * 4) && inside(b.offset, (uint64_t)b.n_pad * 4);
       if (b.w4 != kNone)
         ok = ok && b.ldw4 == b.k_pad / kBK / 4 * 64 && (b.k_pad / kBK) % 4 == 0 && inside(b.w4, (uint64_t)b.n_pad * b.ldw4) &&
-             b.w4_scale != kNone && inside(b.w4_scale, (uint64_t)b.n_pad);
+             b.w4_scale != kNone && inside(b.w4_scale, 2 * (uint64_t)b.n_pad * (uint64_t)(b.k_pad / kBK));
       if (!ok) throw EngineError("model blob: layer " + std::to_string(i) + " is inconsistent");
     }
     BlobLayerInfo li;
@@ -880,6 +901,8 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         ga.ldo = li.n_pad;
       }
     }
+    // scales of the residual plane in the tile order of this epilogue's operand orientation (TileMxScales)
+    if (ga.w4_scale && epi == kEpiStats) ga.w4_scale += (size_t)li.n_pad * (li.k_pad / kBK);
     arm(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
     if (li.segment_level || plan.rows_fast == 0) {
       Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");

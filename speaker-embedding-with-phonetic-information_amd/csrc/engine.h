@@ -28,8 +28,15 @@ struct EngineError : public std::runtime_error {
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision);
 
 // kPrecFp16Mx: e2m1 image of one row of weight residuals res[k_pad] (K-contiguous, padded like the fp16 planes) in the
-// order the kernels walk the K steps (step_wcol from PlanWalkSteps, kernels.h); returns the row's E8M0 scale.
-uint8_t PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row);
+// order the kernels walk the K steps (step_wcol from PlanWalkSteps, kernels.h), with one E8M0 scale per block of four
+// steps and lane group g (the 32 values columns 8 g .. 8 g + 7 of each of the four steps - what one lane group of a
+// 16x16x128 operand holds, the granularity of the instruction's scale operand): scales[k_pad / 32], index 4 * block + g.
+void PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row, uint8_t* scales);
+// The scales of all rows, natural[n_pad][nsteps], in the order the kernels stage them: 512 bytes per (128-row tile, block
+// of four steps) = [64-row half][fragment row i][lane group g][fragment w of the half]: lane (i, g) of a wave reads the
+// four scale bytes of its four weight fragments of a half as one dword.  weights_are_operand_a: the planes / f32
+// epilogues (LDS rows of a weight tile permuted, kernels.hip swap_fields); false: the statistics epilogue.
+void TileMxScales(const uint8_t* natural, int n_pad, int nsteps, bool weights_are_operand_a, uint8_t* tiled);
 
 struct BlobLayerInfo {
   std::string name;

@@ -144,10 +144,12 @@ struct GemmArgs {
   int ldw;
   // kPrecFp16Mx: e2m1 residual plane [n_pad][ldw4 bytes]: 64 bytes per (row, block of four K steps in walk order) =
   // four 16-byte lane-group chunks g; nibble e of chunk g = weight column step_wcol[4 b + e / 8] + 8 g + e % 8;
-  // value = (w - w_hi) / 2^(w4_scale[row] - 127)
+  // value = (w - w_hi) / 2^(w4_scale[row][4 b + g] - 127): one scale per lane-group chunk, the granularity of the
+  // scale operand of v_mfma_scale_f32_16x16x128_f8f6f4 (with one scale per row the 4-bit residual left 1/6 of the
+  // weight rounding error, 7.0e-5 on the embedding; per chunk: 5.5e-5)
   const uint8_t* w4;
   int ldw4;
-  const uint8_t* w4_scale;   // [n_pad] E8M0
+  const uint8_t* w4_scale;   // n_pad * total_ksteps E8M0 bytes in staging order (engine.h TileMxScales): 512 per (tile, block)
   int m_tiles;           // rows / kBM
   int n_tiles;           // n_pad / kBN
   int relu;

@@ -705,6 +705,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   constexpr int XSLOT = NPX * XT;
   constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;             // weight ring behind the activation ring
+  constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: scales of the residual tiles, three blocks x 128 rows x 4 lane groups
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -791,6 +792,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
           const unsigned st4 = __builtin_amdgcn_readfirstlane(lds_base + WBASE + ((istep >> 2) % 3) * WSLOT + WT + wave * 1024);
           glds16_asm(wrow_4 + (istep >> 2) * 64, st4);
           n += 1;
+          if (wave < 2) {   // and its scales: 512 contiguous bytes per (tile, block), already in reading order
+            glds4_sbase(a.w4_scale + ((long)nt * (a.total_ksteps >> 2) + (istep >> 2)) * 512 + wave * 256, (unsigned)lane * 4u,
+                        lds_base + SCB + ((istep >> 2) % 3) * 512 + wave * 256);
+            n += 1;
+          }
         }
       } else if constexpr (WSPLIT) {
         glds16_asm(wrow_lo + wcol, st + WT);
@@ -826,12 +832,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       }
     }
   };
-  if constexpr (MX) {
-    load_xscales(gi.gmax);
-    const uint8_t* sp = a.w4_scale + n0 + wave_n * 64;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) ws_v |= (int)sp[SWAP ? swap_fields(p * 16 + (lane & 15)) : p * 16 + (lane & 15)] << (8 * p);
-  }
+  if constexpr (MX) load_xscales(gi.gmax);
 
   // ---- read side ---------------------------------------------------------------------------------------------
   int rg = 0, rkk = 0, rj = 0;
@@ -920,6 +921,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       const char* w4s = smem + WBASE + (rblk % 3) * WSLOT + WT + w_rd;
 #pragma unroll
       for (int w = 0; w < 4; ++w) f.wh[w] = *(const s16x8*)(w4s + w * 1024);
+      // scales of the block: one dword = the four fragments of this wave's 64-row half for (fr_i, fr_g)
+      ws_v = *(const int*)(smem + SCB + (rblk % 3) * 512 + wave_n * 256 + (fr_i * 4 + fr_g) * 4);
       asm volatile("s_nop 4" ::: "memory");
       static_for<0, 4>([&](auto P) {
         static_for<0, 4>([&](auto Q) {
@@ -1136,8 +1139,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   constexpr int XSLOT = NPX * XT;
   constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;
-  constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: the E8M0 scales of the tile's 128 weight rows (256 bytes reserved)
-  constexpr int PB = SCB + 256;                // epilogue parameters of the tile's columns, two buffers of 3 x 128 floats
+  constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: scales of the residual tiles, three blocks x 128 rows x 4 lane groups
+  constexpr int PB = SCB + 1536;               // epilogue parameters of the tile's columns, two buffers of 3 x 128 floats
   constexpr int KQ = MX ? 4 : 1;               // K steps are dealt out in units of KQ (a 128-deep block is never cut)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1186,6 +1189,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const uint16_t* wtile_hi = nullptr;   // weight row n0, wave-uniform
   const uint16_t* wtile_lo = nullptr;
   const uint8_t* wtile_4 = nullptr;
+  const uint8_t* wtile_s = nullptr;    // scales of the residual plane: this column tile's 512-byte pieces, one per block
   const unsigned woff = (unsigned)(w_rho * a.ldw + ld_chunk * 8) * 2u;   // this lane's row / chunk inside the tile
   const unsigned woff4 = MX ? (unsigned)(w_rho * a.ldw4 + ld_chunk * 16) : 0u;
   int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0, istep = 0;
@@ -1244,6 +1248,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           const unsigned st4 = __builtin_amdgcn_readfirstlane(lds_base + WBASE + ((istep >> 2) % 3) * WSLOT + WT + wave * 1024);
           glds16_sbase(wtile_4 + (istep >> 2) * 64, woff4, st4);
           n += 1;
+          if (wave < 2) {   // and its scales: 512 contiguous bytes per (tile, block), already in reading order
+            glds4_sbase(wtile_s + (istep >> 2) * 512 + wave * 256, (unsigned)lane * 4u,
+                        lds_base + SCB + ((istep >> 2) % 3) * 512 + wave * 256);
+            n += 1;
+          }
         }
       } else if constexpr (WSPLIT) {
         glds16_sbase(wtile_lo + wcol, woff, st + WT);
@@ -1401,6 +1410,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       const char* w4s = smem + WBASE + (rblk % 3) * WSLOT + WT + w_rd;
 #pragma unroll
       for (int w = 0; w < WF; ++w) f.wh[w] = *(const s16x8*)(w4s + w * 1024);
+      // scales of the block (staged with its residual tile): one dword per 64-row half = the bytes of its four
+      // fragments for this lane's (fr_i, fr_g); fragment w in byte w & 3 of word w >> 2
+      const char* sc = smem + SCB + (rblk % 3) * 512 + (col_w >> 6) * 256 + (fr_i * 4 + fr_g) * 4;
+#pragma unroll
+      for (int h = 0; h < WW; ++h) ws_v[h] = *(const int*)(sc + h * 256);
       asm volatile("s_nop 4" ::: "memory");   // v_cvt results -> MFMA operands
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -1486,28 +1500,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     xs_uvec xg;
     if constexpr (MX) {
       wtile_4 = a.w4 + (long)n0 * a.ldw4;
-      // the activation scales travel (scalar cache) while the DMA of the first steps is issued; the scales of the
-      // tile's weight rows go to LDS with that DMA and are picked up after the fill (a per-lane byte gather from
-      // global memory here cost a full load latency in front of the first DMA)
+      wtile_s = a.w4_scale + (long)nt * (S >> 2) * 512;
+      // the activation scales travel (scalar cache) while the DMA of the first steps is issued
       xs_request(gi.gmax, xg);
-      if (wave == 0) glds4_sbase(a.w4_scale + n0, (unsigned)(lane & 31) * 4u, lds_base + SCB);
     }
     issue_step();
     if (n_steps > 1) issue_step();
     xs_finish(xg);
-  };
-  // kPrecFp16Mx, after the fill wait of a part: E8M0 scales of the weight rows behind this lane's fragments (LDS row
-  // p * 16 + fr_i of each 64-row slice), fragment p in byte p
-  auto load_wscales = [&]() __attribute__((always_inline)) {
-    if constexpr (MX) {
-      const uint8_t* sc = (const uint8_t*)smem + SCB + col_w;
-#pragma unroll
-      for (int h = 0; h < WW; ++h) {
-        ws_v[h] = 0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) ws_v[h] |= (int)sc[h * 64 + (SWAP ? swap_fields(p * 16 + fr_i) : p * 16 + fr_i)] << (8 * p);
-      }
-    }
   };
 
   open_part(0);
@@ -1558,7 +1557,6 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     // (open_part leaves no compiler-tracked memory load behind: a vmcnt(0) of hipcc's in front of a first use INSIDE
     // the K loop would drain the LDS-DMA queue on every pass.)
     wait_and_barrier(0);               // the first two steps have landed (and the previous epilogue's stores are out)
-    load_wscales();
     if (group == 1) plain_barrier();
     Frags f;
     const int ns = n_steps;
@@ -1711,7 +1709,7 @@ unsigned sk_last_error() {
 // True when the stream-K variant with MF fragments per wave can run this launch.
 template <int PREC, int MF>
 static bool sk_applicable(const GemmArgs& a) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 256 + 2 * 1536;
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536;
   if (lds > 160 * 1024) return false;
   const int rows = a.m_tiles * kBM;
   if (rows % (64 * MF)) return false;
@@ -1723,7 +1721,7 @@ static bool sk_applicable(const GemmArgs& a) {
 
 template <int PREC, int EPI, int MF>
 static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 256 + 2 * 1536;
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536;
   if constexpr (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {
@@ -1764,7 +1762,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 1536 : 0);
   static std::atomic<unsigned long long> attr_done{0};
   int attr_dev = 0;
   if (lds_attr_needed(&attr_done, &attr_dev)) {

@@ -243,6 +243,7 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
     w4, w4s = P.pack_mx_residual(W.cpu().numpy(), Wh.cpu().view(torch.int16).numpy().view(np.uint16),
                                  [(s[0], s[2], s[3]) for s in segs])
     w4_d, w4s_d = torch.from_numpy(w4).to(dev), torch.from_numpy(w4s).to(dev)
+    w4t_d = torch.from_numpy(P.tile_mx_scales(w4s, epi)).to(dev)    # the same scales in the kernels' staging order
     # group maxima of the source planes (rows relative to logical row 0)
     gmax = []
     for i in range(nsrc):
@@ -257,7 +258,7 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
         d.seg[j].ld, d.seg[j].row_shift, d.seg[j].k_len = src_ld[si], shift, klen
         d.seg[j].gmax = gmax[si].data_ptr()
     d.w_hi, d.w_lo, d.ldw = Wh.data_ptr(), None, K
-    d.w4, d.ldw4, d.w4_scale = w4_d.data_ptr(), K // 128 * 64, w4s_d.data_ptr()
+    d.w4, d.ldw4, d.w4_scale = w4_d.data_ptr(), K // 128 * 64, w4t_d.data_ptr()
     d.rows, d.n_pad = rows, n_pad
     d.bias, d.scale, d.offset = bias.data_ptr(), scale.data_ptr(), offset.data_ptr()
     d.relu, d.bn = 1, 1
@@ -266,8 +267,25 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
     # ---- reference: fp16 x . fp16 w_hi + q4(x / sx) sx . q4((w - w_hi) / sw) sw, in fp64
     Whd = Wh.double()
     R = W.double() - Whd
-    e8 = w4s_d.double()
-    sw = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev), e8 - 127)[:, None]
+    # scale of weight element (n, k): byte 4 * block + lane group of row n, where k is column c of K step `step` of the
+    # walk (consecutive segments over one source = one group, walked chunk by chunk, offset by offset), block = step // 4
+    # and lane group = (c % 32) // 8
+    step_of_col = np.empty(K, dtype=np.int64)
+    k0 = base = j = 0
+    while j < len(segs):
+        ns = 1
+        while j + ns < len(segs) and segs[j + ns][0] == segs[j][0] and segs[j + ns][3] == segs[j][3]:
+            ns += 1
+        klen = segs[j][3]
+        for jj in range(ns):
+            c = np.arange(klen)
+            step_of_col[k0 + jj * klen + c] = base + (c // 32) * ns + jj
+        base += ns * klen // 32
+        k0 += ns * klen
+        j += ns
+    sidx = torch.from_numpy(4 * (step_of_col // 4) + (np.arange(K) % 32) // 8).to(dev)
+    e8 = w4s_d.double()[:, sidx]
+    sw = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev), e8 - 127)
     Rq = _q_e2m1(R / sw, torch) * sw
     z = torch.zeros(rows, n_pad, dtype=torch.float64, device=dev)
     k0 = 0
