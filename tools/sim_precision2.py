@@ -9,7 +9,12 @@ than two fp16 MFMA passes per product - the question VERDICT r01 item 1 asks to 
             (fp4 / fp6 operands, 4x the fp16 rate) or 1.5 passes (an fp8 operand, 2x).  The weight residual uses one
             power-of-two scale per (output row, 32-element K block) like the MX formats; the activations one fixed scale.
 
-usage: sim_precision2.py [topology] [T ...]"""
+  mx2       the same plus a third term q4(x - fp16(x)) . q4(w): the 4-bit residual of the ACTIVATION rounding (it would have
+            to come from the producing epilogue) against a 4-bit image of the weights - 1.5 passes.  Round 2, after the
+            1.25-pass mode was built: the activation rounding is what is left of its error, and all of it on a
+            heavy-tailed model (helpers.trained_like_model; run with topology "trained").
+
+usage: sim_precision2.py [topology | trained] [T ...]"""
 import os
 import sys
 
@@ -126,6 +131,18 @@ class SchemeEval(H.xo.GraphEvaluator):
                     sx = 2.0 ** np.ceil(np.log2(np.abs(xq).max() / GRIDS[fa][-1])) * f
                 xa = qgrid(xq / sx, GRIDS[fa]) * sx
                 return xq @ wh + xa @ wl + b
+            if sc[0] == "mx2":
+                wblock = sc[1]
+                if key not in self.cache:
+                    wh = q16(W)
+                    self.cache[key] = (wh, q_block_scaled(W - wh, GRIDS["4"], block=wblock if wblock else W.shape[0]),
+                                       q_block_scaled(W, GRIDS["4"], block=32))
+                wh, wl, w4 = self.cache[key]
+                xa = q_block_scaled(xq, GRIDS["4"], block=32, axis=1)
+                out = xq @ wh + xa @ wl + b
+                if sc[2]:
+                    out = out + q_block_scaled(x - xq, GRIDS["4"], block=32, axis=1) @ w4
+                return out
             raise ValueError(sc)
         return super()._apply(w, x)
 
@@ -145,9 +162,14 @@ def main():
         "mx x4.w6 blk32": ("mx", "4", "6", "auto", False, 32),
         "mx x4.w6 per-row": ("mx", "4", "6", "auto", False, 0),
         "mx x4.w6 per-row x*.5": ("mx", "4", "6", "auto*.5", False, 0),
+        "1.25 pass, w scale/row": ("mx2", 0, False),
+        "1.25 pass, w scale/blk32": ("mx2", 32, False),
+        "1.5 pass (+x_lo), w/row": ("mx2", 0, True),
+        "1.5 pass (+x_lo), w/blk32": ("mx2", 32, True),
     }
-    for seed in (123, 7, 2024):
-        net, line = H.synth_model(topo, seed)
+    trained = topo == "trained"
+    for seed in ((11,) if trained else (123, 7, 2024)):
+        net, line = H.trained_like_model("v2_xvector", seed) if trained else H.synth_model(topo, seed)
         n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
         n2.apply_nnet_config(line)
         ev64 = H.xo.GraphEvaluator(n2, np.float64)
