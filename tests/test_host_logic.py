@@ -231,3 +231,64 @@ def test_cli_contract_without_gpu(tmp_path):
                  "ark:/dev/null", "ark:/dev/null")
         # fails loudly: there is no CPU fallback behind --use-gpu=no
         assert r.returncode == 255 and b"no CPU path" in r.stderr and b"--use-gpu=no requested" in r.stderr
+
+
+E2M1 = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def _swap_fields(rho):
+    p, g, r = (rho >> 4) & 3, (rho >> 2) & 3, rho & 3
+    return ((p >> 1) << 5) | (g << 3) | ((p & 1) << 2) | r
+
+
+@pytest.mark.parametrize("segs", [[(0, 0, 512)], [(0, -2, 256), (0, 0, 256), (0, 2, 256)], [(0, 0, 256), (1, 0, 128)]],
+                         ids=["plain", "spliced", "two_sources"])
+def test_mx_residual_packing_and_scale_tiling(segs):
+    """XV_PREC_FP16MX packer (host code, no GPU): every lane-group chunk of 32 residuals gets the smallest power-of-two
+    scale that keeps it inside the e2m1 range, the nibbles are the nearest grid values, and xv_tile_mx_scales puts the
+    scale of LDS row rho / lane group g where the kernels' dword read expects it (both operand orientations)."""
+    rng = np.random.default_rng(3)
+    n_pad, K = 256, sum(s[2] for s in segs)
+    w = (rng.standard_normal((n_pad, K)) * rng.uniform(0.01, 4.0, (n_pad, 1))).astype(np.float32)
+    hi = w.astype(np.float16)
+    res = w.astype(np.float64) - hi.astype(np.float64)
+    w4, sc = P.pack_mx_residual(w, hi.view(np.uint16), segs)
+    assert w4.shape == (n_pad, K // 2) and sc.shape == (n_pad, K // 32)
+    # walk order: consecutive segments over one source form a group, walked 32-column chunk by chunk, offset by offset
+    step_cols = []
+    k0 = j = 0
+    while j < len(segs):
+        ns = 1
+        while j + ns < len(segs) and segs[j + ns][0] == segs[j][0] and segs[j + ns][2] == segs[j][2]:
+            ns += 1
+        klen = segs[j][2]
+        for kk in range(klen // 32):
+            for jj in range(ns):
+                step_cols.append(k0 + jj * klen + kk * 32)
+        k0 += ns * klen
+        j += ns
+    assert len(step_cols) == K // 32
+    nib = np.stack([w4 & 15, w4 >> 4], axis=-1).reshape(n_pad, K // 128, 4, 32)      # [row][block][lane group][element]
+    val = np.where(nib & 8, -1.0, 1.0) * E2M1[nib & 7]
+    for b in range(K // 128):
+        for g in range(4):
+            cols = np.array([step_cols[4 * b + e // 8] + 8 * g + e % 8 for e in range(32)])
+            r = res[:, cols]
+            s = 2.0 ** (sc[:, 4 * b + g].astype(np.float64) - 127)[:, None]
+            m = np.abs(r).max(axis=1)
+            assert np.all(m <= 6 * s[:, 0] * (1 + 1e-12)) and np.all((m > 3 * s[:, 0]) | (m == 0))
+            # nearest grid value: the reconstruction error is at most half the local grid spacing (1 above 4, ...)
+            err = np.abs(val[:, b, g, :] * s - r) / s
+            a = np.abs(r / s)
+            half_gap = np.where(a >= 4, 1.0, np.where(a >= 2, 0.5, 0.25))
+            assert np.all(err <= half_gap + 1e-9)
+    for epi, swap in ((0, True), (2, False)):
+        tiled = P.tile_mx_scales(sc, epi)
+        nblk = K // 128
+        for t in range(n_pad // 128):
+            for rho in (0, 1, 17, 63, 64, 100, 127):
+                row = t * 128 + ((rho & 64) | _swap_fields(rho & 63) if swap else rho)
+                h, wf, i = rho >> 6, (rho >> 4) & 3, rho & 15
+                for b in (0, nblk - 1):
+                    for g in range(4):
+                        assert tiled[(t * nblk + b) * 512 + h * 256 + (i * 4 + g) * 4 + wf] == sc[row, 4 * b + g]
