@@ -43,10 +43,16 @@ typedef enum {
                           outputs (they run XV_PREC_FP16X3) */
   XV_PREC_AUTO = 5,    /* XV_PREC_FP16MX for chunks that pool >= 300 frames (XVEC_FAST_MIN_POOLED), XV_PREC_FP16X3 for
                           shorter ones; the choice depends on the chunk's own length only */
-  XV_PREC_FP16MX = 6   /* XV_PREC_FP16X2 with the second product (activations x weight residual) done on block-scaled
+  XV_PREC_FP16MX = 6,  /* XV_PREC_FP16X2 with the second product (activations x weight residual) done on block-scaled
                           4-bit operands at four times the fp16 MFMA rate (v_mfma_scale_f32_16x16x128_f8f6f4): 1.25
                           passes per product.  The residual term is 2^-11 of the product and only has to be good to
                           ~4 bits.  Layers whose K length is not a multiple of 128 run XV_PREC_FP16X2 */
+  XV_PREC_FP16MX2 = 7, /* XV_PREC_FP16MX plus a block-scaled 4-bit product for what the fp16 rounding of the ACTIVATIONS
+                          dropped (the producing layer writes that residual as a 4-bit plane): 1.5 passes per product,
+                          error independent of how well the pooling averages the activation rounding.  Layers whose K
+                          length is not a multiple of 128 run XV_PREC_FP16X3E */
+  XV_PREC_FP16X3E = 8  /* kernel mode of XV_PREC_FP16MX2 passes: XV_PREC_FP16X3 whose planes epilogue writes the fp16
+                          plane + its 4-bit residual instead of two fp16 planes */
 } xv_precision;
 
 typedef struct xv_model xv_model; /* host side: parsed nnet3 model lowered to a TDNN program */
@@ -187,6 +193,9 @@ typedef struct {
   int32_t row_shift;
   int32_t k_len;    /* multiple of 32 */
   const void* gmax; /* XV_PREC_FP16MX: device uint32 [rows/16], float bits of max |x| per 16-row group of this plane */
+  /* XV_PREC_FP16MX2: 4-bit image of (activation - hi), [rows][ld / 2 bytes], and its E8M0 scales [rows][ld / 64 rounded up to a multiple of 4] (what
+   * epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E wrote to out_lo4 / out_lo4_scale), both at logical row 0 */
+  const void* lo4; const void* lo4_scale;
 } xv_seg_desc;
 typedef struct {
   int32_t precision, epilogue; /* epilogue: 0 planes out, 1 fp32 out, 2 per-16-row (sum, sumsq) partials */
@@ -206,6 +215,10 @@ typedef struct {
    * gmax_out (epilogue 0, any precision): device uint32 [rows/16], receives the group maxima of the output plane */
   const void* w4; int32_t ldw4; const void* w4_scale;
   void* gmax_out;
+  /* XV_PREC_FP16MX2: 4-bit image of the weights for the second K walk (xv_pack_mx_weights) + scales in staging order;
+   * out_lo4 / out_lo4_scale (epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E): see xv_seg_desc */
+  const void* w4b; int32_t ldw4b; const void* w4b_scale;
+  void* out_lo4; void* out_lo4_scale;
 } xv_gemm_desc;
 /* Host helper for the test above: packs the e2m1 residual plane of one weight matrix exactly like xv_model_pack does
  * (w, w_hi_f16: [n_pad][k_len] row-major, k_len = sum of the segments' k_len; seg_src[j] equal = same source plane).
@@ -214,7 +227,12 @@ typedef struct {
 xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg,
                               const int32_t* seg_src, const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4,
                               uint8_t* w4_scale);
-/* natural[n_pad][k_len / 32] (what xv_pack_mx_residual wrote) -> the order the kernels stage the scales in for the given
+/* XV_PREC_FP16MX2: the 4-bit image of the weights for the second K walk (w: [n_pad][k_len], the values of the fp16 planes'
+ * domain; every k_len a multiple of 128): w4b receives n_pad * (k_len / 128 * 64) bytes, w4b_scale n_pad * (k_len / 32)
+ * bytes in natural order (tile them with xv_tile_mx_scales). */
+xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
+                             const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale);
+/* natural[n_pad][k_len / 32] (what xv_pack_mx_residual / xv_pack_mx_weights wrote) -> the order the kernels stage the scales in for the given
  * epilogue (xv_gemm_desc.epilogue): n_pad * (k_len / 32) bytes.  n_pad must be a multiple of 128. */
 xv_status xv_tile_mx_scales(const uint8_t* natural, int32_t n_pad, int32_t k_len, int32_t epilogue, uint8_t* tiled);
 xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d);

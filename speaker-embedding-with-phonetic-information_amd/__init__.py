@@ -18,9 +18,9 @@ BIN_DIR = os.path.join(_HERE, "bin")
 
 XV_OK = 0
 XV_ERR_IO, XV_ERR_MODEL, XV_ERR_DEVICE, XV_ERR_ARG, XV_ERR_INTERNAL = 1, 2, 3, 4, 5
-PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO, PREC_FP16MX = 0, 1, 2, 3, 4, 5, 6
+PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO, PREC_FP16MX, PREC_FP16MX2, PREC_FP16X3E = range(9)
 PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3,
-              "fp16x2": PREC_FP16X2, "auto": PREC_AUTO, "fp16mx": PREC_FP16MX}
+              "fp16x2": PREC_FP16X2, "auto": PREC_AUTO, "fp16mx": PREC_FP16MX, "fp16mx2": PREC_FP16MX2}
 # MFMA issue time per algorithmic product in units of one fp16 16x16x32 pass (fp16mx: + one 4-bit 16x16x128 per four)
 MFMA_PASSES = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25}
 EPI_ACT, EPI_F32, EPI_STATS = 0, 1, 2
@@ -39,7 +39,8 @@ class ModelInfo(ctypes.Structure):
 
 class SegDesc(ctypes.Structure):
     _fields_ = [("hi", ctypes.c_void_p), ("lo", ctypes.c_void_p), ("ld", ctypes.c_int32),
-                ("row_shift", ctypes.c_int32), ("k_len", ctypes.c_int32), ("gmax", ctypes.c_void_p)]
+                ("row_shift", ctypes.c_int32), ("k_len", ctypes.c_int32), ("gmax", ctypes.c_void_p),
+                ("lo4", ctypes.c_void_p), ("lo4_scale", ctypes.c_void_p)]
 
 
 class GemmDesc(ctypes.Structure):
@@ -54,7 +55,9 @@ class GemmDesc(ctypes.Structure):
                 ("partial", ctypes.c_void_p), ("ldp", ctypes.c_int32), ("grp_range", ctypes.c_void_p),
                 ("hip_stream", ctypes.c_void_p),
                 ("w4", ctypes.c_void_p), ("ldw4", ctypes.c_int32), ("w4_scale", ctypes.c_void_p),
-                ("gmax_out", ctypes.c_void_p)]
+                ("gmax_out", ctypes.c_void_p),
+                ("w4b", ctypes.c_void_p), ("ldw4b", ctypes.c_int32), ("w4b_scale", ctypes.c_void_p),
+                ("out_lo4", ctypes.c_void_p), ("out_lo4_scale", ctypes.c_void_p)]
 
 
 # every symbol include/xvec_hip.h declares (tests check the library exports exactly these)
@@ -65,7 +68,7 @@ ABI_SYMBOLS = [
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
-    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_tile_mx_scales",
+    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_tile_mx_scales", "xv_pack_mx_weights",
 ]
 
 _lib = None
@@ -120,6 +123,8 @@ def lib():
                                                  ctypes.POINTER(ctypes.c_void_p)]
     L.xv_pack_mx_residual.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.xv_pack_mx_weights.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.xv_tile_mx_scales.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     L.xv_ctx_free.argtypes = [ctypes.c_void_p]
     L.xv_ctx_free.restype = None
@@ -391,6 +396,22 @@ def pack_mx_residual(w, w_hi_f16, segs):
     _check(lib().xv_pack_mx_residual(w.ctypes.data, hi.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data,
                                      klen.ctypes.data, w4.ctypes.data, sc.ctypes.data))
     return w4, sc
+
+
+def pack_mx_weights(w, segs):
+    """4-bit image of a weight matrix for the second K walk of XV_PREC_FP16MX2 + its scales [n_pad, K / 32] (natural order)."""
+    import numpy as np
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    n_pad, K = w.shape
+    src = np.array([s[0] for s in segs], dtype=np.int32)
+    shift = np.array([s[1] for s in segs], dtype=np.int32)
+    klen = np.array([s[2] for s in segs], dtype=np.int32)
+    assert int(klen.sum()) == K and np.all(klen % 128 == 0)
+    w4b = np.zeros((n_pad, K // 2), dtype=np.uint8)
+    sc = np.zeros((n_pad, K // 32), dtype=np.uint8)
+    _check(lib().xv_pack_mx_weights(w.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data, klen.ctypes.data,
+                                    w4b.ctypes.data, sc.ctypes.data))
+    return w4b, sc
 
 
 def tile_mx_scales(scales, epilogue):

@@ -442,6 +442,8 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
       a.seg[j].row_shift = d->seg[j].row_shift;
       a.seg[j].ksteps = d->seg[j].k_len / xv::kBK;
       a.seg[j].gmax = (const unsigned*)d->seg[j].gmax;
+      a.seg[j].lo4 = (const uint8_t*)d->seg[j].lo4;
+      a.seg[j].lo4s = (const uint8_t*)d->seg[j].lo4_scale;
       a.total_ksteps += a.seg[j].ksteps;
     }
     a.w_hi = (const uint16_t*)d->w_hi;
@@ -467,6 +469,14 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
     a.ldw4 = d->ldw4;
     a.w4_scale = (const uint8_t*)d->w4_scale;
     a.gmax_out = (unsigned*)d->gmax_out;
+    a.w4b = (const uint8_t*)d->w4b;
+    a.ldw4b = d->ldw4b;
+    a.w4b_scale = (const uint8_t*)d->w4b_scale;
+    a.out_lo4 = (uint8_t*)d->out_lo4;
+    a.out_lo4s = (uint8_t*)d->out_lo4_scale;
+    if (d->precision == xv::kPrecFp16Mx2 && !xv::gemm_mx2_applicable(a))
+      return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX2 needs what XV_PREC_FP16MX needs and the 4-bit planes of the "
+                              "weights and of every source (whole 128-column steps, sources of at most 512 columns)");
     if (d->precision == xv::kPrecFp16Mx && !xv::gemm_mx_applicable(a))
       return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX needs the residual plane, a group-max table per source, "
                               "K groups of whole 128-column blocks and an even number of 128-row tiles");
@@ -502,6 +512,31 @@ xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t 
       for (int k = 0; k < k_pad; ++k) res[k] = w[(size_t)n * k_pad + k] - xv::host_f16_to_f32(w_hi_f16[(size_t)n * k_pad + k]);
       xv::PackMxRow(res.data(), k_pad, step_wcol.data(), w4 + (size_t)n * ldw4, w4_scale + (size_t)n * (k_pad / xv::kBK));
     }
+    return XV_OK;
+  });
+}
+
+xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
+                             const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale) {
+  if (!w || !seg_src || !seg_shift || !seg_klen || !w4b || !w4b_scale || nseg < 1 || nseg > xv::kMaxSeg || n_pad < 1)
+    return Fail(XV_ERR_ARG, "xv_pack_mx_weights: bad argument");
+  return Guard([&] {
+    long key[xv::kMaxSeg];
+    int shift[xv::kMaxSeg], ksteps[xv::kMaxSeg], k_pad = 0;
+    for (int j = 0; j < nseg; ++j) {
+      if (seg_klen[j] % 128) return Fail(XV_ERR_ARG, "xv_pack_mx_weights: k_len must be a multiple of 128");
+      key[j] = seg_src[j];
+      shift[j] = seg_shift[j];
+      ksteps[j] = seg_klen[j] / xv::kBK;
+      k_pad += seg_klen[j];
+    }
+    xv::WalkGroup wg[xv::kMaxSeg];
+    const int ng = xv::PlanWalkGroups(nseg, key, shift, ksteps, wg);
+    std::vector<int> lo_wcol(k_pad / 128);
+    const int n_lo = xv::PlanWalkLoSteps(ng, wg, lo_wcol.data(), (int)lo_wcol.size());
+    if (n_lo != (int)lo_wcol.size()) return Fail(XV_ERR_ARG, "xv_pack_mx_weights: inconsistent walk");
+    for (int n = 0; n < n_pad; ++n)
+      xv::PackMxWeightsRow(w + (size_t)n * k_pad, lo_wcol.data(), n_lo, w4b + (size_t)n * n_lo * 64, w4b_scale + (size_t)n * n_lo * 4);
     return XV_OK;
   });
 }

@@ -84,6 +84,26 @@ void PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row, 
     }
 }
 
+void PackMxWeightsRow(const float* w, const int* lo_wcol, int n_lo, uint8_t* row, uint8_t* scales) {
+  memset(row, 0, (size_t)n_lo * 64);
+  for (int t = 0; t < n_lo; ++t)
+    for (int g = 0; g < 4; ++g) {
+      const float* c = w + lo_wcol[t] + 32 * g;   // the 32 consecutive columns lane group g holds of this step
+      float mx = 0.f;
+      for (int e = 0; e < 32; ++e) mx = std::max(mx, std::fabs(c[e]));
+      int e8 = 127;
+      if (mx > 0.f && std::isfinite(mx)) {
+        int ex;
+        const float m = frexpf(mx / 6.f, &ex);
+        const int E = (m == 0.5f) ? ex - 1 : ex;
+        e8 = std::min(std::max(127 + E, 1), 254);
+      }
+      scales[4 * t + g] = (uint8_t)e8;
+      const float inv_s = ldexpf(1.f, 127 - e8);
+      for (int e = 0; e < 32; ++e) row[t * 64 + g * 16 + e / 2] |= (uint8_t)(ToE2M1(c[e] * inv_s) << (4 * (e & 1)));
+    }
+}
+
 void TileMxScales(const uint8_t* natural, int n_pad, int nsteps, bool weights_are_operand_a, uint8_t* tiled) {
   const int nblk = nsteps / 4;
   for (int t = 0; t < n_pad / kBN; ++t)

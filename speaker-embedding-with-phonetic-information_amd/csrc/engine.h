@@ -32,6 +32,10 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision);
 // steps and lane group g (the 32 values columns 8 g .. 8 g + 7 of each of the four steps - what one lane group of a
 // 16x16x128 operand holds, the granularity of the instruction's scale operand): scales[k_pad / 32], index 4 * block + g.
 void PackMxRow(const float* res, int k_pad, const int* step_wcol, uint8_t* row, uint8_t* scales);
+// kPrecFp16Mx2: e2m1 image of one row of the weights themselves, w[k_pad], for the second K walk: 64 bytes per 128-column
+// step (lo_wcol from PlanWalkLoSteps), four lane-group chunks of 32 consecutive columns, one E8M0 scale per chunk
+// (scales[4 * n_lo], index 4 * step + g).
+void PackMxWeightsRow(const float* w, const int* lo_wcol, int n_lo, uint8_t* row, uint8_t* scales);
 // The scales of all rows, natural[n_pad][nsteps], in the order the kernels stage them: 512 bytes per (128-row tile, block
 // of four steps) = [64-row half][fragment row i][lane group g][fragment w of the half]: lane (i, g) of a wave reads the
 // four scale bytes of its four weight fragments of a half as one dword.  weights_are_operand_a: the planes / f32

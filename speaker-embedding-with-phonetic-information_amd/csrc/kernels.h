@@ -43,12 +43,22 @@ enum Precision : int {
                     // scale per 16-row group (from the max |x| the producing epilogue recorded), q4(w - w_hi) = a packed
                     // e2m1 plane with one scale per output row.  1.25 MFMA passes per product; the residual term only has
                     // to be good to ~4 bits (it is 2^-11 of the product), DESIGN.md section 3.0.  Frame-level layers only.
+  kPrecFp16Mx2 = 7, // kPrecFp16Mx plus a third term for what the fp16 rounding of the ACTIVATIONS dropped:
+                    // + q4(y - fp16(y)) . q4(w)  (the same block-scaled MFMA, once per 128 columns of K): the producing
+                    // epilogue writes, next to the fp16 plane, the e2m1 image of its rounding residual (one scale per row
+                    // and 64 columns), the packer a 4-bit image of the weights; the consumer walks K a second time in
+                    // 128-column steps whose 4-bit tiles have the shape of the fp16 tiles.  1.5 passes per product; the
+                    // error no longer depends on how well the pooling averages the activation rounding.
+  kPrecFp16x3E = 8, // kPrecFp16x3 whose planes epilogue emits (fp16 plane, 4-bit residual) instead of (hi, lo): the layers
+                    // of a kPrecFp16Mx2 pass that cannot run it themselves (K walk not in whole 128-column blocks)
 };
-constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx; }
-constexpr bool PrecMx(int p) { return p == kPrecFp16Mx; }
-constexpr int PrecXPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3) ? 2 : 1; }   // kernel modes only
+constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16x3E; }
+constexpr bool PrecMx(int p) { return p == kPrecFp16Mx || p == kPrecFp16Mx2; }
+constexpr bool PrecMx2(int p) { return p == kPrecFp16Mx2; }
+constexpr bool PrecEmitsLo4(int p) { return p == kPrecFp16Mx2 || p == kPrecFp16x3E; }   // planes epilogue: fp16 plane + 4-bit residual
+constexpr int PrecXPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x3E) ? 2 : 1; }   // kernel modes only
 // weight planes staged per K step (the 4-bit residual plane of kPrecFp16Mx uses the slot of the fp16 residual plane)
-constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx) ? 2 : 1; }
+constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16x3E) ? 2 : 1; }
 constexpr int PrecPasses(int p) { return PrecXPlanes(p) + PrecWPlanes(p) - 1; }   // MFMAs per algorithmic product (Mx: 1.25)
 
 enum Epilogue : int {
@@ -66,7 +76,14 @@ struct Seg {
   int ksteps;          // K length of the segment / kBK
   int pad_;
   const unsigned* gmax;  // kPrecFp16Mx: [rows/16] max |x| (float bits) of the 16-row groups of this plane, or null
+  // kPrecFp16Mx2: e2m1 image of (activation - its fp16 plane), [rows][ld / 2 bytes] (column c = nibble c & 1 of byte
+  // c / 2), and its E8M0 scales [rows][Lo4ScalePitch(ld)] (one per row and 64 columns); both at logical row 0 like hi
+  const uint8_t* lo4;
+  const uint8_t* lo4s;
 };
+// bytes per row of a plane's residual-scale table: ld / 64 scales, padded to whole dwords (the consumers stage it with
+// 4-byte LDS-DMA)
+constexpr int Lo4ScalePitch(int ld) { return ((ld >> 6) + 3) & ~3; }
 
 // A group of K segments that share one LDS activation tile (filled by the launcher, see kernels.hip).
 struct Grp {
@@ -81,6 +98,9 @@ struct Grp {
   int wstride;  // weight columns between consecutive offsets
   int pad_;
   const unsigned* gmax;   // see Seg
+  const uint8_t* lo4s;    // kPrecFp16Mx2, groups of the second K walk (hi = the 4-bit plane, ld = its row pitch / 2): scales
+  int ld4s;               // bytes per row of lo4s
+  int pad2_;
 };
 
 // The order in which the GEMM kernels walk the K steps of a layer: consecutive Append() terms that read the same
@@ -133,12 +153,27 @@ inline int PlanWalkSteps(int ng, const WalkGroup* g, int* step_wcol, int cap, bo
   return n;
 }
 
+// kPrecFp16Mx2: first weight column of every 128-column step of the second walk (same groups and order: chunk -> offset);
+// returns the number of steps.  Needs every group to have a multiple of four 32-column steps.
+inline int PlanWalkLoSteps(int ng, const WalkGroup* g, int* lo_wcol, int cap) {
+  int n = 0;
+  for (int i = 0; i < ng; ++i)
+    for (int kq = 0; kq < g[i].ksteps / 4; ++kq)
+      for (int ij = 0; ij < g[i].nshift; ++ij) {
+        if (n < cap) lo_wcol[n] = g[i].wcol0 + ij * g[i].wstride + kq * 4 * kBK;
+        ++n;
+      }
+  return n;
+}
+
 struct GemmArgs {
   Seg seg[kMaxSeg];
   int nseg;
-  Grp grp[kMaxSeg];
+  Grp grp[2 * kMaxSeg];   // kPrecFp16Mx2: entries ngrp .. ngrp + ngrp_lo - 1 are the groups of the second K walk
   int ngrp;
-  int total_ksteps;
+  int total_ksteps;     // K steps of the first walk (32 columns each)
+  int ngrp_lo;          // kPrecFp16Mx2 (set by the launcher)
+  int lo_ksteps;        // K steps of the second walk (128 columns each): total_ksteps / 4
   const uint16_t* w_hi;  // [n_pad][ldw] row-major (Kaldi <LinearParams> orientation)
   const uint16_t* w_lo;
   int ldw;
@@ -150,6 +185,12 @@ struct GemmArgs {
   const uint8_t* w4;
   int ldw4;
   const uint8_t* w4_scale;   // n_pad * total_ksteps E8M0 bytes in staging order (engine.h TileMxScales): 512 per (tile, block)
+  // kPrecFp16Mx2: e2m1 image of the weights themselves for the second K walk, [n_pad][ldw4b bytes]: 64 bytes per (row,
+  // step of that walk) = four 16-byte lane-group chunks g of 32 consecutive columns; scales as for w4, one per chunk,
+  // 512 bytes per (tile, step) in staging order
+  const uint8_t* w4b;
+  int ldw4b;
+  const uint8_t* w4b_scale;
   int m_tiles;           // rows / kBM
   int n_tiles;           // n_pad / kBN
   int relu;
@@ -161,6 +202,8 @@ struct GemmArgs {
   uint16_t* out_hi;
   uint16_t* out_lo;
   int ldo;
+  uint8_t* out_lo4;      // precisions with PrecEmitsLo4: 4-bit residual plane [rows][ldo / 2] + scales [rows][ldo / 64] (Seg)
+  uint8_t* out_lo4s;
   unsigned* gmax_out;    // [rows/16] atomic max of |y| (float bits) per 16-row group over all columns (zeroed by the
                          // caller; prep_input does it), or null - what a kPrecFp16Mx consumer scales its fp4 copy by
   const int8_t* out_range;  // with gmax_out: [rows/16][2] first / last (exclusive) row of each group that is a computable
@@ -206,6 +249,7 @@ const char* last_gemm_kernel();
 // True when kPrecFp16Mx can run this launch (residual plane + scales present, every K group a multiple of four steps
 // with a group-max table, even tile count); otherwise the caller launches kPrecFp16x2 on the same operands.
 bool gemm_mx_applicable(const GemmArgs& a);
+bool gemm_mx2_applicable(const GemmArgs& a);   // kPrecFp16Mx2: also the 4-bit planes, sources of whole 128-column steps
 // Stream-K workspace (partial-tile exchange) of a stream: allocated on first use, released by the owner of the
 // stream before it destroys it (Engine::~Engine).  sk_last_error: non-zero once any stream-K launch of this process
 // timed out waiting for another workgroup's partial tile (checked by the engine after it synchronises).

@@ -65,8 +65,8 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop) {
 static thread_local char g_last_kernel[96] = "";
 const char* last_gemm_kernel() { return g_last_kernel; }
 static const char* prec_name(int p) {
-  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx"};
-  return (p >= 0 && p <= 6) ? n[p] : "?";
+  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e"};
+  return (p >= 0 && p <= 8) ? n[p] : "?";
 }
 static const char* epi_name(int e) { return e == kEpiAct ? "act" : e == kEpiF32 ? "f32" : e == kEpiStats ? "stats" : "splitk"; }
 static void note_kernel(const char* variant, int prec, int epi, int mf) {
@@ -402,7 +402,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
         *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
         *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
-        if constexpr (SPLIT) {
+        if constexpr (PrecEmitsLo4(PREC)) {
+          // what the fp16 rounding dropped, as e2m1 with one power-of-two scale per row and 64-column block (this
+          // wave's 64 columns of the row: the four lanes fr_g of the row hold them): 2^(e - 2), e = exponent of the
+          // largest residual, so that it lands in [4, 8) (saturating at 6 like the activation copies of kPrecFp16Mx)
+          float r[16], m = 0.f;
+#pragma unroll
+          for (int v = 0; v < 8; ++v) {
+            r[2 * v] = y[2 * v] - from16<F16>((uint16_t)(hw[v] & 0xffffu));
+            r[2 * v + 1] = y[2 * v + 1] - from16<F16>((uint16_t)(hw[v] >> 16));
+            m = fmaxf(m, fmaxf(fabsf(r[2 * v]), fabsf(r[2 * v + 1])));
+          }
+          {
+            float ma = m, mb = m;
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+            m = fmaxf(ma, mb);
+            ma = m;
+            mb = m;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+            m = fmaxf(ma, mb);
+          }
+          unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 255u;
+          e = e < 3u ? 1u : (e > 254u ? 252u : e - 2u);
+          const float sc4 = __builtin_bit_cast(float, e << 23);
+          unsigned c0 = 0u, c1 = 0u;
+          static_for<0, 4>([&](auto V) {
+            constexpr int v = decltype(V)::value;
+            c0 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c0, r[2 * v], r[2 * v + 1], sc4, v);
+            c1 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c1, r[8 + 2 * v], r[8 + 2 * v + 1], sc4, v);
+          });
+          uint8_t* d4 = a.out_lo4 + (long)row * (a.ldo >> 1) + (ncol >> 1);
+          *(unsigned*)d4 = c0;
+          *(unsigned*)(d4 + 16) = c1;
+          if (fr_g == 0) a.out_lo4s[(long)row * Lo4ScalePitch(a.ldo) + (nbase >> 6)] = (uint8_t)e;
+        } else if constexpr (SPLIT) {
           uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
           *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
           *(u32x4*)(dl + 32) = u32x4{lw[4], lw[5], lw[6], lw[7]};
@@ -664,6 +697,18 @@ __device__ __forceinline__ void glds4_sbase(const void* sbase, unsigned voff, un
       : "memory");
 }
 
+// the same for lanes 0..15 only (the others neither read nor write)
+__device__ __forceinline__ void glds4_sbase_lanes16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  unsigned long long ex;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, 0xffff\n\t"
+      "global_load_lds_dword %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(ex)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -675,9 +720,12 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ void wait_vm_lgkm0_barrier_n(int n) {   // n wave-uniform, 0..8
+__device__ __forceinline__ void wait_vm_lgkm0_barrier_n(int n) {   // n wave-uniform, 0..11 (else: everything)
   switch (n) {
     case 1: wait_vm_lgkm0_barrier<1>(); break;
     case 2: wait_vm_lgkm0_barrier<2>(); break;
@@ -687,6 +735,9 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier_n(int n) {   // n wave-uni
     case 6: wait_vm_lgkm0_barrier<6>(); break;
     case 7: wait_vm_lgkm0_barrier<7>(); break;
     case 8: wait_vm_lgkm0_barrier<8>(); break;
+    case 9: wait_vm_lgkm0_barrier<9>(); break;
+    case 10: wait_vm_lgkm0_barrier<10>(); break;
+    case 11: wait_vm_lgkm0_barrier<11>(); break;
     default: wait_vm_lgkm0_barrier<0>(); break;
   }
 }
@@ -1077,7 +1128,59 @@ static void build_groups(GemmArgs* g) {
     G.wstride = wg[i].wstride;
     G.pad_ = 0;
     G.gmax = s0.gmax;
+    G.lo4s = nullptr;
+    G.ld4s = 0;
+    G.pad2_ = 0;
   }
+  g->ngrp_lo = 0;
+  g->lo_ksteps = 0;
+}
+
+// kPrecFp16Mx2: the groups of the second K walk behind the first ones - the same sources, time offsets and order, steps of
+// 128 columns over the 4-bit residual planes (as 16-bit elements: a quarter of the row pitch and of the steps).
+static void build_lo_groups(GemmArgs* g) {
+  WalkGroup wg[kMaxSeg];
+  {
+    long key[kMaxSeg];
+    int shift[kMaxSeg], ksteps[kMaxSeg];
+    for (int j = 0; j < g->nseg; ++j) {
+      key[j] = j;
+      for (int k = 0; k < j; ++k)
+        if (g->seg[k].hi == g->seg[j].hi && g->seg[k].lo == g->seg[j].lo && g->seg[k].ld == g->seg[j].ld) {
+          key[j] = key[k];
+          break;
+        }
+      shift[j] = g->seg[j].row_shift;
+      ksteps[j] = g->seg[j].ksteps;
+    }
+    PlanWalkGroups(g->nseg, key, shift, ksteps, wg);
+  }
+  g->ngrp_lo = g->ngrp;
+  g->lo_ksteps = 0;
+  for (int i = 0; i < g->ngrp; ++i) {
+    const Seg& s0 = g->seg[wg[i].first_seg];
+    Grp& G = g->grp[g->ngrp + i];
+    G = g->grp[i];
+    G.hi = (const uint16_t*)s0.lo4;
+    G.lo = nullptr;
+    G.ld = s0.ld / 4;
+    G.ksteps = g->grp[i].ksteps / 4;
+    G.gmax = nullptr;
+    G.lo4s = s0.lo4s;
+    G.ld4s = Lo4ScalePitch(s0.ld);
+    g->lo_ksteps += G.ksteps * G.nshift;
+  }
+}
+
+bool gemm_mx2_applicable(const GemmArgs& a) {
+  if (!gemm_mx_applicable(a) || !a.w4b || !a.w4b_scale || a.ldw4b <= 0) return false;
+  GemmArgs b = a;
+  build_groups(&b);
+  for (int i = 0; i < b.ngrp; ++i)   // whole 128-column steps; at most two scale dwords per row in the slab
+    if (b.grp[i].ksteps % 4 || b.grp[i].ld % 128 || b.grp[i].ld > 512) return false;
+  for (int j = 0; j < a.nseg; ++j)
+    if (!a.seg[j].lo4 || !a.seg[j].lo4s) return false;
+  return true;
 }
 
 bool gemm_mx_applicable(const GemmArgs& a) {
@@ -1141,6 +1244,16 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   constexpr int WBASE = 3 * XSLOT;
   constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: scales of the residual tiles, three blocks x 128 rows x 4 lane groups
   constexpr int PB = SCB + 1536;               // epilogue parameters of the tile's columns, two buffers of 3 x 128 floats
+  // kPrecFp16Mx2: the K walk goes on, after the S steps of 32 columns, with S / 4 steps of 128 columns over the 4-bit
+  // residual planes of the activations (64 bytes per row and step: the tiles have the shape of the fp16 tiles and use the
+  // same rings and fragment reads) against the 4-bit image of the weights; one block-scaled MFMA per fragment pair.
+  // Scales: weights - 512 bytes per step through the SCB ring like those of the residual blocks; activations - one byte
+  // per row and 64 columns, all of a source's bytes for the tile rows staged once per group as [dword c][row]
+  // ("slab", two buffers: the next group's arrives while the last steps of the current one are read).
+  constexpr bool MX2 = PrecMx2(PREC);
+  constexpr int SLB = PB + 2 * 1536;
+  constexpr int SLAB_ROWS = TM + 16;
+  constexpr int SLAB_BYTES = SLAB_ROWS * 8;    // two dwords per row: sources up to 512 columns wide
   constexpr int KQ = MX ? 4 : 1;               // K steps are dealt out in units of KQ (a 128-deep block is never cut)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1159,15 +1272,32 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // same time, so its activation rows come out of HBM once and out of the XCD's L2 for the others (a contiguous
   // range of whole tiles per workgroup had 32 workgroups stream 32 different row tiles through a 4 MB L2: 1.3 GB of
   // fabric reads per tdnn2 launch against 0.38 GB for the per-tile kernel).
-  const int S = a.total_ksteps;
+  const int SH = a.total_ksteps;               // steps of the first walk
+  const int S = SH + (MX2 ? a.lo_ksteps : 0);  // all steps of a tile
+  const int NG = a.ngrp + (MX2 ? a.ngrp_lo : 0);
   const int SQ = S / KQ;
   const int G8 = gridDim.x >> 3;
   const int xcd = bid & 7, jb = bid >> 3;
   const int L = a.sk_lanes, cpl = a.n_tiles / L, Ng = G8 / L;
   const int col_lane = jb % L, grp_j = jb / L;
   const int tb0 = (int)((long)a.sk_mtiles * xcd / 8), tb1 = (int)((long)a.sk_mtiles * (xcd + 1) / 8);   // row tiles
-  const long steps_b = (long)(tb1 - tb0) * cpl * SQ;
-  const long s0 = steps_b * grp_j / Ng * KQ, s1 = steps_b * (grp_j + 1) / Ng * KQ;
+  long s0, s1;
+  if constexpr (MX2) {
+    // cuts anywhere in the second walk, at multiples of four steps in the first one
+    const long all = (long)(tb1 - tb0) * cpl * S;
+    auto cut = [&](long g) {
+      const long s = all * g / Ng;
+      int k = (int)(s % S);
+      if (k < SH) k &= ~3;
+      return s - s % S + k;
+    };
+    s0 = cut(grp_j);
+    s1 = cut(grp_j + 1);
+  } else {
+    const long steps_b = (long)(tb1 - tb0) * cpl * SQ;
+    s0 = steps_b * grp_j / Ng * KQ;
+    s1 = steps_b * (grp_j + 1) / Ng * KQ;
+  }
   const int k_head = (int)(s0 % S), k_tail = (int)(s1 % S);
   const int t_first = (int)((s0 + S - 1) / S), t_end = (int)(s1 / S);   // whole tiles [t_first, t_end) of the block
   const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
@@ -1190,8 +1320,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const uint16_t* wtile_lo = nullptr;
   const uint8_t* wtile_4 = nullptr;
   const uint8_t* wtile_s = nullptr;    // scales of the residual plane: this column tile's 512-byte pieces, one per block
+  const uint8_t* wtile_b = nullptr;    // kPrecFp16Mx2: 4-bit weight image, row n0; and its scales (512 bytes per step)
+  const uint8_t* wtile_bs = nullptr;
   const unsigned woff = (unsigned)(w_rho * a.ldw + ld_chunk * 8) * 2u;   // this lane's row / chunk inside the tile
   const unsigned woff4 = MX ? (unsigned)(w_rho * a.ldw4 + ld_chunk * 16) : 0u;
+  const unsigned woffb = MX2 ? (unsigned)(w_rho * a.ldw4b + ld_chunk * 16) : 0u;
+  bool force_slab = false;             // the next step of the second walk stages its group's activation scales
   int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0, istep = 0;
   bool force_x = true;
   Grp gi = a.grp[0];
@@ -1213,6 +1347,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   };
   auto issue_step = [&]() __attribute__((always_inline)) -> int {
     int n = 0;
+    const bool lo_step = MX2 && istep >= SH;   // a step of the second walk: 4-bit planes, 128 columns
     if (ij == 0 || force_x) {
       force_x = false;
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + ixslot * XSLOT + wave * 1024);
@@ -1233,30 +1368,61 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       n += CH * NPX;
       ixslot = ixslot == 2 ? 0 : ixslot + 1;
     }
+    if constexpr (MX2) {
+      if (lo_step && ((ikk == 0 && ij == 0) || force_slab)) {
+        // scales of this group's activation residuals for the tile rows (+ halo): dword c of row r -> slab[c][r]
+        force_slab = false;
+        const int nc = gi.ld4s >> 2;
+        const unsigned sl = lds_base + SLB + ((ig - a.ngrp) & 1) * SLAB_BYTES;
+        const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + wave * 64) * gi.ld4s;
+        const unsigned voff = (unsigned)(lane * gi.ld4s);
+        for (int c = 0; c < nc; ++c) {
+          glds4_sbase(src + c * 4, voff, sl + (c * SLAB_ROWS + wave * 64) * 4);
+          if (wave == 0) glds4_sbase_lanes16(src + (long)TM * gi.ld4s + c * 4, voff, sl + (c * SLAB_ROWS + TM) * 4);
+        }
+        n += nc * (wave == 0 ? 2 : 1);
+      }
+    }
     {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
       const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
-      glds16_sbase(wtile_hi + wcol, woff, st);
-      n += 1;
-      if constexpr (MX) {
-        // The 4-bit residual tile of block b = istep / 4 (8 KiB) travels with the block's second step into the
-        // residual half of weight slot b % 3: a ring of its own, three blocks deep.  It is read in the COMPUTE segment
-        // of the block's last step (after that step's fp16 MFMAs, into the registers of the fp16 weight fragments),
-        // which the step ring could not allow - the other wave group refills a step's slot one barrier interval
-        // after its LOAD segment.
-        if ((istep & 3) == 1) {
-          const unsigned st4 = __builtin_amdgcn_readfirstlane(lds_base + WBASE + ((istep >> 2) % 3) * WSLOT + WT + wave * 1024);
-          glds16_sbase(wtile_4 + (istep >> 2) * 64, woff4, st4);
+      if (lo_step) {
+        // 4-bit weight tile of the step (64 bytes per row, steps in walk order) into the fp16 half of the slot, and its
+        // scales into the SCB ring: slots continue behind the last residual block's, which is still unread when the
+        // first two steps of this walk are issued
+        if constexpr (MX2) {
+          const int t_lo = istep - SH;
+          glds16_sbase(wtile_b + t_lo * 64, woffb, st);
           n += 1;
-          if (wave < 2) {   // and its scales: 512 contiguous bytes per (tile, block), already in reading order
-            glds4_sbase(wtile_s + (istep >> 2) * 512 + wave * 256, (unsigned)lane * 4u,
-                        lds_base + SCB + ((istep >> 2) % 3) * 512 + wave * 256);
+          if (wave < 2) {
+            glds4_sbase(wtile_bs + t_lo * 512 + wave * 256, (unsigned)lane * 4u,
+                        lds_base + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + wave * 256);
             n += 1;
           }
         }
-      } else if constexpr (WSPLIT) {
-        glds16_sbase(wtile_lo + wcol, woff, st + WT);
+      } else {
+        glds16_sbase(wtile_hi + wcol, woff, st);
         n += 1;
+        if constexpr (MX) {
+          // The 4-bit residual tile of block b = istep / 4 (8 KiB) travels with the block's second step into the
+          // residual half of weight slot b % 3: a ring of its own, three blocks deep.  It is read in the COMPUTE segment
+          // of the block's last step (after that step's fp16 MFMAs, into the registers of the fp16 weight fragments),
+          // which the step ring could not allow - the other wave group refills a step's slot one barrier interval
+          // after its LOAD segment.
+          if ((istep & 3) == 1) {
+            const unsigned st4 = __builtin_amdgcn_readfirstlane(lds_base + WBASE + ((istep >> 2) % 3) * WSLOT + WT + wave * 1024);
+            glds16_sbase(wtile_4 + (istep >> 2) * 64, woff4, st4);
+            n += 1;
+            if (wave < 2) {   // and its scales: 512 contiguous bytes per (tile, block), already in reading order
+              glds4_sbase(wtile_s + (istep >> 2) * 512 + wave * 256, (unsigned)lane * 4u,
+                          lds_base + SCB + ((istep >> 2) % 3) * 512 + wave * 256);
+              n += 1;
+            }
+          }
+        } else if constexpr (WSPLIT) {
+          glds16_sbase(wtile_lo + wcol, woff, st + WT);
+          n += 1;
+        }
       }
       iwslot = iwslot == 2 ? 0 : iwslot + 1;
     }
@@ -1265,7 +1431,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       ij = 0;
       if (++ikk == gi.ksteps) {
         ikk = 0;
-        if (++ig < a.ngrp) {
+        if (++ig < NG) {
           gi = a.grp[ig];
           bind_group();
         }
@@ -1344,11 +1510,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       rxslot = rxslot == 2 ? 0 : rxslot + 1;
       if (++rkk == r_ksteps) {
         rkk = 0;
-        if (++rg < a.ngrp) {
+        if (++rg < NG) {
           r_nshift = a.grp[rg].nshift;
           r_ksteps = a.grp[rg].ksteps;
           r_dstep = a.grp[rg].dstep;
-          if constexpr (MX) xs_reload = true;   // the COMPUTE segment of THIS step still converts with the old group's scales
+          if constexpr (MX) xs_reload = rg < a.ngrp;   // the COMPUTE segment of THIS step still converts with the old group's scales
         }
       }
     }
@@ -1429,6 +1595,34 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       }
     }
   };
+  // kPrecFp16Mx2, a step of the second walk: the fragments just read ARE the 4-bit operands (16 bytes per lane = 32
+  // columns of the step's 128); one block-scaled MFMA per fragment pair.  t_lo = index of the step in the walk, (lg, lkk,
+  // lj) = its group / 128-column chunk / offset.  Scales: the weight rows' from the SCB ring (one dword per 64-row half),
+  // the activation rows' from the group's slab - byte 2 lkk + (fr_g >> 1) of the row (one scale per 64 columns).
+  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj) __attribute__((always_inline)) {
+    if constexpr (MX2) {
+      const char* sc = smem + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + (col_w >> 6) * 256 + (fr_i * 4 + fr_g) * 4;
+      int ws_lo[WW];
+#pragma unroll
+      for (int h = 0; h < WW; ++h) ws_lo[h] = *(const int*)(sc + h * 256);
+      const int bi = 2 * lkk + (fr_g >> 1);
+      const uint8_t* sl = (const uint8_t*)smem + SLB + ((lg - a.ngrp) & 1) * SLAB_BYTES +
+                          ((bi >> 2) * SLAB_ROWS + row_w + fr_i + lj * a.grp[lg].dstep) * 4 + (bi & 3);
+      int xs_lo = 0;
+#pragma unroll
+      for (int i = 0; i < XF; ++i) xs_lo |= (int)sl[i * 64] << (8 * i);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        static_for<0, 4>([&](auto P) {
+          static_for<0, 4>([&](auto Q) {
+            constexpr int p = decltype(P)::value, q = decltype(Q)::value;
+            if constexpr (SWAP) mfma_mx4_inplace<p, q>(f.wh[WI(h, p)], f.xh[XI(h, q)], acc[h][p][q], ws_lo[WIDE ? h : 0], xs_lo);
+            else mfma_mx4_inplace<p, q>(f.xh[XI(h, p)], f.wh[WI(h, q)], acc[h][p][q], xs_lo, ws_lo[WIDE ? h : 0]);
+          });
+        });
+      }
+    }
+  };
   auto wait_and_barrier = [&](int n) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1445,7 +1639,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     g = 0;
     for (;;) {
       const int n = a.grp[g].ksteps * a.grp[g].nshift;
-      if (k < n || g + 1 >= a.ngrp) break;
+      if (k < n || g + 1 >= NG) break;
       k -= n;
       ++g;
     }
@@ -1462,6 +1656,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // previous part's epilogue; the first wait of a part therefore drains everything (vmcnt(0): the epilogue's stores were
   // issued after these DMA instructions and the counter does not tell them apart).
   int kind = 0, n_steps = 0;   // kind 0: whole tile, 1: tail part (accumulators -> workspace), 2: head part
+  int n_hi = 0, rstep = 0;     // steps of the part that belong to the first walk; step the read side is at
   auto open_part = [&](int part) __attribute__((always_inline)) {
     // part order: tail (first K steps of the range's last tile), whole tiles, head (last K steps of its first tile)
     int tile, kb, ke;
@@ -1488,9 +1683,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     ixslot = iwslot = rxslot = rwslot = 0;
     istep = kb;
     rblk = kb >> 2;
+    rstep = kb;
     xs_reload = false;
     force_x = true;
+    force_slab = MX2 && kb >= SH;
     n_steps = ke - kb;
+    n_hi = kb >= SH ? 0 : (ke < SH ? ke : SH) - kb;
     if (EPI != kEpiSplitK && kind != 1 && wave < (a.bn ? 6 : 2)) {
       // bias / scale / offset of the tile's columns -> LDS buffer part & 1, one 256-byte piece per wave; complete with the
       // first wait of the part, read by its epilogue (which runs after open_part of the NEXT part: the other buffer)
@@ -1500,13 +1698,17 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     xs_uvec xg;
     if constexpr (MX) {
       wtile_4 = a.w4 + (long)n0 * a.ldw4;
-      wtile_s = a.w4_scale + (long)nt * (S >> 2) * 512;
+      wtile_s = a.w4_scale + (long)nt * (SH >> 2) * 512;
+      if constexpr (MX2) {
+        wtile_b = a.w4b + (long)n0 * a.ldw4b;
+        wtile_bs = a.w4b_scale + (long)nt * (S - SH) * 512;
+      }
       // the activation scales travel (scalar cache) while the DMA of the first steps is issued
-      xs_request(gi.gmax, xg);
+      if (n_hi) xs_request(gi.gmax, xg);
     }
     issue_step();
     if (n_steps > 1) issue_step();
-    xs_finish(xg);
+    if (n_hi) xs_finish(xg);
   };
 
   open_part(0);
@@ -1560,12 +1762,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     if (group == 1) plain_barrier();
     Frags f;
     const int ns = n_steps;
+    const int ns_hi = MX2 ? n_hi : ns;
     if constexpr (MX) {
       // Blocks of four steps (unrolled: the position inside a block is a compile-time constant): every COMPUTE segment
       // converts its activation fragments into one dword of the 4-bit fragments, the last one also fetches the block's
       // 4-bit weight fragments and issues the 32 residual MFMAs.
 #pragma nounroll
-      for (int j = 0; j < ns; j += 4, ++rblk) {
+      for (int j = 0; j < ns_hi; j += 4, ++rblk) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           // with 1.25 passes per product the LOAD segment (12 fragment reads, 3-6 LDS-DMA instructions) is as long as
@@ -1579,6 +1782,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           mfmas(f);
           convert(f, s);
           if (s == 3) mx_mfmas(f);
+          plain_barrier();
+        }
+      }
+      if constexpr (MX2) {
+        rstep += ns_hi;
+#pragma nounroll
+        for (int j = ns_hi; j < ns; ++j, ++rstep) {   // the second walk: one 128-column step = 32 block-scaled MFMAs
+          __builtin_amdgcn_s_setprio(1);
+          const int lg = rg, lkk = rkk, lj = rj;
+          read_step(f);
+          const int n = (j + 2 < ns) ? issue_step() : 0;
+          wait_and_barrier(n);
+          __builtin_amdgcn_s_setprio(0);
+          lo_mfmas(f, rstep - SH, lg, lkk, lj);
           plain_barrier();
         }
       }
@@ -1709,7 +1926,7 @@ unsigned sk_last_error() {
 // True when the stream-K variant with MF fragments per wave can run this launch.
 template <int PREC, int MF>
 static bool sk_applicable(const GemmArgs& a) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536;
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536 + (PrecMx2(PREC) ? 2 * (64 * MF + 16) * 8 : 0);
   if (lds > 160 * 1024) return false;
   const int rows = a.m_tiles * kBM;
   if (rows % (64 * MF)) return false;
@@ -1721,7 +1938,7 @@ static bool sk_applicable(const GemmArgs& a) {
 
 template <int PREC, int EPI, int MF>
 static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536;
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536 + (PrecMx2(PREC) ? 2 * (64 * MF + 16) * 8 : 0);
   if constexpr (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {
@@ -1736,6 +1953,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
     const int grid = device_cu_count() / 8 * 8;
     GemmArgs b = a;
     build_groups(&b);
+    if constexpr (PrecMx2(PREC)) build_lo_groups(&b);
     b.sk_mtiles = a.m_tiles * kBM / (64 * MF);
     {
       // column lanes: the largest of 4, 2, 1 that divides the column tiles and the workgroups of an XCD block
@@ -1776,6 +1994,7 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   dim3 grid(mt8 * a.n_tiles), block(512);
   GemmArgs b = a;
   build_groups(&b);
+  if constexpr (PrecMx2(PREC)) build_lo_groups(&b);
   {
     // stagger window = XVEC_GEMM_STAGGER percent of the modelled tile time (K steps x ~2200 cycles in split mode,
     // ~1000 single pass, + ~14000 fixed)
@@ -1802,7 +2021,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   const bool sk_default = PREC == kPrecFp16x2 || PREC == kPrecFp16Mx || a.total_ksteps >= 32;
   if constexpr (PrecMx(PREC)) {
     // 512-row stream-K tiles or the 256-row per-tile kernel (bit-identical); nothing else implements the mode
-    if (!gemm_mx_applicable(a)) return hipErrorInvalidValue;
+    if (PrecMx2(PREC) ? !gemm_mx2_applicable(a) : !gemm_mx_applicable(a)) return hipErrorInvalidValue;
     if (variant != 2 && variant != 1 && sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
     return launch_one_v2<PREC, EPI>(a, s);
   }
@@ -1893,6 +2112,10 @@ static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC>
 static hipError_t launch_prec(const GemmArgs& a, int epi, hipStream_t s) {
+  if constexpr (PREC == kPrecFp16x3E) {   // planes out only (the layers in front of a kPrecFp16Mx2 consumer)
+    if (a.ksplit > 1 || epi != kEpiAct || !a.out_lo4 || !a.out_lo4s) return hipErrorInvalidValue;
+    return launch_one<PREC, kEpiAct>(a, s);
+  }
   if constexpr (PrecMx(PREC)) {   // frame-level layers only: planes out or pooled statistics
     if (a.ksplit > 1) return hipErrorInvalidValue;
     if (epi == kEpiAct) return launch_one<PREC, kEpiAct>(a, s);
@@ -1921,6 +2144,8 @@ hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipS
     case kPrecFp16x3: return launch_prec<kPrecFp16x3>(a, epilogue, s);
     case kPrecFp16x2: return launch_prec<kPrecFp16x2>(a, epilogue, s);
     case kPrecFp16Mx: return launch_prec<kPrecFp16Mx>(a, epilogue, s);
+    case kPrecFp16Mx2: return launch_prec<kPrecFp16Mx2>(a, epilogue, s);
+    case kPrecFp16x3E: return launch_prec<kPrecFp16x3E>(a, epilogue, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -18,9 +18,19 @@ def _torch():
     return torch
 
 
-F16_MODES = (2, 3, 4)          # fp16, fp16x3, fp16x2
-X_SPLIT = (0, 3)               # modes whose activations carry a residual plane
-W_SPLIT = (0, 3, 4)            # modes whose weights carry one (fp16x2: fp16 activations x split weights)
+F16_MODES = (2, 3, 4, 8)       # fp16, fp16x3, fp16x2, fp16x3e
+X_SPLIT = (0, 3, 8)            # modes whose activations carry a residual plane
+W_SPLIT = (0, 3, 4, 8)         # modes whose weights carry one (fp16x2: fp16 activations x split weights)
+E2M1_GRID = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def _decode_lo4(lo4, lo4s, n_cols):
+    """4-bit residual plane [rows, n_cols / 2] + E8M0 scales [rows, n_cols / 64] -> float64 [rows, n_cols]"""
+    b = lo4.cpu().numpy()
+    nib = np.stack([b & 15, b >> 4], axis=-1).reshape(b.shape[0], n_cols)
+    val = np.where(nib & 8, -1.0, 1.0) * E2M1_GRID[nib & 7]
+    sc = 2.0 ** (lo4s.cpu().numpy()[:, :n_cols // 64].astype(np.float64) - 127)
+    return val * np.repeat(sc, 64, axis=1)
 
 
 def _split(t, prec, torch, split):
@@ -48,7 +58,7 @@ def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None):
         src_ld[s[0]] = max(src_ld.get(s[0], 0), s[1])
     # split-fp16 residuals are 2^-12 of the value: operands are scaled up so that they stay fp16 normals (the engine
     # scales its packed weights the same way, PackModel)
-    amp = 16.0 if prec in (3, 4) else 1.0
+    amp = 16.0 if prec in (3, 4, 8) else 1.0
     X = [(torch.randn(rows + 2 * HALO, src_ld[i], generator=g) * amp).to(dev) for i in range(nsrc)]
     K = sum(s[3] for s in segs)
     W = (torch.randn(n_pad, K, generator=g) * (amp * amp / np.sqrt(K))).to(dev)
@@ -92,6 +102,13 @@ def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None):
         oh = torch.zeros(rows, n_pad, dtype=torch.float16 if prec in F16_MODES else torch.bfloat16, device=dev)
         ol = torch.zeros_like(oh)
         d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), (ol.data_ptr() if prec in X_SPLIT else None), n_pad
+        if prec == 8:   # fp16 plane + 4-bit image of what its rounding dropped
+            o4 = torch.zeros(rows, n_pad // 2, dtype=torch.uint8, device=dev)
+            o4s = torch.zeros(rows, (n_pad // 64 + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+            d.out_lo, d.out_lo4, d.out_lo4_scale = None, o4.data_ptr(), o4s.data_ptr()
+            P.kernel_tdnn_gemm(d)
+            torch.cuda.synchronize()
+            return oh.double().cpu().numpy() + _decode_lo4(o4, o4s, n_pad), z.cpu().numpy()
         P.kernel_tdnn_gemm(d)
         torch.cuda.synchronize()
         return _planes_value(oh, ol if prec in X_SPLIT else None).double().cpu().numpy(), z.cpu().numpy()
@@ -142,6 +159,19 @@ def test_gemm_act_epilogue(prec):
     out, ref = _run_case(prec, 0, 384, 512, TDNN2, relu=True, bn=True, seed=1)
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err < TOL[prec] + OUT_Q[prec], err
+
+
+@pytest.mark.parametrize("segs", [TDNN2, TDNN1], ids=["tdnn2", "tdnn1"])
+def test_gemm_planes_epilogue_with_4bit_residual(segs):
+    """XV_PREC_FP16X3E: the planes epilogue writes the fp16 plane and the e2m1 image of its rounding residual (one scale
+    per row and 64 columns, the largest residual of the block in the top binade): together 2-3 bits better than the fp16
+    plane alone - worst case half a grid step (1) at a scale of a quarter of the largest residual."""
+    out, ref = _run_case(8, 0, 384, 512, segs, relu=True, bn=True, seed=1)
+    err = np.abs(out - ref)
+    blk = np.abs(ref).reshape(ref.shape[0], -1, 64).max(axis=2, keepdims=True)        # per (row, 64 columns)
+    rel = (err.reshape(ref.shape[0], -1, 64) / np.maximum(blk, 1e-30)).max()
+    assert rel < 2.0 ** -13 * 1.05 + TOL[3], rel
+    assert np.sqrt((err ** 2).mean()) < 0.25 * 2.0 ** -12 * np.sqrt((ref ** 2).mean())   # fp16 alone: ~0.29 * 2^-11
 
 
 @pytest.mark.parametrize("relu,bn", [(False, False), (True, False), (False, True)])
@@ -211,12 +241,45 @@ def _q_e2m1(t, torch):
     return torch.sign(t) * grid[idx]
 
 
+def _lo4_plane(x32, xh, torch):
+    """What the planes epilogue of XV_PREC_FP16MX2 / FP16X3E writes next to the fp16 plane xh of the fp32 values x32: the
+    e2m1 codes of r = x32 - xh with one scale 2^(e - 2) per row and 64 columns (e = exponent of the block's largest |r|),
+    packed two per byte, the E8M0 scale bytes, and the decoded values."""
+    r = x32.double() - xh.double()
+    rows, n = r.shape
+    b = r.reshape(rows, n // 64, 64)
+    m = b.abs().amax(dim=2, keepdim=True)
+    ebits = (m.float().view(torch.int32) >> 23) & 255
+    e8 = torch.where(ebits < 3, torch.ones_like(ebits), torch.where(ebits > 254, torch.full_like(ebits, 252), ebits - 2))
+    sc = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=r.device), e8.double() - 127)
+    q = _q_e2m1(b / sc, torch)
+    grid = torch.tensor(E2M1, dtype=torch.float64, device=r.device)
+    code = (q.abs()[..., None] == grid).long().argmax(dim=-1) | ((b < 0).long() << 3)
+    code = code.reshape(rows, n)
+    packed = (code[:, 0::2] | (code[:, 1::2] << 4)).to(torch.uint8).contiguous()
+    pitch = (n // 64 + 3) // 4 * 4        # scale rows are padded to whole dwords
+    e8p = torch.zeros(rows, pitch, dtype=torch.uint8, device=r.device)
+    e8p[:, :n // 64] = e8.reshape(rows, n // 64).to(torch.uint8)
+    return packed, e8p, (q * sc).reshape(rows, n)
+
+
+def _w4_image(W, torch):
+    """4-bit image of the weights for the second walk: per row and 32 consecutive columns the smallest power of two 2^E
+    with max |w| / 2^E <= 6, codes to nearest even - what xv_pack_mx_weights packs (values only)"""
+    n, K = W.shape
+    b = W.double().reshape(n, K // 32, 32)
+    m = b.abs().amax(dim=2, keepdim=True)
+    E = torch.ceil(torch.log2(torch.clamp(m, min=1e-300) / 6.0))
+    sc = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=W.device), E)
+    return (_q_e2m1(b / sc, torch) * sc).reshape(n, K)
+
+
 def _gmax_bits(plane_abs_max, torch):
     """float32 bit patterns of the group maxima, as the producing epilogue records them"""
     return plane_abs_max.float().view(torch.int32)
 
 
-def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
+def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6):
     torch = _torch()
     P = _pkg()
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -250,13 +313,22 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
         body = Xh[i][HALO:HALO + rows].float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))
         gmax.append(_gmax_bits(body, torch).contiguous())
 
+    lo4 = [_lo4_plane(X[i], Xh[i], torch) for i in range(nsrc)] if prec == 7 else None
     d = P.GemmDesc()
-    d.precision, d.epilogue, d.nseg = P.PREC_FP16MX, epi, len(segs)
+    d.precision, d.epilogue, d.nseg = prec, epi, len(segs)
     for j, (si, ld, shift, klen) in enumerate(segs):
         d.seg[j].hi = Xh[si].data_ptr() + HALO * src_ld[si] * 2
         d.seg[j].lo = None
         d.seg[j].ld, d.seg[j].row_shift, d.seg[j].k_len = src_ld[si], shift, klen
         d.seg[j].gmax = gmax[si].data_ptr()
+        if prec == 7:
+            d.seg[j].lo4 = lo4[si][0].data_ptr() + HALO * (src_ld[si] // 2)
+            d.seg[j].lo4_scale = lo4[si][1].data_ptr() + HALO * lo4[si][1].shape[1]
+    if prec == 7:
+        w4b, w4bs = P.pack_mx_weights(W.cpu().numpy(), [(s[0], s[2], s[3]) for s in segs])
+        w4b_d = torch.from_numpy(w4b).to(dev)
+        w4bs_d = torch.from_numpy(P.tile_mx_scales(w4bs, epi)).to(dev)
+        d.w4b, d.ldw4b, d.w4b_scale = w4b_d.data_ptr(), K // 2, w4bs_d.data_ptr()
     d.w_hi, d.w_lo, d.ldw = Wh.data_ptr(), None, K
     d.w4, d.ldw4, d.w4_scale = w4_d.data_ptr(), K // 128 * 64, w4t_d.data_ptr()
     d.rows, d.n_pad = rows, n_pad
@@ -287,6 +359,7 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
     e8 = w4s_d.double()[:, sidx]
     sw = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev), e8 - 127)
     Rq = _q_e2m1(R / sw, torch) * sw
+    W4q = _w4_image(W, torch) if prec == 7 else None
     z = torch.zeros(rows, n_pad, dtype=torch.float64, device=dev)
     k0 = 0
     for (si, ld, shift, klen) in segs:
@@ -296,6 +369,8 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
         sx = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev), ebits - 2 - 127)
         x4 = _q_e2m1(xs / sx, torch) * sx
         z += xs @ Whd[:, k0:k0 + klen].T + x4 @ Rq[:, k0:k0 + klen].T
+        if prec == 7:   # + q4(x - fp16(x)) . q4(w)
+            z += lo4[si][2][HALO + shift: HALO + shift + rows, :klen] @ W4q[:, k0:k0 + klen].T
         k0 += klen
     z = torch.clamp(z + bias.double(), min=0) * scale.double() + offset.double()
 
@@ -305,12 +380,18 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None):
         gm_out = torch.zeros(rows // 16, dtype=torch.int32, device=dev)
         d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), None, n_pad
         d.gmax_out = gm_out.data_ptr()
+        if prec == 7:
+            o4 = torch.zeros(rows, n_pad // 2, dtype=torch.uint8, device=dev)
+            o4s = torch.zeros(rows, (n_pad // 64 + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+            d.out_lo4, d.out_lo4_scale = o4.data_ptr(), o4s.data_ptr()
         P.kernel_tdnn_gemm(d)
         torch.cuda.synchronize()
         # the recorded group maxima are those of the fp32 results before the fp16 rounding of the plane
         want = z.float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))
         got = gm_out.view(torch.float32)
         assert torch.allclose(got, want, rtol=1e-4, atol=0), (got[:4], want[:4])
+        if prec == 7:   # the output plane with its own 4-bit residual: two to three bits better than fp16 alone
+            return oh.double().cpu().numpy() + _decode_lo4(o4, o4s, n_pad), z.cpu().numpy()
         return oh.double().cpu().numpy(), z.cpu().numpy()
     ngrp = rows // 16
     rng = np.random.default_rng(seed)
@@ -361,3 +442,16 @@ def test_gemm_mx_refuses_unsuitable_launch():
     with pytest.raises(P.XvError):
         # two sources of two K steps each: no 128-column block of the walk lies inside one source
         _run_mx_case(0, 768, 512, [(0, 64, 0, 64), (1, 64, 0, 64)], seed=1)
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX, [(0, 512, 0, 512)]], ids=["tdnn3", "cvec5", "tdnn4"])
+def test_gemm_mx2_stream_k(epi, segs):
+    """XV_PREC_FP16MX2 on the persistent kernel: the second K walk (4-bit residual of the activations x 4-bit image of the
+    weights) against an exact emulation of both 4-bit products; parts cut inside both walks."""
+    out, ref = _run_mx_case(epi, 66 * 512, 512, segs, seed=17, prec=7)
+    if epi == 2:
+        scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+        assert (np.abs(out - ref) / scale).max() < 3e-5
+    else:
+        assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13
