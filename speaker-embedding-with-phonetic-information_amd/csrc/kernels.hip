@@ -757,6 +757,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   constexpr int WSLOT = NPW * WT;
   constexpr int WBASE = 3 * XSLOT;             // weight ring behind the activation ring
   constexpr int SCB = WBASE + 3 * WSLOT;       // kPrecFp16Mx: scales of the residual tiles, three blocks x 128 rows x 4 lane groups
+  constexpr bool MX2 = PrecMx2(PREC);          // second K walk over the 4-bit planes: see the stream-K kernel
+  constexpr int SLB = SCB + 1536;
+  constexpr int SLAB_ROWS = XROWS;
+  constexpr int SLAB_BYTES = SLAB_ROWS * 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -797,6 +801,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   const uint16_t* wrow_hi;
   const uint16_t* wrow_lo;
   const uint8_t* wrow_4;
+  const uint8_t* wrow_b;
   {
     const int rho = wave * 16 + ld_row;
     const int wrow = SWAP ? ((rho & 64) | swap_fields(rho & 63)) : rho;
@@ -804,7 +809,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     wrow_hi = a.w_hi + off;
     wrow_lo = (WSPLIT && !MX) ? a.w_lo + off : nullptr;
     wrow_4 = MX ? a.w4 + (long)(n0 + wrow) * a.ldw4 + ld_chunk * 16 : nullptr;
+    wrow_b = MX2 ? a.w4b + (long)(n0 + wrow) * a.ldw4b + ld_chunk * 16 : nullptr;
   }
+  const int SH = a.total_ksteps;
+  const int NG = a.ngrp + (MX2 ? a.ngrp_lo : 0);
   const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
 
   // ---- issue side: walks the K steps in the order  group -> K chunk -> time offset ------------------------------
@@ -833,7 +841,37 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       }
       ixslot = ixslot == 2 ? 0 : ixslot + 1;
     }
-    {
+    const bool lo_step = MX2 && istep >= SH;
+    if constexpr (MX2) {
+      if (lo_step && ikk == 0 && ij == 0) {   // scales of this group's activation residuals for the tile rows (+ halo)
+        const int nc = gi.ld4s >> 2;
+        const unsigned sl = lds_base + SLB + ((ig - a.ngrp) & 1) * SLAB_BYTES;
+        const unsigned voff = (unsigned)(lane * gi.ld4s);
+        if (wave < 4) {
+          const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + wave * 64) * gi.ld4s;
+          for (int c = 0; c < nc; ++c) glds4_sbase(src + c * 4, voff, sl + (c * SLAB_ROWS + wave * 64) * 4);
+          n += nc;
+        } else if (wave == 4) {
+          const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + 256) * gi.ld4s;
+          for (int c = 0; c < nc; ++c) glds4_sbase_lanes16(src + c * 4, voff, sl + (c * SLAB_ROWS + 256) * 4);
+          n += nc;
+        }
+      }
+    }
+    if (lo_step) {
+      if constexpr (MX2) {
+        const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
+        const int t_lo = istep - SH;
+        glds16_asm(wrow_b + t_lo * 64, st);
+        n += 1;
+        if (wave < 2) {
+          glds4_sbase(a.w4b_scale + ((long)nt * a.lo_ksteps + t_lo) * 512 + wave * 256, (unsigned)lane * 4u,
+                      lds_base + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + wave * 256);
+          n += 1;
+        }
+      }
+      iwslot = iwslot == 2 ? 0 : iwslot + 1;
+    } else {
       const unsigned st = __builtin_amdgcn_readfirstlane(lds_base + WBASE + iwslot * WSLOT + wave * 1024);
       const int wcol = gi.wcol0 + ij * gi.wstride + ikk * kBK;
       glds16_asm(wrow_hi + wcol, st);
@@ -860,7 +898,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       ij = 0;
       if (++ikk == gi.ksteps) {
         ikk = 0;
-        if (++ig < a.ngrp) gi = a.grp[ig];
+        if (++ig < NG) gi = a.grp[ig];
       }
     }
     return n;
@@ -921,11 +959,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       rxslot = rxslot == 2 ? 0 : rxslot + 1;
       if (++rkk == r_ksteps) {
         rkk = 0;
-        if (++rg < a.ngrp) {
+        if (++rg < NG) {
           r_nshift = a.grp[rg].nshift;
           r_ksteps = a.grp[rg].ksteps;
           r_dstep = a.grp[rg].dstep;
-          if constexpr (MX) xs_reload = true;
+          if constexpr (MX) xs_reload = rg < a.ngrp;
         }
       }
     }
@@ -985,6 +1023,25 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     }
   };
 
+  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj) __attribute__((always_inline)) {
+    if constexpr (MX2) {
+      const int ws_lo = *(const int*)(smem + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + wave_n * 256 + (fr_i * 4 + fr_g) * 4);
+      const int bi = 2 * lkk + (fr_g >> 1);
+      const uint8_t* sl = (const uint8_t*)smem + SLB + ((lg - a.ngrp) & 1) * SLAB_BYTES +
+                          ((bi >> 2) * SLAB_ROWS + wave_m * 64 + fr_i + lj * a.grp[lg].dstep) * 4 + (bi & 3);
+      int xs_lo = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xs_lo |= (int)sl[i * 64] << (8 * i);
+      static_for<0, 4>([&](auto P) {
+        static_for<0, 4>([&](auto Q) {
+          constexpr int p = decltype(P)::value, q = decltype(Q)::value;
+          if constexpr (SWAP) mfma_mx4_inplace<p, q>(f.wh[p], f.xh[q], acc[p][q], ws_lo, xs_lo);
+          else mfma_mx4_inplace<p, q>(f.xh[p], f.wh[q], acc[p][q], xs_lo, ws_lo);
+        });
+      });
+    }
+  };
+
   // Ping-pong schedule.  The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  A K
   // step of a group is a LOAD segment (ds_read its fragments of step j, issue its share of the DMA of step j+2,
   // wait until only that share is outstanding, i.e. its share of step j+1 has landed) and a COMPUTE segment (48 /
@@ -1015,7 +1072,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  const int S = a.total_ksteps;
+  const int S = SH + (MX2 ? a.lo_ksteps : 0);
   const int group = wave >> 2;
   issue_step();
   const int n1 = S > 1 ? issue_step() : 0;
@@ -1030,7 +1087,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   Frags f;
   if constexpr (MX) {
 #pragma nounroll
-    for (int j = 0; j < S; j += 4, ++rblk) {
+    for (int j = 0; j < SH; j += 4, ++rblk) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         read_step(f);
@@ -1040,6 +1097,19 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
         mfmas(f);
         convert(f, s);
         if (s == 3) mx_mfmas(f);
+        __builtin_amdgcn_s_setprio(0);
+        plain_barrier();
+      }
+    }
+    if constexpr (MX2) {
+#pragma nounroll
+      for (int j = SH; j < S; ++j) {   // the second walk (see the stream-K kernel)
+        const int lg = rg, lkk = rkk, lj = rj;
+        read_step(f);
+        const int n = (j + 2 < S) ? issue_step() : 0;
+        wait_and_barrier(n);
+        __builtin_amdgcn_s_setprio(1);
+        lo_mfmas(f, j - SH, lg, lkk, lj);
         __builtin_amdgcn_s_setprio(0);
         plain_barrier();
       }
@@ -1980,7 +2050,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 1536 : 0);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 1536 : 0) + (PrecMx2(PREC) ? 2 * (256 + 16) * 8 : 0);
   static std::atomic<unsigned long long> attr_done{0};
   int attr_dev = 0;
   if (lds_attr_needed(&attr_done, &attr_dev)) {

@@ -455,3 +455,15 @@ def test_gemm_mx2_stream_k(epi, segs):
         assert (np.abs(out - ref) / scale).max() < 3e-5
     else:
         assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX], ids=["tdnn3", "cvec5"])
+def test_gemm_mx2_per_tile_kernel(epi, segs):
+    # 3 x 256 rows: too few tiles for the persistent grid -> the 256-row per-tile kernel
+    out, ref = _run_mx_case(epi, 768, 512, segs, seed=19, prec=7)
+    if epi == 2:
+        scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+        assert (np.abs(out - ref) / scale).max() < 3e-5
+    else:
+        assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13
