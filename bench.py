@@ -37,8 +37,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # precision mode -> MFMAs executed per algorithmic product in the frame-level GEMMs
-PRECISION_NOTES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "auto": None, "bf16": 1, "fp16": 1}
-KERNEL_PASSES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "bf16": 1, "fp16": 1}
+PRECISION_NOTES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "fp16mx2": 1.5, "auto": None, "bf16": 1, "fp16": 1}
+KERNEL_PASSES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "fp16mx2": 1.5, "fp16x3e": 3, "bf16": 1, "fp16": 1}
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 

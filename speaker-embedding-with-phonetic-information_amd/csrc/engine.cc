@@ -12,8 +12,10 @@ namespace xv {
 
 namespace {
 
+constexpr int kDefaultFastMinPooledMx2 = 100;
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 3;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual plane
+constexpr uint32_t kBlobVersion = 4;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
+                                       // plane; 4: + the 4-bit weight image of kPrecFp16Mx2
 constexpr uint64_t kNone = ~0ull;
 
 struct BlobHeader {
@@ -35,7 +37,8 @@ struct BlobLayer {
   int32_t in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
   uint64_t w_hi, w_lo, bias, scale, offset;  // relative to data_offset
   uint64_t w4, w4_scale;                     // kPrecFp16Mx residual plane + its E8M0 scales in both tile orders, or kNone
-  int32_t ldw4, reserved;
+  int32_t ldw4, ldw4b;
+  uint64_t w4b, w4b_scale;                   // kPrecFp16Mx2: 4-bit image of the weights + scales (both tile orders), or kNone
 };
 
 // Round-to-nearest-even onto the e2m1 grid {0, .5, 1, 1.5, 2, 3, 4, 6} (saturating), like v_cvt_scalef32_pk_fp4_*.
@@ -123,7 +126,7 @@ void TileMxScales(const uint8_t* natural, int n_pad, int nsteps, bool weights_ar
 }
 
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
-  if (precision < kPrecBf16x3 || precision > kPrecFp16Mx) throw EngineError("unknown precision mode");
+  if (precision < kPrecBf16x3 || precision > kPrecFp16Mx2) throw EngineError("unknown precision mode");
   const bool split = PrecWPlanes(precision) == 2;
   const bool f16 = PrecF16(precision);
   const int nl = (int)prog.layers.size();
@@ -169,9 +172,9 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     b.offset = cur;
     cur = Align256(cur + (uint64_t)b.n_pad * 4);
     // kPrecFp16Mx residual plane (frame-level layers whose K walk consists of whole blocks of four steps)
-    b.w4 = b.w4_scale = kNone;
-    b.ldw4 = 0;
-    if ((precision == kPrecAuto || precision == kPrecFp16Mx) && !L.segment_level) {
+    b.w4 = b.w4_scale = b.w4b = b.w4b_scale = kNone;
+    b.ldw4 = b.ldw4b = 0;
+    if ((precision == kPrecAuto || precision == kPrecFp16Mx || precision == kPrecFp16Mx2) && !L.segment_level) {
       long key[kMaxSeg];
       int shift[kMaxSeg], ksteps[kMaxSeg];
       for (int j = 0; j < b.nsrc; ++j) {
@@ -189,6 +192,25 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4);
         b.w4_scale = cur;
         cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);   // both tile orders (TileMxScales)
+      }
+      if (precision == kPrecFp16Mx2) {
+        // second K walk: every source a whole number of 128-column steps, at most 512 columns wide (kernels.hip,
+        // gemm_mx2_applicable).  A layer that cannot run it must read the network input only (it then runs kPrecFp16x3E
+        // on the two planes prep_input writes): the other layers' outputs have no fp16 residual plane in this mode
+        bool lo_ok = b.w4 != kNone, input_only = true;
+        for (int j = 0; j < b.nsrc; ++j) {
+          if (RoundUp(b.src_dim[j], kBK) % 128 || RoundUp(b.src_dim[j], kBN) > 512 || b.src_layer[j] < 0) lo_ok = false;
+          if (b.src_layer[j] != kSrcInput) input_only = false;
+        }
+        if (lo_ok) {
+          b.ldw4b = nsteps / 4 * 64;
+          b.w4b = cur;
+          cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4b);
+          b.w4b_scale = cur;
+          cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
+        } else if (!input_only) {
+          throw EngineError("precision fp16mx2 cannot run layer " + L.name + " (it needs sources of whole 128-column blocks, at most 512 wide)");
+        }
       }
     }
   }
@@ -294,6 +316,18 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
       }
       TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4_scale);
       TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4_scale + (size_t)b.n_pad * nsc);
+      if (b.w4b != kNone) {   // kPrecFp16Mx2: 4-bit image of the (scaled) weights in the order of the second walk
+        std::vector<int> lo_wcol(b.k_pad / 128);
+        const int n_lo = PlanWalkLoSteps(ng, wg, lo_wcol.data(), (int)lo_wcol.size());
+        std::fill(nat.begin(), nat.end(), 127);
+        std::vector<float> wrow(b.k_pad);
+        for (int n = 0; n < L.out_dim; ++n) {
+          for (int k = 0; k < b.k_pad; ++k) wrow[k] = src_col[k] >= 0 ? L.w[(size_t)n * L.in_dim + src_col[k]] * wscale : 0.f;
+          PackMxWeightsRow(wrow.data(), lo_wcol.data(), n_lo, data + b.w4b + (size_t)n * b.ldw4b, nat.data() + (size_t)n * nsc);
+        }
+        TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4b_scale);
+        TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4b_scale + (size_t)b.n_pad * nsc);
+      }
     }
     float* bias = (float*)(data + b.bias);
     float* scale = (float*)(data + b.scale);
@@ -332,7 +366,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
   if (h.n_layers < 1 || h.n_layers > 4096 || h.data_offset > n ||
       sizeof(BlobHeader) + (uint64_t)h.n_layers * sizeof(BlobLayer) > h.data_offset)
     throw EngineError("model blob: layer table does not fit the header");
-  if (h.precision < kPrecBf16x3 || h.precision > kPrecFp16Mx) throw EngineError("model blob: unknown precision mode");
+  if (h.precision < kPrecBf16x3 || h.precision > kPrecFp16Mx2) throw EngineError("model blob: unknown precision mode");
   if (h.output_layer < 0 || h.output_layer >= h.n_layers || h.pooled_layer >= h.n_layers)
     throw EngineError("model blob: layer index out of range");
   const uint64_t data_bytes = n - h.data_offset;
@@ -370,6 +404,9 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
       if (b.w4 != kNone)
         ok = ok && b.ldw4 == b.k_pad / kBK / 4 * 64 && (b.k_pad / kBK) % 4 == 0 && inside(b.w4, (uint64_t)b.n_pad * b.ldw4) &&
              b.w4_scale != kNone && inside(b.w4_scale, 2 * (uint64_t)b.n_pad * (uint64_t)(b.k_pad / kBK));
+      if (b.w4b != kNone)
+        ok = ok && b.w4 != kNone && b.ldw4b == b.k_pad / 128 * 64 && inside(b.w4b, (uint64_t)b.n_pad * b.ldw4b) &&
+             b.w4b_scale != kNone && inside(b.w4b_scale, 2 * (uint64_t)b.n_pad * (uint64_t)(b.k_pad / kBK));
       if (!ok) throw EngineError("model blob: layer " + std::to_string(i) + " is inconsistent");
     }
     BlobLayerInfo li;
@@ -385,6 +422,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
     li.left = b.left;
     li.right = b.right;
     li.has_w4 = b.w4 != kNone;
+    li.has_w4b = b.w4b != kNone;
     for (int j = 0; j < b.nsrc; ++j) {
       LayerSource s;
       s.layer = b.src_layer[j];
@@ -457,16 +495,20 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
   nplanes_ = PrecWPlanes(info_.precision);   // residual planes exist for every split mode
   // Kernel modes.  slow_prec_ runs everything that is not a frame-level GEMM of a "fast" chunk; fast chunks (only
   // kPrecFp16x2 / kPrecAuto have them) are those that pool at least fast_min_pooled_ frames, see FillPlan.
-  const bool fast_family = info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx;
+  const bool fast_family = info_.precision == kPrecFp16x2 || info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx ||
+                           info_.precision == kPrecFp16Mx2;
   slow_prec_ = fast_family ? (int)kPrecFp16x3 : info_.precision;
   has_fast_ = !frame_mode_ && fast_family;
   // fast chunks run kPrecFp16Mx on the layers that allow it (packed residual plane, sources with a group-max table)
   // and kPrecFp16x2 on the others
-  fast_mx_ = has_fast_ && (info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx);
+  fast_mx_ = has_fast_ && (info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx || info_.precision == kPrecFp16Mx2);
+  fast_mx2_ = has_fast_ && info_.precision == kPrecFp16Mx2;
   fast_min_pooled_ = 0;
-  if (info_.precision == kPrecAuto) {
+  if (info_.precision == kPrecAuto || info_.precision == kPrecFp16Mx2) {
+    // kPrecFp16Mx2 corrects the activation rounding, but what is left still averages over the pooled frames: 3-4e-5 at
+    // 386 pooled frames, 4.5e-5 at 123, 0.6-1.5e-4 at 11 - chunks below the threshold take the three-pass arithmetic
     const char* e = getenv("XVEC_FAST_MIN_POOLED");
-    fast_min_pooled_ = (e && *e) ? atoi(e) : kDefaultFastMinPooled;
+    fast_min_pooled_ = (e && *e) ? atoi(e) : (info_.precision == kPrecAuto ? kDefaultFastMinPooled : kDefaultFastMinPooledMx2);
   }
   Check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   {
@@ -504,6 +546,9 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     layers_[i].w4 = b.w4 == kNone ? nullptr : base + b.w4;
     layers_[i].w4_scale = b.w4_scale == kNone ? nullptr : base + b.w4_scale;
     layers_[i].ldw4 = b.ldw4;
+    layers_[i].w4b = b.w4b == kNone ? nullptr : base + b.w4b;
+    layers_[i].w4b_scale = b.w4b_scale == kNone ? nullptr : base + b.w4b_scale;
+    layers_[i].ldw4b = b.ldw4b;
   }
   in_ld_ = RoundUp(info_.input_dim, kBK);
   stats_ld_ = RoundUp(2 * info_.pool_dim, kBK);
@@ -594,6 +639,10 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
       }
       Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
       if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true);
+      if (fast_mx2_) {
+        Ensure(&L.act[i].act_lo4, r * (li.n_pad / 2), true);
+        Ensure(&L.act[i].act_lo4s, r * Lo4ScalePitch(li.n_pad), true);
+      }
     }
     // per layer: max |activation| of every 16-row group (what a kPrecFp16Mx consumer scales its 4-bit copy by)
     if (fast_mx_) Ensure(&L.gmax, layers_.size() * (size_t)(rows / kRowAlign) * 4, true);
@@ -861,6 +910,11 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       sg.ksteps = RoundUp(src.dim, kBK) / kBK;
       sg.gmax = (mx_pass && !li.segment_level && src.layer >= 0 && !info_.layers[src.layer].segment_level) ? gmax_of(src.layer)
                                                                                                       : nullptr;
+      if (fast_mx2_ && !li.segment_level && src.layer >= 0 && !info_.layers[src.layer].segment_level) {
+        const int pn = info_.layers[src.layer].n_pad;
+        sg.lo4 = (const uint8_t*)L.act[src.layer].act_lo4.p + (size_t)kHalo * (pn / 2);
+        sg.lo4s = (const uint8_t*)L.act[src.layer].act_lo4s.p + (size_t)kHalo * Lo4ScalePitch(pn);
+      }
       ksteps += sg.ksteps;
     }
     ga.total_ksteps = ksteps;
@@ -870,6 +924,9 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     ga.w4 = dl.w4;
     ga.w4_scale = dl.w4_scale;
     ga.ldw4 = dl.ldw4;
+    ga.w4b = dl.w4b;
+    ga.w4b_scale = dl.w4b_scale;
+    ga.ldw4b = dl.ldw4b;
     ga.n_tiles = li.n_pad / kBN;
     ga.relu = li.relu;
     ga.bn = li.bn;
@@ -894,6 +951,10 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         ga.out_hi = ActBase(L.act[i].act_hi, li.n_pad);
         ga.out_lo = ActBase(L.act[i].act_lo, li.n_pad);
         ga.ldo = li.n_pad;
+        if (fast_mx2_) {
+          ga.out_lo4 = (uint8_t*)L.act[i].act_lo4.p + (size_t)kHalo * (li.n_pad / 2);
+          ga.out_lo4s = (uint8_t*)L.act[i].act_lo4s.p + (size_t)kHalo * Lo4ScalePitch(li.n_pad);
+        }
       }
     } else {
       ga.m_tiles = plan.b_pad / kBM;
@@ -923,6 +984,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     }
     // scales of the residual plane in the tile order of this epilogue's operand orientation (TileMxScales)
     if (ga.w4_scale && epi == kEpiStats) ga.w4_scale += (size_t)li.n_pad * (li.k_pad / kBK);
+    if (ga.w4b_scale && epi == kEpiStats) ga.w4b_scale += (size_t)li.n_pad * (li.k_pad / kBK);
     arm(std::string("tdnn_gemm<") + (epi == kEpiAct ? "act" : epi == kEpiF32 ? "f32" : "stats") + ">:" + li.name);
     if (li.segment_level || plan.rows_fast == 0) {
       Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
@@ -938,9 +1000,13 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         for (int j = 0; j < gr.nseg; ++j) {
           gr.seg[j].hi += r0 * gr.seg[j].ld;
           if (gr.seg[j].lo) gr.seg[j].lo += r0 * gr.seg[j].ld;
+          if (gr.seg[j].lo4) gr.seg[j].lo4 += r0 * (gr.seg[j].ld / 2);
+          if (gr.seg[j].lo4s) gr.seg[j].lo4s += r0 * Lo4ScalePitch(gr.seg[j].ld);
         }
         if (gr.out_hi) gr.out_hi += r0 * gr.ldo;
         if (gr.out_lo) gr.out_lo += r0 * gr.ldo;
+        if (gr.out_lo4) gr.out_lo4 += r0 * (gr.ldo / 2);
+        if (gr.out_lo4s) gr.out_lo4s += r0 * Lo4ScalePitch(gr.ldo);
         // the fast region records the group maxima of the planes it writes and, where the layer allows, runs the
         // 1.25-pass mode on them (region 0 starts at row 0: the tables need no offset)
         if (region == 0 && mx_pass && epi == kEpiAct) {
@@ -954,7 +1020,16 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         if (gr.grp_range) gr.grp_range += (r0 / kRowAlign) * 2;
         gr.m_valid = (int)(r1 - r0);
         int rprec = prec;
-        if (region == 0) rprec = (mx_pass && gemm_mx_applicable(gr)) ? (int)kPrecFp16Mx : (int)kPrecFp16x2;
+        if (region == 0) {
+          if (fast_mx2_) {
+            // every layer emits the 4-bit residual of its fp16 plane; a layer that cannot run the second walk reads the
+            // network input only (PackModel checked it) and runs the three-pass arithmetic on the planes of prep_input
+            rprec = gemm_mx2_applicable(gr) ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3E;
+            if (rprec == kPrecFp16x3E && epi != kEpiAct) throw EngineError("fp16mx2: layer " + li.name + " cannot run the mode");
+          } else {
+            rprec = (mx_pass && gemm_mx_applicable(gr)) ? (int)kPrecFp16Mx : (int)kPrecFp16x2;
+          }
+        }
         Check(launch_tdnn_gemm(gr, rprec, epi, s), "tdnn_gemm launch");
         if (first_prof) prof_labels_.back() += std::string(" ") + last_gemm_kernel();
       }

@@ -46,6 +46,7 @@ struct BlobLayerInfo {
   std::string name;
   int in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
   bool has_w4 = false;   // carries the 4-bit residual plane of kPrecFp16Mx
+  bool has_w4b = false;  // and the 4-bit weight image of kPrecFp16Mx2
   std::vector<LayerSource> src;
 };
 
@@ -136,9 +137,13 @@ class Engine {
     const uint8_t* w4;
     const uint8_t* w4_scale;
     int ldw4;
+    const uint8_t* w4b;         // kPrecFp16Mx2
+    const uint8_t* w4b_scale;
+    int ldw4b;
   };
   struct ActBuf {
     Buf act_hi, act_lo;   // frame-level: [halo + rows + halo][n_pad]; segment-level: [b_pad][n_pad]
+    Buf act_lo4, act_lo4s;   // kPrecFp16Mx2: 4-bit residual of act_hi [..][n_pad / 2] and its scales [..][Lo4ScalePitch(n_pad)]
   };
   // A lane = one in-flight batch: its own stream and its own activation / workspace buffers.  Consecutive
   // forward calls on the engine's own streams alternate between lanes, so the tail of one batch (partially filled
@@ -195,6 +200,7 @@ class Engine {
   int slow_prec_ = 0;
   bool has_fast_ = false;
   bool fast_mx_ = false;
+  bool fast_mx2_ = false;   // kPrecFp16Mx2: every frame-level layer of a fast chunk runs it (or kPrecFp16x3E on the input)
   int fast_min_pooled_ = 0;
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;   // host-slot uploads (SubmitHost)

@@ -286,6 +286,7 @@ int main(int argc, char** argv) {
     else if (opt.precision == "fp16x2") precision = xv::kPrecFp16x2;
     else if (opt.precision == "auto") precision = xv::kPrecAuto;
     else if (opt.precision == "fp16mx") precision = xv::kPrecFp16Mx;
+    else if (opt.precision == "fp16mx2") precision = xv::kPrecFp16Mx2;
     else {
       fprintf(stderr, "%s: invalid --precision=%s\n", kProg, opt.precision.c_str());
       return 1;

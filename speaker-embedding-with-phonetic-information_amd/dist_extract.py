@@ -49,7 +49,7 @@ def main(argv=None):
     ap.add_argument("--chunk-size", type=int, default=-1)
     ap.add_argument("--min-chunk-size", type=int, default=100)
     ap.add_argument("--pad-input", default="true")
-    ap.add_argument("--precision", default="auto", choices=["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "auto"])
+    ap.add_argument("--precision", default="auto", choices=["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "fp16mx2", "auto"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-run", action="store_true", help="shard + broadcast only (no device; used by CPU tests)")
     args = ap.parse_args(argv)

@@ -28,6 +28,7 @@ def _run(tmp_path, tag, env, *args):
     ("auto", "v2_xvector", 200, 400, True),       # two regions, ragged lengths
     ("fp16x2", "v5_cvector", 160, 400, False),    # two-source Append, AM branch
     ("bf16", "v2_xvector", 256, 400, False),
+    ("fp16mx2", "v2_xvector", 200, 400, True),    # second K walk; parts cut inside both walks; two regions
 ])
 def test_stream_k_is_bit_identical_to_per_tile_kernels(tmp_path, prec, topology, n, T, ragged):
     args = [topology, prec, n, T] + (["ragged"] if ragged else [])
