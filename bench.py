@@ -475,7 +475,7 @@ def main():
             del c3
             os.environ["XVEC_LANES"] = str(args.lanes)
             # the other arithmetic modes on the same workload, each with its measured error (never `value`)
-            for pname in ("fp16x3", "fp16x2", "bf16", "fp16"):
+            for pname in ("fp16x3", "fp16mx2", "fp16x2", "bf16", "fp16"):
                 if pname == args.precision:
                     continue
                 c2 = P.Context(model, device=local_rank, precision=P.PRECISIONS[pname])
@@ -500,7 +500,7 @@ def main():
                 tref = np.stack([tev.compute(u)[0] for u in tu])
                 res["parity_trained_like_model"] = {
                     pn: H.rel_err(P.Context(tmodel, device=local_rank, precision=P.PRECISIONS[pn]).forward_batch(tf, to), tref)
-                    for pn in ("fp16x3", "fp16x2", args.precision)}
+                    for pn in ("fp16x3", "fp16mx2", "fp16x2", args.precision)}
             except Exception as e:   # noqa: BLE001
                 res["parity_trained_like_model"] = {"error": str(e)}
             # BASELINE.json configs 3 and 5 on this GPU

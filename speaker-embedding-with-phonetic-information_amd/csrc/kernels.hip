@@ -351,6 +351,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
     // h = p>>1, position inside the group (p&1)*4 + r
     const int ncol = nbase + fr_g * 8;
+    unsigned e4[4] = {0u, 0u, 0u, 0u};   // PrecEmitsLo4: scale byte of row q * 16 + fr_i (the same in the row's four lanes)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = mbase + q * 16 + fr_i;
@@ -383,13 +384,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
           }
         }
+        float ymax = 0.f;   // max |y| of this lane's 16 values (its share of the row's 64 columns)
+        if (PrecEmitsLo4(PREC) || a.gmax_out) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) ymax = fmaxf(ymax, fabsf(y[v]));
+        }
         if (a.gmax_out) {
           // max |y| of this 16-row group (a NaN is skipped by fmaxf, the main product carries it anyway; rows that are
           // not computable frames of the layer do not count) -> one atomic max per wave: non-negative floats order
           // like their bit patterns
-          float m = gm[q];
-#pragma unroll
-          for (int v = 0; v < 16; ++v) m = fmaxf(m, fabsf(y[v]));
+          float m = fmaxf(gm[q], ymax);
           gm[q] = m;
           if (gm_phase != 1) {
             if (fr_i < e.first[q] || fr_i >= e.last[q]) m = 0.f;
@@ -403,16 +407,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
         *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
         if constexpr (PrecEmitsLo4(PREC)) {
-          // what the fp16 rounding dropped, as e2m1 with one power-of-two scale per row and 64-column block (this
-          // wave's 64 columns of the row: the four lanes fr_g of the row hold them): 2^(e - 2), e = exponent of the
-          // largest residual, so that it lands in [4, 8) (saturating at 6 like the activation copies of kPrecFp16Mx)
-          float r[16], m = 0.f;
-#pragma unroll
-          for (int v = 0; v < 8; ++v) {
-            r[2 * v] = y[2 * v] - from16<F16>((uint16_t)(hw[v] & 0xffffu));
-            r[2 * v + 1] = y[2 * v + 1] - from16<F16>((uint16_t)(hw[v] >> 16));
-            m = fmaxf(m, fmaxf(fabsf(r[2 * v]), fabsf(r[2 * v + 1])));
-          }
+          // what the fp16 rounding dropped, y - fp16(y), as e2m1 with one power-of-two scale per row and 64-column block
+          // (this wave's 64 columns of the row: the four lanes fr_g of the row hold them).  The residual of a value in
+          // [2^E, 2^(E+1)) is at most 2^(E-11); with E the exponent of the block's largest |y| the scale 2^(E-13) maps
+          // every residual into [-4, 4]: no saturation, the largest ones in the top binades of the grid.  (A scale from
+          // the residuals themselves costs a second pass over them and buys nothing: their maximum is almost always in
+          // the same binade.)  Below the fp16 normal range the residual is bounded by 2^-25.
+          float m = ymax;
           {
             float ma = m, mb = m;
             asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
@@ -423,24 +424,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             m = fmaxf(ma, mb);
           }
           unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 255u;
-          e = e < 3u ? 1u : (e > 254u ? 252u : e - 2u);
+          e = e < 113u ? 100u : (e > 254u ? 241u : e - 13u);
           const float sc4 = __builtin_bit_cast(float, e << 23);
           unsigned c0 = 0u, c1 = 0u;
           static_for<0, 4>([&](auto V) {
             constexpr int v = decltype(V)::value;
-            c0 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c0, r[2 * v], r[2 * v + 1], sc4, v);
-            c1 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c1, r[8 + 2 * v], r[8 + 2 * v + 1], sc4, v);
+            float r0, r1, r2, r3;
+            asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw[v]), "v"(y[2 * v]));
+            asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw[v]), "v"(y[2 * v + 1]));
+            asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(hw[4 + v]), "v"(y[8 + 2 * v]));
+            asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(hw[4 + v]), "v"(y[8 + 2 * v + 1]));
+            c0 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c0, r0, r1, sc4, v);
+            c1 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c1, r2, r3, sc4, v);
           });
           uint8_t* d4 = a.out_lo4 + (long)row * (a.ldo >> 1) + (ncol >> 1);
           *(unsigned*)d4 = c0;
           *(unsigned*)(d4 + 16) = c1;
-          if (fr_g == 0) a.out_lo4s[(long)row * Lo4ScalePitch(a.ldo) + (nbase >> 6)] = (uint8_t)e;
+          e4[q] = e;
         } else if constexpr (SPLIT) {
           uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
           *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
           *(u32x4*)(dl + 32) = u32x4{lw[4], lw[5], lw[6], lw[7]};
         }
       }
+    }
+    if constexpr (EPI == kEpiAct && PrecEmitsLo4(PREC)) {
+      // the scale bytes of the block's 64 rows in one store: lane (fr_i, fr_g) writes the one of row fr_g * 16 + fr_i
+      const unsigned eb = fr_g == 0 ? e4[0] : fr_g == 1 ? e4[1] : fr_g == 2 ? e4[2] : e4[3];
+      a.out_lo4s[(long)(mbase + fr_g * 16 + fr_i) * Lo4ScalePitch(a.ldo) + (nbase >> 6)] = (uint8_t)eb;
     }
   } else {
     // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i.  The cross-lane adds leave the sums of

@@ -68,16 +68,19 @@ const char* kUsage =
     "  --pad-input=true|false           pad short chunks by edge replication instead of skipping (default true)\n"
     "  --output-node=<name>             compute this node as the output (native form of nnet3-copy --nnet-config)\n"
     "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
-    "  --precision=fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
-    "                                   arithmetic of the MFMA GEMMs.  Default fp16x3 (split fp16, three MFMAs per\n"
-    "                                   product): fp32-grade results on any model.  auto: chunks that pool >= 300 frames\n"
-    "                                   run fp16mx (fp16 activations x fp16 weights + a block-scaled 4-bit residual\n"
-    "                                   product, 1.25 MFMA passes, ~1.8x faster), the others fp16x3; the error of the\n"
-    "                                   fast chunks is the fp16 rounding of the activations averaged by the pooling -\n"
-    "                                   within 1e-4 on models with Kaldi-initialisation-like weights, 1-3e-4 on\n"
+    "  --precision=fp16mx2|fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
+    "                                   arithmetic of the MFMA GEMMs.  Default: fp16mx2 where every layer can run it, else\n"
+    "                                   fp16x3 (nnet3-compute: always fp16x3).  fp16x3: split fp16, three MFMAs per\n"
+    "                                   product, fp32-grade (3e-7..4e-6 from the fp32 oracle).  fp16mx2: fp16 product +\n"
+    "                                   two block-scaled 4-bit products that correct the fp16 rounding of the weights\n"
+    "                                   and of the activations, 1.5 passes, ~1.4x faster: 3-5.5e-5 on every model\n"
+    "                                   tried; chunks that pool < 100 frames run fp16x3.  auto: chunks that pool >= 300\n"
+    "                                   frames run fp16mx (weights corrected only, 1.25 passes, ~1.9x faster than\n"
+    "                                   fp16x3), the others fp16x3; its error is the activation rounding averaged by the\n"
+    "                                   pooling - 5-8e-5 on models with Kaldi-initialisation-like weights, 1-2e-4 on\n"
     "                                   heavy-tailed ones (DESIGN.md section 3.0): check it on your model first.\n"
-    "  --fast-min-pooled=<int>          --precision=auto: chunks that pool at least this many frames take the fast\n"
-    "                                   kernels (default 300, or $XVEC_FAST_MIN_POOLED)\n"
+    "  --fast-min-pooled=<int>          auto / fp16mx2: chunks that pool at least this many frames take the fast\n"
+    "                                   kernels (default 300 / 100, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
@@ -96,7 +99,7 @@ struct Options {
   bool pad_input = true;
   std::string output_node;
   std::string nnet_config;
-  std::string precision = "fp16x3";
+  std::string precision = "default";
   int batch_frames = 1 << 17;
   int fast_min_pooled = -1;
   int device = -1;
@@ -278,6 +281,10 @@ int main(int argc, char** argv) {
     }
     const std::string nnet_rx = pos[0], feat_rspec = pos[1], vec_wspec = pos[2];
 
+    // default: fp16mx2 (1.5 MFMA passes, 3-5.5e-5 from the fp32 oracle on every model tried, the heavy-tailed ones included)
+    // for pooled outputs where every layer can run it, else fp16x3 (fp32-grade, three passes); frame-level outputs: fp16x3
+    const bool default_precision = opt.precision == "default";
+    if (default_precision) opt.precision = g_frame_job ? "fp16x3" : "fp16mx2";
     int precision;
     if (opt.precision == "bf16x3") precision = xv::kPrecBf16x3;
     else if (opt.precision == "bf16") precision = xv::kPrecBf16;
@@ -325,7 +332,16 @@ int main(int argc, char** argv) {
     }
     if (device >= ndev) device %= ndev;
     if (opt.fast_min_pooled >= 0) setenv("XVEC_FAST_MIN_POOLED", std::to_string(opt.fast_min_pooled).c_str(), 1);   // read by the engine
-    std::vector<uint8_t> blob = xv::PackModel(prog, precision);
+    std::vector<uint8_t> blob;
+    try {
+      blob = xv::PackModel(prog, precision);
+    } catch (const xv::EngineError& e) {
+      if (!default_precision || precision != xv::kPrecFp16Mx2) throw;
+      XLOG(e.what() << ": using --precision=fp16x3");
+      opt.precision = "fp16x3";
+      precision = xv::kPrecFp16x3;
+      blob = xv::PackModel(prog, precision);
+    }
     xv::Engine engine(blob.data(), blob.size(), device);
     XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "

@@ -179,14 +179,15 @@ def test_cli_profile_json(job):
 
 
 def test_cli_precision_modes(job):
-    """--precision: the default is fp16x3 (fp32-grade on any model); auto = the fast kernels (fp16mx) for the chunks that
-    pool >= 300 frames, fp16x3 for the others; --fast-min-pooled moves the threshold; every mode within the parity
-    tolerance on this model, and the switch really switches."""
+    """--precision: the default is fp16mx2 (1.5 passes, model-independent error; chunks that pool < 100 frames take
+    fp16x3); auto = fp16mx for the chunks that pool >= 300 frames, fp16x3 for the others; --fast-min-pooled moves the
+    thresholds; every mode within the parity tolerance on this model, and the switch really switches."""
     d, utts, ev = job
     n2 = ev.net
     ev64 = H.xo.GraphEvaluator(n2, np.float64)
     res = {}
-    for tag, extra in (("default", []), ("auto", ["--precision=auto"]), ("fp16x3", ["--precision=fp16x3"]),
+    for tag, extra in (("default", []), ("fp16mx2", ["--precision=fp16mx2"]), ("auto", ["--precision=auto"]),
+                       ("fp16x3", ["--precision=fp16x3"]),
                        ("bf16x3", ["--precision=bf16x3"]), ("fp16mx", ["--precision=fp16mx"]),
                        ("auto_all_slow", ["--precision=auto", "--fast-min-pooled=100000"]),
                        ("auto_low", ["--precision=auto", "--fast-min-pooled=100"])):
@@ -199,10 +200,17 @@ def test_cli_precision_modes(job):
         ref = H.xo.extract_xvector(ev64, x, 10000, 25, True)
         if ref is None:
             continue
-        for tag in ("auto", "fp16x3", "bf16x3"):
+        for tag in ("auto", "fp16x3", "bf16x3", "default"):
             assert H.rel_err(res[tag][k][None], ref[None]) < TOL, (tag, k)
-    for k in res["fp16x3"]:
-        assert np.array_equal(res["default"][k], res["fp16x3"][k])                # the default IS fp16x3
+        assert H.rel_err(res["default"][k][None], ref[None]) < 6e-5, k
+    for k, x in utts:
+        if k not in res["fp16x3"]:
+            continue
+        assert np.array_equal(res["default"][k], res["fp16mx2"][k])               # the default IS fp16mx2 ...
+        if 25 <= x.shape[0] < 110:
+            assert np.array_equal(res["default"][k], res["fp16x3"][k])            # ... whose short chunks take fp16x3
+        if x.shape[0] >= 130:
+            assert not np.array_equal(res["default"][k], res["fp16x3"][k])
     long_k = [k for k, x in utts if x.shape[0] >= 330]          # 400, 1000, 333 frames: fast kernels in auto
     short_k = [k for k, x in utts if 25 <= x.shape[0] < 300]    # 137, 25 frames: three-pass in auto
     assert long_k and short_k

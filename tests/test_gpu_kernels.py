@@ -164,8 +164,8 @@ def test_gemm_act_epilogue(prec):
 @pytest.mark.parametrize("segs", [TDNN2, TDNN1], ids=["tdnn2", "tdnn1"])
 def test_gemm_planes_epilogue_with_4bit_residual(segs):
     """XV_PREC_FP16X3E: the planes epilogue writes the fp16 plane and the e2m1 image of its rounding residual (one scale
-    per row and 64 columns, the largest residual of the block in the top binade): together 2-3 bits better than the fp16
-    plane alone - worst case half a grid step (1) at a scale of a quarter of the largest residual."""
+    per row and 64 columns, 2^-13 of the binade of the block's largest value): together 2-3 bits better than the fp16
+    plane alone - worst case half a grid step (0.5 between 2 and 4) at that scale."""
     out, ref = _run_case(8, 0, 384, 512, segs, relu=True, bn=True, seed=1)
     err = np.abs(out - ref)
     blk = np.abs(ref).reshape(ref.shape[0], -1, 64).max(axis=2, keepdims=True)        # per (row, 64 columns)
@@ -243,14 +243,14 @@ def _q_e2m1(t, torch):
 
 def _lo4_plane(x32, xh, torch):
     """What the planes epilogue of XV_PREC_FP16MX2 / FP16X3E writes next to the fp16 plane xh of the fp32 values x32: the
-    e2m1 codes of r = x32 - xh with one scale 2^(e - 2) per row and 64 columns (e = exponent of the block's largest |r|),
-    packed two per byte, the E8M0 scale bytes, and the decoded values."""
+    e2m1 codes of r = x32 - xh with one scale 2^(E - 13) per row and 64 columns (E = exponent of the block's largest
+    |x32|: every residual then lies in [-4, 4]), packed two per byte, the E8M0 scale bytes, and the decoded values."""
     r = x32.double() - xh.double()
     rows, n = r.shape
     b = r.reshape(rows, n // 64, 64)
-    m = b.abs().amax(dim=2, keepdim=True)
-    ebits = (m.float().view(torch.int32) >> 23) & 255
-    e8 = torch.where(ebits < 3, torch.ones_like(ebits), torch.where(ebits > 254, torch.full_like(ebits, 252), ebits - 2))
+    m = x32.float().abs().reshape(rows, n // 64, 64).amax(dim=2, keepdim=True)
+    ebits = (m.view(torch.int32) >> 23) & 255
+    e8 = torch.where(ebits < 113, torch.full_like(ebits, 100), torch.where(ebits > 254, torch.full_like(ebits, 241), ebits - 13))
     sc = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=r.device), e8.double() - 127)
     q = _q_e2m1(b / sc, torch)
     grid = torch.tensor(E2M1, dtype=torch.float64, device=r.device)
