@@ -130,8 +130,9 @@ def test_trained_like_model_needs_the_three_pass_mode(seed):
     spread over 1e-3 .. 10 (helpers.trained_like_model): the error of every mode that keeps activations in ONE fp16
     plane is set by the activation rounding, and that depends on the model - on this one fp16x2 and auto (fp16mx) land
     at 1 - 2.5e-4, above the 1e-4 bar that they meet on Kaldi's own initialisation distribution (the other tests and
-    the benchmark model).  fp16x3 keeps fp32-grade results; hence it is the command-line default and the fast modes are
-    opt-in (INTEGRATION.md)."""
+    the benchmark model).  fp16x3 keeps fp32-grade results; the one-plane fast modes are opt-in, the
+    command line's default is fp16mx2, which carries a 4-bit second plane for the activations
+    (test_fp16mx2_is_model_independent)."""
     P = H.pkg()
     net, line = H.trained_like_model("v2_xvector", seed)
     model = P.Model(raw=net.to_bytes(True), nnet_config=line)
