@@ -292,3 +292,27 @@ def test_mx_residual_packing_and_scale_tiling(segs):
                 for b in (0, nblk - 1):
                     for g in range(4):
                         assert tiled[(t * nblk + b) * 512 + h * 256 + (i * 4 + g) * 4 + wf] == sc[row, 4 * b + g]
+
+
+def test_mx_weight_image_packing():
+    """xv_pack_mx_weights (host code): the 4-bit image of the weights for the second K walk of XV_PREC_FP16MX2 - per row
+    and lane-group chunk of 32 consecutive columns the smallest power-of-two scale that keeps the chunk inside the e2m1
+    range, nearest grid values, 64 bytes per 128-column step in walk order (chunk -> offset)."""
+    rng = np.random.default_rng(5)
+    segs = [(0, -2, 256), (0, 0, 256), (0, 2, 256), (1, 0, 128)]
+    n_pad, K = 128, sum(s[2] for s in segs)
+    w = (rng.standard_normal((n_pad, K)) * rng.uniform(0.01, 40.0, (n_pad, 1))).astype(np.float32)
+    w4b, sc = P.pack_mx_weights(w, segs)
+    assert w4b.shape == (n_pad, K // 2) and sc.shape == (n_pad, K // 32)
+    lo_col = [kq * 128 + j * 256 for kq in range(2) for j in range(3)] + [768]      # steps of the second walk
+    nib = np.stack([w4b & 15, w4b >> 4], axis=-1).reshape(n_pad, K // 128, 4, 32)      # [row][step][lane group][element]
+    val = np.where(nib & 8, -1.0, 1.0) * E2M1[nib & 7]
+    for t, c0 in enumerate(lo_col):
+        for g in range(4):
+            x = w[:, c0 + 32 * g: c0 + 32 * g + 32].astype(np.float64)
+            s = 2.0 ** (sc[:, 4 * t + g].astype(np.float64) - 127)[:, None]
+            m = np.abs(x).max(axis=1)
+            assert np.all(m <= 6 * s[:, 0] * (1 + 1e-12)) and np.all(m > 3 * s[:, 0])
+            a = np.abs(x / s)
+            half_gap = np.where(a >= 4, 1.0, np.where(a >= 2, 0.5, 0.25))
+            assert np.all(np.abs(val[:, t, g, :] * s - x) / s <= half_gap + 1e-9)
