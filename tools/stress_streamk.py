@@ -1,7 +1,7 @@
 """GPU box: soak test of the stream-K exchange (partial tiles handed from workgroup to workgroup through the coherent
 workspace, flags keyed by a per-launch epoch).  Thousands of forward passes over several batch shapes, two engine lanes
 in flight, every result compared bit for bit with the first one of its shape; the same again with a second context on
-the same GPU running concurrently from another thread.  usage: stress_streamk.py [iterations]"""
+the same GPU running concurrently from another thread.  usage: stress_streamk.py [iterations] [precision]"""
 import importlib
 import os
 import sys
@@ -17,6 +17,7 @@ import helpers as H  # noqa: E402
 
 P = importlib.import_module("speaker-embedding-with-phonetic-information_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+PREC = sys.argv[2] if len(sys.argv) > 2 else "auto"
 os.environ["XVEC_LANES"] = "2"
 net, line = H.synth_model("v2_xvector")
 model = P.Model(raw=net.to_bytes(True), nnet_config=line)
@@ -27,7 +28,7 @@ bad = []
 
 
 def worker(tag):
-    ctx = P.Context(model, device=0)
+    ctx = P.Context(model, device=0, precision=P.PRECISIONS[PREC])
     data = []
     for lens in shapes:
         rows = int(np.sum(lens))
