@@ -58,6 +58,14 @@ inline uint8_t ToE2M1(float x) {
 }
 
 inline int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
+// K columns a source occupies in a layer's weight planes.  The modes with 4-bit products walk K in blocks of 128 columns:
+// there a source that is another layer's output is padded to a multiple of 128 (its plane is that wide and zero beyond
+// the layer's dimension, the weights of the padding are zero) - a 650-wide source (the phonetic branch of the c-vector
+// networks) costs 14 % more steps and can then run them instead of the two-pass arithmetic.
+inline int SrcKPad(int dim, int src_layer, bool segment_level, int precision) {
+  const bool blocks = precision == kPrecAuto || precision == kPrecFp16Mx || precision == kPrecFp16Mx2;
+  return RoundUp(dim, (blocks && !segment_level && src_layer >= 0) ? 128 : kBK);
+}
 inline uint64_t Align256(uint64_t x) { return (x + 255) & ~255ull; }
 
 }  // namespace
@@ -144,7 +152,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
       b.src_layer[j] = L.src[j].layer;
       b.src_offset[j] = L.src[j].offset;
       b.src_dim[j] = L.src[j].dim;
-      kp += RoundUp(L.src[j].dim, kBK);
+      kp += SrcKPad(L.src[j].dim, L.src[j].layer, L.segment_level, precision);
     }
     b.in_dim = L.in_dim;
     b.out_dim = L.out_dim;
@@ -180,7 +188,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
       for (int j = 0; j < b.nsrc; ++j) {
         key[j] = b.src_layer[j];
         shift[j] = b.src_offset[j];
-        ksteps[j] = RoundUp(b.src_dim[j], kBK) / kBK;
+        ksteps[j] = SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) / kBK;
       }
       WalkGroup wg[kMaxSeg];
       const int ng = PlanWalkGroups(b.nsrc, key, shift, ksteps, wg);
@@ -199,7 +207,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         // on the two planes prep_input writes): the other layers' outputs have no fp16 residual plane in this mode
         bool lo_ok = b.w4 != kNone, input_only = true;
         for (int j = 0; j < b.nsrc; ++j) {
-          if (RoundUp(b.src_dim[j], kBK) % 128 || RoundUp(b.src_dim[j], kBN) > 512 || b.src_layer[j] < 0) lo_ok = false;
+          if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 128 || b.src_layer[j] < 0) lo_ok = false;
           if (b.src_layer[j] != kSrcInput) input_only = false;
         }
         if (lo_ok) {
@@ -209,7 +217,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           b.w4b_scale = cur;
           cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
         } else if (!input_only) {
-          throw EngineError("precision fp16mx2 cannot run layer " + L.name + " (it needs sources of whole 128-column blocks, at most 512 wide)");
+          throw EngineError("precision fp16mx2 cannot run layer " + L.name + " (every source but the network input must be another layer's output)");
         }
       }
     }
@@ -272,7 +280,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           }
         }
         kcol += b.src_dim[j];
-        kpad += RoundUp(b.src_dim[j], kBK);
+        kpad += SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision);
       }
     }
     if (b.w4 != kNone) {
@@ -283,7 +291,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
       for (int j = 0; j < b.nsrc; ++j) {
         key[j] = b.src_layer[j];
         shift[j] = b.src_offset[j];
-        ksteps[j] = RoundUp(b.src_dim[j], kBK) / kBK;
+        ksteps[j] = SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) / kBK;
       }
       WalkGroup wg[kMaxSeg];
       const int ng = PlanWalkGroups(b.nsrc, key, shift, ksteps, wg);
@@ -296,7 +304,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         for (int j = 0; j < b.nsrc; ++j) {
           for (int d = 0; d < b.src_dim[j]; ++d) src_col[kpad + d] = kcol + d;
           kcol += b.src_dim[j];
-          kpad += RoundUp(b.src_dim[j], kBK);
+          kpad += SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision);
         }
       }
       uint8_t* w4 = data + b.w4;
@@ -395,7 +403,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
       int kp = 0;
       for (int j = 0; ok && j < b.nsrc; ++j) {
         ok = b.src_layer[j] >= kSrcPooled && b.src_layer[j] < i && b.src_dim[j] >= 1 && std::abs(b.src_offset[j]) <= 15;
-        kp += RoundUp(b.src_dim[j], kBK);
+        kp += SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, h.precision);
       }
       ok = ok && kp == b.k_pad;
       const uint64_t wbytes = (uint64_t)b.n_pad * b.k_pad * 2;
@@ -907,7 +915,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         sg.ld = pi.n_pad;
       }
       sg.row_shift = li.segment_level ? 0 : src.offset;
-      sg.ksteps = RoundUp(src.dim, kBK) / kBK;
+      sg.ksteps = SrcKPad(src.dim, src.layer, li.segment_level, info_.precision) / kBK;
       sg.gmax = (mx_pass && !li.segment_level && src.layer >= 0 && !info_.layers[src.layer].segment_level) ? gmax_of(src.layer)
                                                                                                       : nullptr;
       if (fast_mx2_ && !li.segment_level && src.layer >= 0 && !info_.layers[src.layer].segment_level) {

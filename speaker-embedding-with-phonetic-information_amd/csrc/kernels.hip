@@ -771,7 +771,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   constexpr bool MX2 = PrecMx2(PREC);          // second K walk over the 4-bit planes: see the stream-K kernel
   constexpr int SLB = SCB + 1536;
   constexpr int SLAB_ROWS = XROWS;
-  constexpr int SLAB_BYTES = SLAB_ROWS * 8;
+  constexpr int SLAB_BYTES = SLAB_ROWS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -830,6 +830,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   int ig = 0, ikk = 0, ij = 0;        // group, 32-column chunk inside the group, offset index inside the group
   int ixslot = 0, iwslot = 0;         // ring slots the next activation stage / weight stage go to
   int istep = 0;
+  int islab = 0, rslab = 0;   // kPrecFp16Mx2: slabs of activation-residual scales issued / begun by the read side
   Grp gi = a.grp[0];
   auto issue_step = [&]() __attribute__((always_inline)) -> int {    // returns the number of DMA instructions this wave issued
     int n = 0;
@@ -854,18 +855,16 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     }
     const bool lo_step = MX2 && istep >= SH;
     if constexpr (MX2) {
-      if (lo_step && ikk == 0 && ij == 0) {   // scales of this group's activation residuals for the tile rows (+ halo)
-        const int nc = gi.ld4s >> 2;
-        const unsigned sl = lds_base + SLB + ((ig - a.ngrp) & 1) * SLAB_BYTES;
+      if (lo_step && ij == 0 && (ikk & 1) == 0) {   // scales of the activation residuals of this and the next chunk
+        const unsigned sl = lds_base + SLB + (islab % 3) * SLAB_BYTES;
+        ++islab;
         const unsigned voff = (unsigned)(lane * gi.ld4s);
         if (wave < 4) {
-          const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + wave * 64) * gi.ld4s;
-          for (int c = 0; c < nc; ++c) glds4_sbase(src + c * 4, voff, sl + (c * SLAB_ROWS + wave * 64) * 4);
-          n += nc;
+          glds4_sbase(gi.lo4s + (long)(m0 + gi.shift0 + wave * 64) * gi.ld4s + (ikk >> 1) * 4, voff, sl + wave * 256);
+          n += 1;
         } else if (wave == 4) {
-          const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + 256) * gi.ld4s;
-          for (int c = 0; c < nc; ++c) glds4_sbase_lanes16(src + c * 4, voff, sl + (c * SLAB_ROWS + 256) * 4);
-          n += nc;
+          glds4_sbase_lanes16(gi.lo4s + (long)(m0 + gi.shift0 + 256) * gi.ld4s + (ikk >> 1) * 4, voff, sl + 256 * 4);
+          n += 1;
         }
       }
     }
@@ -1034,12 +1033,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     }
   };
 
-  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj) __attribute__((always_inline)) {
+  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj, const int slab) __attribute__((always_inline)) {
     if constexpr (MX2) {
       const int ws_lo = *(const int*)(smem + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + wave_n * 256 + (fr_i * 4 + fr_g) * 4);
-      const int bi = 2 * lkk + (fr_g >> 1);
-      const uint8_t* sl = (const uint8_t*)smem + SLB + ((lg - a.ngrp) & 1) * SLAB_BYTES +
-                          ((bi >> 2) * SLAB_ROWS + wave_m * 64 + fr_i + lj * a.grp[lg].dstep) * 4 + (bi & 3);
+      const uint8_t* sl = (const uint8_t*)smem + SLB + slab * SLAB_BYTES + (wave_m * 64 + fr_i + lj * a.grp[lg].dstep) * 4 +
+                          2 * (lkk & 1) + (fr_g >> 1);
       int xs_lo = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) xs_lo |= (int)sl[i * 64] << (8 * i);
@@ -1116,11 +1114,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
 #pragma nounroll
       for (int j = SH; j < S; ++j) {   // the second walk (see the stream-K kernel)
         const int lg = rg, lkk = rkk, lj = rj;
+        if (lj == 0 && (lkk & 1) == 0) ++rslab;
         read_step(f);
         const int n = (j + 2 < S) ? issue_step() : 0;
         wait_and_barrier(n);
         __builtin_amdgcn_s_setprio(1);
-        lo_mfmas(f, j - SH, lg, lkk, lj);
+        lo_mfmas(f, j - SH, lg, lkk, lj, (rslab - 1) % 3);
         __builtin_amdgcn_s_setprio(0);
         plain_barrier();
       }
@@ -1257,8 +1256,8 @@ bool gemm_mx2_applicable(const GemmArgs& a) {
   if (!gemm_mx_applicable(a) || !a.w4b || !a.w4b_scale || a.ldw4b <= 0) return false;
   GemmArgs b = a;
   build_groups(&b);
-  for (int i = 0; i < b.ngrp; ++i)   // whole 128-column steps; at most two scale dwords per row in the slab
-    if (b.grp[i].ksteps % 4 || b.grp[i].ld % 128 || b.grp[i].ld > 512) return false;
+  for (int i = 0; i < b.ngrp; ++i)   // whole 128-column steps
+    if (b.grp[i].ksteps % 4 || b.grp[i].ld % 128) return false;
   for (int j = 0; j < a.nseg; ++j)
     if (!a.seg[j].lo4 || !a.seg[j].lo4s) return false;
   return true;
@@ -1329,12 +1328,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // residual planes of the activations (64 bytes per row and step: the tiles have the shape of the fp16 tiles and use the
   // same rings and fragment reads) against the 4-bit image of the weights; one block-scaled MFMA per fragment pair.
   // Scales: weights - 512 bytes per step through the SCB ring like those of the residual blocks; activations - one byte
-  // per row and 64 columns, all of a source's bytes for the tile rows staged once per group as [dword c][row]
-  // ("slab", two buffers: the next group's arrives while the last steps of the current one are read).
+  // per row and 64 columns: the dword of a row that covers two consecutive steps (256 columns) is staged for the tile
+  // rows + halo as a "slab" when the walk of a group reaches it (ring of three slabs; the issue and the read side count
+  // them with the same rule).
   constexpr bool MX2 = PrecMx2(PREC);
   constexpr int SLB = PB + 2 * 1536;
   constexpr int SLAB_ROWS = TM + 16;
-  constexpr int SLAB_BYTES = SLAB_ROWS * 8;    // two dwords per row: sources up to 512 columns wide
+  constexpr int SLAB_BYTES = SLAB_ROWS * 4;
   constexpr int KQ = MX ? 4 : 1;               // K steps are dealt out in units of KQ (a 128-deep block is never cut)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1406,7 +1406,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const unsigned woff = (unsigned)(w_rho * a.ldw + ld_chunk * 8) * 2u;   // this lane's row / chunk inside the tile
   const unsigned woff4 = MX ? (unsigned)(w_rho * a.ldw4 + ld_chunk * 16) : 0u;
   const unsigned woffb = MX2 ? (unsigned)(w_rho * a.ldw4b + ld_chunk * 16) : 0u;
-  bool force_slab = false;             // the next step of the second walk stages its group's activation scales
+  bool force_slab = false;             // the next step of the second walk stages a slab whatever its position (part start)
+  int islab = 0, rslab = 0;            // slabs issued / begun by the read side in this part
   int ig = 0, ikk = 0, ij = 0, ixslot = 0, iwslot = 0, istep = 0;
   bool force_x = true;
   Grp gi = a.grp[0];
@@ -1450,18 +1451,19 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       ixslot = ixslot == 2 ? 0 : ixslot + 1;
     }
     if constexpr (MX2) {
-      if (lo_step && ((ikk == 0 && ij == 0) || force_slab)) {
-        // scales of this group's activation residuals for the tile rows (+ halo): dword c of row r -> slab[c][r]
+      if (lo_step && ((ij == 0 && (ikk & 1) == 0) || force_slab)) {
+        // scales of the activation residuals of this and the next 128-column chunk for the tile rows (+ halo)
         force_slab = false;
-        const int nc = gi.ld4s >> 2;
-        const unsigned sl = lds_base + SLB + ((ig - a.ngrp) & 1) * SLAB_BYTES;
-        const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + wave * 64) * gi.ld4s;
+        const unsigned sl = lds_base + SLB + (islab % 3) * SLAB_BYTES;
+        ++islab;
+        const uint8_t* src = gi.lo4s + (long)(m0 + gi.shift0 + wave * 64) * gi.ld4s + (ikk >> 1) * 4;
         const unsigned voff = (unsigned)(lane * gi.ld4s);
-        for (int c = 0; c < nc; ++c) {
-          glds4_sbase(src + c * 4, voff, sl + (c * SLAB_ROWS + wave * 64) * 4);
-          if (wave == 0) glds4_sbase_lanes16(src + (long)TM * gi.ld4s + c * 4, voff, sl + (c * SLAB_ROWS + TM) * 4);
+        glds4_sbase(src, voff, sl + wave * 256);
+        n += 1;
+        if (wave == 0) {
+          glds4_sbase_lanes16(src + (long)TM * gi.ld4s, voff, sl + TM * 4);
+          n += 1;
         }
-        n += nc * (wave == 0 ? 2 : 1);
       }
     }
     {
@@ -1680,15 +1682,14 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // columns of the step's 128); one block-scaled MFMA per fragment pair.  t_lo = index of the step in the walk, (lg, lkk,
   // lj) = its group / 128-column chunk / offset.  Scales: the weight rows' from the SCB ring (one dword per 64-row half),
   // the activation rows' from the group's slab - byte 2 lkk + (fr_g >> 1) of the row (one scale per 64 columns).
-  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj) __attribute__((always_inline)) {
+  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj, const int slab) __attribute__((always_inline)) {
     if constexpr (MX2) {
       const char* sc = smem + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + (col_w >> 6) * 256 + (fr_i * 4 + fr_g) * 4;
       int ws_lo[WW];
 #pragma unroll
       for (int h = 0; h < WW; ++h) ws_lo[h] = *(const int*)(sc + h * 256);
-      const int bi = 2 * lkk + (fr_g >> 1);
-      const uint8_t* sl = (const uint8_t*)smem + SLB + ((lg - a.ngrp) & 1) * SLAB_BYTES +
-                          ((bi >> 2) * SLAB_ROWS + row_w + fr_i + lj * a.grp[lg].dstep) * 4 + (bi & 3);
+      const uint8_t* sl = (const uint8_t*)smem + SLB + slab * SLAB_BYTES + (row_w + fr_i + lj * a.grp[lg].dstep) * 4 +
+                          2 * (lkk & 1) + (fr_g >> 1);
       int xs_lo = 0;
 #pragma unroll
       for (int i = 0; i < XF; ++i) xs_lo |= (int)sl[i * 64] << (8 * i);
@@ -1768,6 +1769,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     xs_reload = false;
     force_x = true;
     force_slab = MX2 && kb >= SH;
+    islab = rslab = 0;
     n_steps = ke - kb;
     n_hi = kb >= SH ? 0 : (ke < SH ? ke : SH) - kb;
     if (EPI != kEpiSplitK && kind != 1 && wave < (a.bn ? 6 : 2)) {
@@ -1872,11 +1874,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
         for (int j = ns_hi; j < ns; ++j, ++rstep) {   // the second walk: one 128-column step = 32 block-scaled MFMAs
           __builtin_amdgcn_s_setprio(1);
           const int lg = rg, lkk = rkk, lj = rj;
+          if ((lj == 0 && (lkk & 1) == 0) || (j == ns_hi && ns_hi == 0)) ++rslab;   // the rule of issue_step
           read_step(f);
           const int n = (j + 2 < ns) ? issue_step() : 0;
           wait_and_barrier(n);
           __builtin_amdgcn_s_setprio(0);
-          lo_mfmas(f, rstep - SH, lg, lkk, lj);
+          lo_mfmas(f, rstep - SH, lg, lkk, lj, (rslab - 1) % 3);
           plain_barrier();
         }
       }
@@ -2007,7 +2010,7 @@ unsigned sk_last_error() {
 // True when the stream-K variant with MF fragments per wave can run this launch.
 template <int PREC, int MF>
 static bool sk_applicable(const GemmArgs& a) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536 + (PrecMx2(PREC) ? 2 * (64 * MF + 16) * 8 : 0);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536 + (PrecMx2(PREC) ? 3 * (64 * MF + 16) * 4 : 0);
   if (lds > 160 * 1024) return false;
   const int rows = a.m_tiles * kBM;
   if (rows % (64 * MF)) return false;
@@ -2019,7 +2022,7 @@ static bool sk_applicable(const GemmArgs& a) {
 
 template <int PREC, int EPI, int MF>
 static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536 + (PrecMx2(PREC) ? 2 * (64 * MF + 16) * 8 : 0);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (64 * MF + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + 1536 + 2 * 1536 + (PrecMx2(PREC) ? 3 * (64 * MF + 16) * 4 : 0);
   if constexpr (lds > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {
@@ -2061,7 +2064,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 1536 : 0) + (PrecMx2(PREC) ? 2 * (256 + 16) * 8 : 0);
+  constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 1536 : 0) + (PrecMx2(PREC) ? 3 * (256 + 16) * 4 : 0);
   static std::atomic<unsigned long long> attr_done{0};
   int attr_dev = 0;
   if (lds_attr_needed(&attr_done, &attr_dev)) {

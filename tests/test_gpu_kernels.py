@@ -444,8 +444,12 @@ def test_gemm_mx_refuses_unsuitable_launch():
         _run_mx_case(0, 768, 512, [(0, 64, 0, 64), (1, 64, 0, 64)], seed=1)
 
 
+AM_MX = [(0, 768, -3, 768), (0, 768, 0, 768), (0, 768, 3, 768)]     # phonetic branch: 650-wide sources padded to 768
+CVEC5_ODD = [(0, 512, 0, 512), (1, 128, 0, 128), (2, 384, 0, 384)]   # an odd number of 128-column chunks per source
+
+
 @pytest.mark.parametrize("epi", [0, 2])
-@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX, [(0, 512, 0, 512)]], ids=["tdnn3", "cvec5", "tdnn4"])
+@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX, [(0, 512, 0, 512)], AM_MX, CVEC5_ODD], ids=["tdnn3", "cvec5", "tdnn4", "am768", "odd"])
 def test_gemm_mx2_stream_k(epi, segs):
     """XV_PREC_FP16MX2 on the persistent kernel: the second K walk (4-bit residual of the activations x 4-bit image of the
     weights) against an exact emulation of both 4-bit products; parts cut inside both walks."""
@@ -458,7 +462,7 @@ def test_gemm_mx2_stream_k(epi, segs):
 
 
 @pytest.mark.parametrize("epi", [0, 2])
-@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX], ids=["tdnn3", "cvec5"])
+@pytest.mark.parametrize("segs", [TDNN3, CVEC5_MX, AM_MX, CVEC5_ODD], ids=["tdnn3", "cvec5", "am768", "odd"])
 def test_gemm_mx2_per_tile_kernel(epi, segs):
     # 3 x 256 rows: too few tiles for the persistent grid -> the 256-row per-tile kernel
     out, ref = _run_mx_case(epi, 768, 512, segs, seed=19, prec=7)

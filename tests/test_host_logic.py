@@ -66,16 +66,18 @@ def test_binary_and_text_models_pack_identically():
 
 
 def test_split_fp16_modes_share_one_weight_image_scaled_by_a_power_of_two():
-    """fp16x3 / fp16x2 / auto are kernel policies over the same packed weights: fp16 hi + lo planes of W * 2^S, S chosen so
-    that max |w| * 2^S lies in [2^13, 2^14) (the residual plane then holds fp16 normals); the exact inverse sits in the
-    epilogue parameters (bias * 2^S, scale * 2^-S)."""
+    """fp16x3 / fp16x2 are kernel policies over the same packed weights: fp16 hi + lo planes of W * 2^S, S chosen so that
+    max |w| * 2^S lies in [2^13, 2^14) (the residual plane then holds fp16 normals); the exact inverse sits in the
+    epilogue parameters (bias * 2^S, scale * 2^-S).  (The modes with 4-bit products - auto, fp16mx, fp16mx2 - hold the same
+    values with the K of inter-layer sources padded to blocks of 128 columns, plus their 4-bit planes.)"""
     net = H.nm.synthesize(H.tiny_config(), seed=3)
     m = P.Model(raw=net.to_bytes(True))
-    blobs = [m.pack(p) for p in (P.PREC_FP16X3, P.PREC_FP16X2, P.PREC_AUTO)]
+    blobs = [m.pack(p) for p in (P.PREC_FP16X3, P.PREC_FP16X2)]
     assert len(set(len(b) for b in blobs)) == 1
     # identical up to the precision field of the header
-    diff = [i for i in range(len(blobs[0])) if blobs[0][i] != blobs[2][i]]
+    diff = [i for i in range(len(blobs[0])) if blobs[0][i] != blobs[1][i]]
     assert 0 < len(diff) <= 4
+    assert len(m.pack(P.PREC_AUTO)) >= len(blobs[0]) and len(m.pack(P.PRECISIONS["fp16mx2"])) >= len(blobs[0])
     w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12 x 12
     scale = 2.0 ** (14 - np.frexp(np.abs(w).max())[1])
     assert 2 ** 13 <= np.abs(w).max() * scale < 2 ** 14
