@@ -1,3 +1,6 @@
+"""GPU box: embedding error of fp16mx2 / fp16mx / fp16x3 against the fp64 oracle on three models (Kaldi-initialisation-like,
+two heavy-tailed BatchNorm-calibrated ones) over chunk lengths 25 .. 400, and solo == batched for the first chunk.
+usage: python tools/check_mx2.py"""
 import sys, os
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
