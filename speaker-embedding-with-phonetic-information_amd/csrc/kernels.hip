@@ -273,7 +273,7 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
 // workgroup tile's columns, ncol0 = first column of the 64 x 64 block inside the tile.  (Fetched from global memory
 // right before use - the stream-K kernel has no registers to hold them through the K loop - every block's epilogue
 // started with a full load latency behind the next part's DMA: -6 % on the whole forward pass.)
-template <int EPI>
+template <int EPI, bool LAZY = false>
 __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const float* par, const int mbase, const int ncol0,
                                                       const int lane, EpiRegs& e) {
   const int fr_i = lane & 15;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
   if constexpr (EPI == kEpiAct || EPI == kEpiF32) {
     const int ncol = ncol0 + fr_g * 8;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < (LAZY ? 0 : 4); ++p) {
       const int c = ncol + (p >> 1) * 32 + (p & 1) * 4;
       const f32x4 b4 = *(const f32x4*)(par + c);
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, o4 = {0.f, 0.f, 0.f, 0.f};
@@ -326,9 +326,13 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
 // gm / gm_phase (planes epilogue with a.gmax_out): lane-local maxima of |y| per 16-row group q carried between calls that
 // cover the same rows - phase 0: this call stands alone; 1: first of two (accumulate only); 2: second (accumulate, then
 // reduce over the wave and publish).
-template <int PREC, int EPI>
+// LAZY (planes / f32 epilogues of the stream-K kernel): bias / scale / offset are not taken from e but read from the copy
+// of the tile's parameters in LDS (par, pcol = first column of the block inside the tile) where they are used, four
+// columns at a time, again for every 16-row group: 48 registers less next to the 128 accumulators of a 64 x 128 wave tile.
+template <int PREC, int EPI, bool LAZY = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], const int mbase, const int nbase,
-                                              const int lane, const EpiRegs& e, float (&gm)[4], const int gm_phase) {
+                                              const int lane, const EpiRegs& e, float (&gm)[4], const int gm_phase,
+                                              const float* par = nullptr, const int pcol = 0) {
   constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
   constexpr bool F16 = PrecF16(PREC);
   const int fr_i = lane & 15;
@@ -357,13 +361,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       const int row = mbase + q * 16 + fr_i;
       float y[16];
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < 4; ++p) {
+        f32x4 b4, s4 = {1.f, 1.f, 1.f, 1.f}, o4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LAZY) {
+          int c = pcol + fr_g * 8 + (p >> 1) * 32 + (p & 1) * 4;
+          asm volatile("" : "+v"(c));   // keeps the reads inside the loop over q (hoisted they are 48 live registers again)
+          b4 = *(const f32x4*)(par + c);
+          if (a.bn) {
+            s4 = *(const f32x4*)(par + 128 + c);
+            o4 = *(const f32x4*)(par + 256 + c);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            b4[r] = e.bs[p * 4 + r];
+            s4[r] = e.sc[p * 4 + r];
+            o4[r] = e.of[p * 4 + r];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + e.bs[p * 4 + r];
+          float z = acc[p][q][r] + b4[r];
           z = (z < relu_floor) ? relu_floor : z;   // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
-          y[p * 4 + r] = __builtin_fmaf(z, e.sc[p * 4 + r], e.of[p * 4 + r]);   // scale 1 / offset 0 without BatchNorm
+          y[p * 4 + r] = __builtin_fmaf(z, s4[r], o4[r]);   // scale 1 / offset 0 without BatchNorm
         }
+      }
       if constexpr (EPI == kEpiF32) {
         if (row < a.m_valid) {
           float* dst = a.out_f32 + (long)row * a.ldf + ncol;
@@ -1925,9 +1947,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
         float gm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
+          constexpr bool LAZY = (EPI == kEpiAct || EPI == kEpiF32) && MX;   // where the registers are short (spills)
           EpiRegs er;
-          epilogue_prefetch_lds<EPI>(a, e_par, e_m0 + row_w, h * 64, lane, er);
-          gemm_epilogue<PREC, EPI>(a, acc[h], e_m0 + row_w, e_n0 + h * 64, lane, er, gm, h == 0 ? 1 : 2);
+          epilogue_prefetch_lds<EPI, LAZY>(a, e_par, e_m0 + row_w, h * 64, lane, er);
+          gemm_epilogue<PREC, EPI, LAZY>(a, acc[h], e_m0 + row_w, e_n0 + h * 64, lane, er, gm, h == 0 ? 1 : 2, e_par, h * 64);
         }
       } else {
         EpiRegs er;
