@@ -33,6 +33,11 @@ typedef enum {
 } xv_status;
 
 typedef enum {
+  XV_PREC_DEFAULT = -1, /* the policy of the command-line tools, and what every entry point of this library defaults to:
+                          XV_PREC_FP16MX2 for a pooled (x-vector) output whose layers can all run it, XV_PREC_FP16X3
+                          otherwise (a layer the 4-bit walk cannot cover, frame-level outputs).  Never an opt-in mode:
+                          the arithmetic it picks meets the parity bar on every model tried, heavy-tailed ones included
+                          (DESIGN.md section 3.0).  xv_ctx_info reports the mode that was chosen */
   XV_PREC_BF16X3 = 0,  /* split-bf16 MFMA (3 products, fp32 accumulate): fp32-grade, the first version's parity mode */
   XV_PREC_BF16 = 1,    /* single-pass bf16 MFMA */
   XV_PREC_FP16 = 2,    /* single-pass fp16 MFMA */

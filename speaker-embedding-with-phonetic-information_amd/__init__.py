@@ -19,7 +19,8 @@ BIN_DIR = os.path.join(_HERE, "bin")
 XV_OK = 0
 XV_ERR_IO, XV_ERR_MODEL, XV_ERR_DEVICE, XV_ERR_ARG, XV_ERR_INTERNAL = 1, 2, 3, 4, 5
 PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO, PREC_FP16MX, PREC_FP16MX2, PREC_FP16X3E = range(9)
-PRECISIONS = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3,
+PREC_DEFAULT = -1   # XV_PREC_DEFAULT: the one policy of every entry point (fp16mx2 where the model allows, else fp16x3)
+PRECISIONS = {"default": PREC_DEFAULT, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3,
               "fp16x2": PREC_FP16X2, "auto": PREC_AUTO, "fp16mx": PREC_FP16MX, "fp16mx2": PREC_FP16MX2}
 # MFMA issue time per algorithmic product in units of one fp16 16x16x32 pass (fp16mx: + one 4-bit 16x16x128 per four)
 MFMA_PASSES = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25}
@@ -185,7 +186,7 @@ class Model:
         lib().xv_model_describe(self._h, buf, n)
         return buf.value.decode()
 
-    def pack(self, precision=PREC_AUTO):
+    def pack(self, precision=PREC_DEFAULT):
         n = ctypes.c_size_t(0)
         _check(lib().xv_model_pack(self._h, precision, None, ctypes.byref(n)))
         buf = ctypes.create_string_buffer(n.value)
@@ -196,7 +197,7 @@ class Model:
 class Context:
     """Weights resident on one MI355X + workspaces.  Raises XvError(XV_ERR_DEVICE) without a gfx950 GPU."""
 
-    def __init__(self, model=None, blob=None, device=0, precision=PREC_AUTO, device_blob=None):
+    def __init__(self, model=None, blob=None, device=0, precision=PREC_DEFAULT, device_blob=None):
         """device_blob = (device pointer as int, nbytes): the packed image already in this GPU's memory (e.g. the
         buffer a RCCL broadcast filled); the weights then never visit the host."""
         L = lib()
@@ -295,7 +296,7 @@ class Context:
         return out, ok.astype(bool)
 
 
-def create_broadcast(model, devices, precision=PREC_AUTO):
+def create_broadcast(model, devices, precision=PREC_DEFAULT):
     """xv_ctx_create_broadcast: one process, one context per listed GPU; the packed weights are uploaded to the first
     device and broadcast with ONE ncclBroadcast (RCCL), each context is built from the image its device received."""
     L = lib()

@@ -131,7 +131,7 @@ size_t xv_model_describe(const xv_model* m, char* buf, size_t n) {
 xv_status xv_model_pack(const xv_model* m, int precision, void* blob, size_t* nbytes) {
   if (!m || !nbytes) return Fail(XV_ERR_ARG, "xv_model_pack: null argument");
   return Guard([&] {
-    std::vector<uint8_t> b = xv::PackModel(m->prog, precision);
+    std::vector<uint8_t> b = xv::PackModelPolicy(m->prog, precision);
     if (blob) {
       if (*nbytes < b.size()) return Fail(XV_ERR_ARG, "xv_model_pack: buffer too small");
       memcpy(blob, b.data(), b.size());
@@ -144,7 +144,7 @@ xv_status xv_model_pack(const xv_model* m, int precision, void* blob, size_t* nb
 xv_status xv_ctx_create(const xv_model* m, int device, int precision, xv_ctx** out) {
   if (!m || !out) return Fail(XV_ERR_ARG, "xv_ctx_create: null argument");
   return Guard([&] {
-    std::vector<uint8_t> b = xv::PackModel(m->prog, precision);
+    std::vector<uint8_t> b = xv::PackModelPolicy(m->prog, precision);
     std::unique_ptr<xv_ctx> c(new xv_ctx);
     c->eng.reset(new xv::Engine(b.data(), b.size(), device));
     *out = c.release();
@@ -356,7 +356,7 @@ xv_status xv_segment_mean(int device, const float* x, int32_t n, int32_t dim, co
 xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, int precision, xv_ctx** out) {
   if (!m || !devices || !out || n < 1) return Fail(XV_ERR_ARG, "xv_ctx_create_broadcast: bad argument");
   return Guard([&]() -> xv_status {
-    std::vector<uint8_t> blob = xv::PackModel(m->prog, precision);
+    std::vector<uint8_t> blob = xv::PackModelPolicy(m->prog, precision);
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!lib) return Fail(XV_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());

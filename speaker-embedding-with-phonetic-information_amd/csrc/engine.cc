@@ -351,6 +351,29 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
   return blob;
 }
 
+const char* PrecisionName(int precision) {
+  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e"};
+  return precision == kPrecDefault ? "default" : (precision >= 0 && precision <= 8) ? n[precision] : "?";
+}
+
+std::vector<uint8_t> PackModelPolicy(const TdnnProgram& prog, int precision, int* resolved) {
+  int p = precision;
+  std::vector<uint8_t> blob;
+  if (precision == kPrecDefault) {
+    p = prog.output_is_segment ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3;
+    if (p == kPrecFp16Mx2) {
+      try {
+        blob = PackModel(prog, p);
+      } catch (const EngineError&) {   // a layer the second K walk cannot cover: the fp32-grade three-pass mode
+        p = kPrecFp16x3;
+      }
+    }
+  }
+  if (blob.empty()) blob = PackModel(prog, p);
+  if (resolved) *resolved = p;
+  return blob;
+}
+
 std::vector<uint8_t> ReadBlobHead(const void* device_blob, size_t n) {
   if (n < sizeof(BlobHeader)) throw EngineError("model blob too small");
   BlobHeader h;
@@ -578,6 +601,8 @@ Engine::~Engine() {
     for (ActBuf& a : L.act) {
       fr(a.act_hi);
       fr(a.act_lo);
+      fr(a.act_lo4);
+      fr(a.act_lo4s);
     }
     fr(L.in_hi);
     fr(L.in_lo);
@@ -1256,8 +1281,12 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
 
 void Engine::CheckKernelFaults() const {
   // a stream-K workgroup that gave up waiting for another workgroup's partial tile (bounded spin, kernels.hip) left
-  // this word behind; the results of that launch are not to be trusted
-  if (sk_last_error())
+  // a word behind on its launch stream; the results of that launch are not to be trusted.  The word belongs to the
+  // stream, i.e. to this engine, and reading it clears it: the caller may retry (XVEC_GEMM_VARIANT=2) or exit cleanly
+  (void)hipSetDevice(device_);
+  unsigned err = sk_take_error(stream_);
+  for (const Lane& L : lanes_) err |= sk_take_error(L.stream);
+  if (err)
     throw EngineError("a stream-K GEMM launch timed out waiting for a partial tile of another workgroup (results invalid); "
                       "XVEC_GEMM_VARIANT=2 selects the per-tile kernels");
 }
@@ -1267,8 +1296,8 @@ const float* Engine::WaitHost(int slot) {
   HostSlot& S = host_slots_[slot];
   if (!S.pending) throw EngineError("WaitHost: nothing submitted on this slot");
   Check(hipEventSynchronize(S.done), "hipEventSynchronize(slot)");
+  S.pending = false;   // before the fault check: the slot is free again whatever the launch reported
   CheckKernelFaults();
-  S.pending = false;
   return (const float*)S.h_out;
 }
 

@@ -26,6 +26,12 @@ struct EngineError : public std::runtime_error {
 // Flat, position-independent image of a lowered + padded + precision-split model.  This is what one
 // rank broadcasts to the others over RCCL and what an Engine is built from.
 std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision);
+// The same with precision kPrecDefault (-1, XV_PREC_DEFAULT) resolved by the one policy every entry point shares (C ABI,
+// command-line tools, Python host, multi-GPU launcher): kPrecFp16Mx2 for a pooled output whose layers can all run it,
+// kPrecFp16x3 where PackModel rejects that mode for the model and for frame-level outputs.  *resolved = the mode packed.
+constexpr int kPrecDefault = -1;
+std::vector<uint8_t> PackModelPolicy(const TdnnProgram& prog, int precision, int* resolved = nullptr);
+const char* PrecisionName(int precision);   // "fp16mx2", ...; "?" for an unknown value
 
 // kPrecFp16Mx: e2m1 image of one row of weight residuals res[k_pad] (K-contiguous, padded like the fp16 planes) in the
 // order the kernels walk the K steps (step_wcol from PlanWalkSteps, kernels.h), with one E8M0 scale per block of four

@@ -234,7 +234,7 @@ struct GemmArgs {
   float* sk_ws;
   unsigned* sk_flags;
   unsigned sk_epoch;
-  unsigned* sk_error;    // host-mapped word: receives sk_epoch when a flag wait timed out (see sk_last_error)
+  unsigned* sk_error;    // host-mapped word: of the launch stream: receives sk_epoch when a flag wait timed out (see sk_take_error)
 };
 
 // Arms a (start, stop) event pair for the kernels of the NEXT launch_* call of this thread (profiling; see kernels.hip).
@@ -251,10 +251,12 @@ const char* last_gemm_kernel();
 bool gemm_mx_applicable(const GemmArgs& a);
 bool gemm_mx2_applicable(const GemmArgs& a);   // kPrecFp16Mx2: also the 4-bit planes, sources of whole 128-column steps
 // Stream-K workspace (partial-tile exchange) of a stream: allocated on first use, released by the owner of the
-// stream before it destroys it (Engine::~Engine).  sk_last_error: non-zero once any stream-K launch of this process
-// timed out waiting for another workgroup's partial tile (checked by the engine after it synchronises).
+// stream before it destroys it (Engine::~Engine).  sk_take_error: non-zero when a stream-K launch on stream s (of the
+// current device) timed out waiting for another workgroup's partial tile since the last call; the word is per stream and
+// is cleared by the call, so one engine's fault neither poisons the others nor repeats (checked by the engine after it
+// synchronises the stream).
 void release_stream_workspace(hipStream_t s);
-unsigned sk_last_error();
+unsigned sk_take_error(hipStream_t s);
 
 // fp32 packed features [src rows][dim] -> 16-bit planes [dev rows][ld] (zero padded columns,
 // zero rows for alignment padding).  grp_utt[g] = utterance of 16-row group g or -1.

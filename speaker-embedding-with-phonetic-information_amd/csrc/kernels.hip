@@ -1968,17 +1968,18 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
 struct SkWorkspace {
   float* ws = nullptr;
   unsigned* flags = nullptr;
+  unsigned* error = nullptr;   // pinned host word, device-visible: receives the epoch of a launch on THIS stream whose flag wait timed out
   size_t ws_bytes = 0;
   int grid = 0;
 };
 static std::mutex g_sk_mu;
 static std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk_table;
 static unsigned g_sk_epoch = 0;
-static unsigned* g_sk_error = nullptr;   // pinned host word, device-visible: written by a kernel whose flag wait timed out
 
 static void sk_free(SkWorkspace* w) {
   if (w->ws) (void)hipFree(w->ws);
   if (w->flags) (void)hipFree(w->flags);
+  if (w->error) (void)hipHostFree(w->error);
   *w = SkWorkspace();
 }
 
@@ -1987,14 +1988,17 @@ static hipError_t sk_workspace(hipStream_t s, int grid, size_t ws_bytes, SkWorks
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (!g_sk_error) {
-    if ((e = hipHostMalloc((void**)&g_sk_error, 64, hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess) return e;
-    *g_sk_error = 0;
-  }
   SkWorkspace& w = g_sk_table[std::make_pair(dev, s)];
   if (w.ws_bytes < ws_bytes || w.grid < grid) {
     // (re)allocation: only ever on the first launches of a stream; hipFree synchronises the device
+    unsigned* keep_error = w.error;   // the error word of a stream survives a regrown workspace
+    w.error = nullptr;
     sk_free(&w);
+    w.error = keep_error;
+    if (!w.error) {
+      if ((e = hipHostMalloc((void**)&w.error, 64, hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess) return e;
+      *w.error = 0;
+    }
     // fine-grained = coherent across the XCDs' L2s without cache maintenance (the exchange happens inside a kernel)
     if ((e = hipExtMallocWithFlags((void**)&w.ws, ws_bytes, hipDeviceMallocFinegrained)) != hipSuccess) {
       sk_free(&w);
@@ -2010,7 +2014,7 @@ static hipError_t sk_workspace(hipStream_t s, int grid, size_t ws_bytes, SkWorks
   }
   if (++g_sk_epoch == 0) ++g_sk_epoch;   // 0 is the cleared state
   *epoch = g_sk_epoch;
-  *err = g_sk_error;
+  *err = w.error;
   *out = w;
   return hipSuccess;
 }
@@ -2025,9 +2029,16 @@ void release_stream_workspace(hipStream_t s) {
   g_sk_table.erase(it);
 }
 
-unsigned sk_last_error() {
+unsigned sk_take_error(hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_sk_mu);
-  return g_sk_error ? *(volatile unsigned*)g_sk_error : 0u;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0u;
+  auto it = g_sk_table.find(std::make_pair(dev, s));
+  if (it == g_sk_table.end() || !it->second.error) return 0u;
+  volatile unsigned* w = it->second.error;
+  const unsigned v = *w;
+  if (v) *w = 0u;   // reported once: later launches on the stream start clean
+  return v;
 }
 
 // True when the stream-K variant with MF fragments per wave can run this launch.

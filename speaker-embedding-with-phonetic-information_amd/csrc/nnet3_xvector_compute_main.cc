@@ -281,12 +281,12 @@ int main(int argc, char** argv) {
     }
     const std::string nnet_rx = pos[0], feat_rspec = pos[1], vec_wspec = pos[2];
 
-    // default: fp16mx2 (1.5 MFMA passes, 3-5.5e-5 from the fp32 oracle on every model tried, the heavy-tailed ones included)
-    // for pooled outputs where every layer can run it, else fp16x3 (fp32-grade, three passes); frame-level outputs: fp16x3
-    const bool default_precision = opt.precision == "default";
-    if (default_precision) opt.precision = g_frame_job ? "fp16x3" : "fp16mx2";
+    // default: the library's one policy (XV_PREC_DEFAULT, engine.cc PackModelPolicy): fp16mx2 (1.5 MFMA passes, 3-5.5e-5 from
+    // the fp32 oracle on every model tried, the heavy-tailed ones included) for pooled outputs where every layer can run
+    // it, else fp16x3 (fp32-grade, three passes); frame-level outputs: fp16x3
     int precision;
-    if (opt.precision == "bf16x3") precision = xv::kPrecBf16x3;
+    if (opt.precision == "default") precision = xv::kPrecDefault;
+    else if (opt.precision == "bf16x3") precision = xv::kPrecBf16x3;
     else if (opt.precision == "bf16") precision = xv::kPrecBf16;
     else if (opt.precision == "fp16") precision = xv::kPrecFp16;
     else if (opt.precision == "fp16x3") precision = xv::kPrecFp16x3;
@@ -332,16 +332,8 @@ int main(int argc, char** argv) {
     }
     if (device >= ndev) device %= ndev;
     if (opt.fast_min_pooled >= 0) setenv("XVEC_FAST_MIN_POOLED", std::to_string(opt.fast_min_pooled).c_str(), 1);   // read by the engine
-    std::vector<uint8_t> blob;
-    try {
-      blob = xv::PackModel(prog, precision);
-    } catch (const xv::EngineError& e) {
-      if (!default_precision || precision != xv::kPrecFp16Mx2) throw;
-      XLOG(e.what() << ": using --precision=fp16x3");
-      opt.precision = "fp16x3";
-      precision = xv::kPrecFp16x3;
-      blob = xv::PackModel(prog, precision);
-    }
+    const std::vector<uint8_t> blob = xv::PackModelPolicy(prog, precision, &precision);
+    if (opt.precision == "default") opt.precision = std::string("default = ") + xv::PrecisionName(precision);
     xv::Engine engine(blob.data(), blob.size(), device);
     XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "

@@ -49,7 +49,13 @@ def main(argv=None):
     ap.add_argument("--chunk-size", type=int, default=-1)
     ap.add_argument("--min-chunk-size", type=int, default=100)
     ap.add_argument("--pad-input", default="true")
-    ap.add_argument("--precision", default="auto", choices=["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "fp16mx2", "auto"])
+    ap.add_argument("--precision", default="default",
+                    choices=["default", "bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "fp16mx2", "auto"],
+                    help="default = the policy of nnet3-xvector-compute (XV_PREC_DEFAULT): fp16mx2 where every layer can run it, "
+                         "else fp16x3; the others are opt-in")
+    ap.add_argument("--force-device", type=int, default=None,
+                    help="HIP device every rank uses instead of LOCAL_RANK (ranks sharing one GPU: the recipes' nj > #GPUs "
+                         "launch mode, and how the N > 1 path is exercised on a one-GPU box with --backend gloo)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-run", action="store_true", help="shard + broadcast only (no device; used by CPU tests)")
     args = ap.parse_args(argv)
@@ -62,6 +68,8 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.force_device is not None:
+        local_rank = args.force_device
     use_cuda = args.backend == "nccl"
     if use_cuda:
         torch.cuda.set_device(local_rank)

@@ -150,14 +150,19 @@ def test_trained_like_model_needs_the_three_pass_mode(seed):
     assert errs["auto"] > 2e-5                                      # the fast kernels really ran
 
 
-@pytest.mark.parametrize("which", ["init_123", "trained_11", "trained_12"])
+@pytest.mark.parametrize("which", ["init_123", "trained_11", "trained_12", "v5_trained_11"])
 def test_fp16mx2_is_model_independent(which):
     """XV_PREC_FP16MX2 corrects the fp16 rounding of the activations with a 4-bit residual plane (1.5 MFMA passes per
     product): on the heavy-tailed, BatchNorm-calibrated models where the one-plane modes land at 1.2 - 1.7e-4 it stays
     below 6e-5 at every chunk length (chunks that pool fewer than 100 frames take the three-pass arithmetic), and a
     chunk's embedding does not depend on its neighbours in the batch."""
     P = H.pkg()
-    net, line = H.synth_model("v2_xvector", 123) if which == "init_123" else H.trained_like_model("v2_xvector", int(which[-2:]))
+    if which == "init_123":
+        net, line = H.synth_model("v2_xvector", 123)
+    elif which.startswith("v5_"):   # the c-vector network (phonetic branch, two-source Append: train_cvector_with_am.sh:65-89)
+        net, line = H.trained_like_model("v5_cvector", int(which[-2:]))
+    else:
+        net, line = H.trained_like_model("v2_xvector", int(which[-2:]))
     model = P.Model(raw=net.to_bytes(True), nnet_config=line)
     ev64 = _oracle(net, line, np.float64)
     lens = [400, 137, 400, 314, 60, 400, 25, 200, 115, 400]
@@ -303,18 +308,50 @@ def test_context_from_packed_blob_is_identical(v2):
     assert np.array_equal(a.forward_batch(x, [0, 400]), b.forward_batch(x, [0, 400]))
 
 
-def test_full_size_batch_properties(v2):
-    """BASELINE config 2 size (256 chunks x 400 frames): size-independent properties instead of a slow oracle run:
-    every row equals the row computed alone (spot-checked), identical inputs give identical outputs, and a
-    sample is checked against the oracle."""
-    P, net, line, model = v2
-    ctx = P.Context(model, precision=P.PREC_BF16X3)
-    pool = [H.features(1000 + i, 400) for i in range(8)]
-    utts = [pool[i % 8] for i in range(256)]
+def _kernels_that_ran(ctx, feats, offs):
+    """Names of the GEMM instantiations one forward pass launches (engine profile labels: `tdnn_gemm<act>:tdnn2.batchnorm
+    tdnn_gemm_kernel_sk<fp16mx2,act,8>`)."""
+    ctx.set_profiling(True)
+    ctx.forward_batch(feats, offs)
+    rep = ctx.profile_report()
+    ctx.set_profiling(False)
+    return " ".join(l for (l, _, _) in rep)
+
+
+@pytest.mark.parametrize("topology,mode", [("v2_xvector", "bf16x3"), ("v2_xvector", "default"), ("v2_xvector", "auto"),
+                                           ("v5_cvector", "default"), ("v5_cvector", "auto")])
+def test_full_size_batch_properties(topology, mode):
+    """BASELINE configs 2 and 3 at full size (256 chunks x 400 frames, v2 x-vector and v5 c-vector), in the arithmetic
+    that ships (`default` = XV_PREC_DEFAULT -> fp16mx2) and in the opt-in fast mode (`auto` -> fp16mx), plus the
+    three-pass reference mode: size-independent properties instead of a slow oracle run -
+      * identical inputs give identical outputs wherever they sit in the batch (32 distinct chunks, each 8 times);
+      * every distinct chunk computed ALONE gives the same bits as inside the full batch (the stream-K kernels of the
+        full batch against the per-tile kernels of a one-chunk launch);
+      * 8 rows are checked against the fp64 oracle at the parity tolerance;
+      * the profile report proves that the stream-K instantiation of the mode under test really ran."""
+    P = H.pkg()
+    net, line = H.synth_model(topology)
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    ctx = P.Context(model, precision=P.PRECISIONS[mode])
+    pool = [H.features(1000 + i, 400) for i in range(32)]
+    utts = [pool[i % 32] for i in range(256)]
     feats, offs = H.pack(utts)
     out = ctx.forward_batch(feats, offs)
-    for i in range(8, 256):
-        assert np.array_equal(out[i], out[i % 8])
-    ev32 = _oracle(net, line, np.float32)
-    ref = np.stack([ev32.compute(pool[i])[0] for i in range(2)])
-    assert H.rel_err(out[:2], ref) < TOL_PARITY
+    assert np.all(np.isfinite(out))
+    for i in range(32, 256):
+        assert np.array_equal(out[i], out[i % 32]), i
+    for i in (0, 5, 31):
+        solo = ctx.forward_batch(*H.pack(pool[i:i + 1]))
+        assert np.array_equal(solo[0], out[i]), i
+    ev64 = _oracle(net, line, np.float64)
+    ref = np.stack([ev64.compute(pool[i])[0] for i in range(8)])
+    errs = [H.rel_err(out[i:i + 1], ref[i:i + 1]) for i in range(8)]
+    print("%s %s at 256 x 400: max %.2e mean %.2e" % (topology, mode, max(errs), float(np.mean(errs))))
+    assert max(errs) < TOL_PARITY, errs
+    ran = _kernels_that_ran(ctx, feats, offs)
+    want = {"bf16x3": "bf16x3", "default": "fp16mx2", "auto": "fp16mx"}[mode]
+    assert ("tdnn_gemm_kernel_sk<%s,act,8>" % want) in ran or mode == "bf16x3", ran
+    assert ("<%s," % want) in ran, ran
+    if mode == "default":
+        assert ctx.precision == P.PREC_FP16MX2
+        assert "tdnn_gemm_kernel_sk<fp16mx2,stats,8>" in ran, ran

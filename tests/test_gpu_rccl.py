@@ -77,3 +77,92 @@ def test_dist_extract_nccl_one_rank(tmp_path):
     for k, x in utts:
         ref = H.xo.extract_xvector(ev, x, 10000, 25, True)
         assert H.rel_err(got[k][None], ref[None]) < 1e-4, k
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_dist_extract(tmp_path, nproc, out_name, extra):
+    out = tmp_path / out_name
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(H.ROOT, H.PKG_NAME, "dist_extract.py"),
+           "--nnet", str(tmp_path / "final.raw"), "--output-node", "tdnn6.affine", "--feats-scp", str(tmp_path / "feats.scp"),
+           "--out-dir", str(out), "--name", "t", "--min-chunk-size", "25", "--chunk-size", "10000"] + extra
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    return out, r.stdout
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank_byte_for_byte(tmp_path):
+    """Shard equivalence with real compute at N > 1 ("outputs of N-way sharded run == 1-way run,
+    bit-for-bit per utterance"; sharding rule utils/split_scp.pl:208-217, concatenation
+    egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:99): dist_extract.py with two ranks that share device 0
+    (gloo carries the weight broadcast; the launcher starts before any GPU call) against a one-rank run of the same
+    job.  The merged scp must list the same keys in the same order and every vector must be byte-identical - no
+    utterance's embedding may depend on which rank, batch or neighbours it was computed with."""
+    net, _ = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    lens = [400, 137, 25, 333, 1000, 64, 400, 400, 211, 15, 399, 640, 87]
+    utts = [("utt%02d" % i, H.features(900 + i, T)) for i, T in enumerate(lens)]
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"))
+    one, log1 = _run_dist_extract(tmp_path, 1, "one", ["--backend", "gloo", "--force-device", "0"])
+    two, log2 = _run_dist_extract(tmp_path, 2, "two", ["--backend", "gloo", "--force-device", "0"])
+    assert "Done 13 utterances, failed for 0 (over 1 ranks)" in log1
+    assert "Done 13 utterances, failed for 0 (over 2 ranks)" in log2
+    k1 = [l.split()[0] for l in open(one / "xvector_t.scp")]
+    k2 = [l.split()[0] for l in open(two / "xvector_t.scp")]
+    assert k1 == k2 == [k for k, _ in utts]
+    # rank shards: 7 + 6, contiguous (split_scp.pl rule), each in its own ark
+    assert [l.split()[0] for l in open(two / "xvector_t.1.scp")] == k1[:7]
+    assert [l.split()[0] for l in open(two / "xvector_t.2.scp")] == k1[7:]
+    v1 = dict(kio.read_scp(str(one / "xvector_t.scp"), "vector"))
+    v2 = dict(kio.read_scp(str(two / "xvector_t.scp"), "vector"))
+    for k in k1:
+        assert v1[k].tobytes() == v2[k].tobytes(), k
+    # the concatenated per-rank arks ARE the one-rank ark (same records, same order)
+    cat = (two / "xvector_t.1.ark").read_bytes() + (two / "xvector_t.2.ark").read_bytes()
+    assert cat == (one / "xvector_t.1.ark").read_bytes()
+
+
+def test_bench_two_ranks_on_one_gpu_prints_one_line():
+    """bench.py's N > 1 path (process group, size + weight broadcast, per-rank context from the broadcast image, barrier +
+    max-over-ranks timing) executed for real: two ranks sharing device 0 over gloo.  The throughput of such a run means
+    nothing; the contract does: exactly one JSON line, from rank 0, with n_gpus = 2."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-extra-modes", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                       env=dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["roofline"]["frac"] > 0 and d["parity_rel_err_vs_oracle_fp32"] < 1e-4
+
+
+def test_ctx_create_broadcast_over_two_devices():
+    """xv_ctx_create_broadcast with n = 2: ncclCommInitAll over two devices, one ncclBroadcast of the packed image over
+    xGMI, one context per GPU built from the image the broadcast left there; both must reproduce xv_ctx_create bit for
+    bit.  Needs two visible GPUs (the test boxes have one: skipped there, runs on the driver's 8-GPU node)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    P = H.pkg()
+    net, line = H.synth_model("v2_xvector")
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    utts = [H.features(i, T) for i, T in enumerate((400, 57, 333))]
+    feats, offs = H.pack(utts)
+    want = P.Context(model).forward_batch(feats, offs)
+    ctxs = P.create_broadcast(model, [0, 1])
+    assert [c.device for c in ctxs] == [0, 1]
+    for c in ctxs:
+        assert np.array_equal(c.forward_batch(feats, offs), want)

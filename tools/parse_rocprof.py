@@ -47,15 +47,16 @@ def main():
                  "counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM; prep_input reads a known 9.42 MB and reports 4.7 MB).", "",
                  "| # | kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes (2*fetch+write) | duration us |", "|---|---|---|---|---|---|"]
         # per kernel instantiation, under the name bench.py's roofline uses (engine profile labels, kernels.hip note_kernel)
-        prec = ["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx"]
-        epi = ["act", "f32", "stats", "splitk"]
+        prec = ["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e"]   # kernels.hip prec_name
+        epi = ["act", "f32", "stats", "splitk", "lsm"]
+        nm = lambda tab, i: tab[int(i)] if int(i) < len(tab) else str(i)   # noqa: E731 - unknown indices keep their number
         by = {}
         for i, ((k, f, us), (_, w, _)) in enumerate(zip(per["FETCH_SIZE"], per["WRITE_SIZE"])):
             b = (2 * f + w) * 1024
             lines.append("| %d | %s | %.1f | %.1f | %.3e | %.1f |" % (i, k, f, w, b, us))
             m = re.search(r"(tdnn_gemm_kernel\w*)<(\d+), (\d+)(?:, (\d+))?>", k)
             if m:
-                name = "%s<%s,%s%s>" % (m.group(1), prec[int(m.group(2))], epi[int(m.group(3))], "," + m.group(4) if m.group(4) else "")
+                name = "%s<%s,%s%s>" % (m.group(1), nm(prec, m.group(2)), nm(epi, m.group(3)), "," + m.group(4) if m.group(4) else "")
                 by.setdefault(name, []).append(b)
         open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
         if by:
