@@ -146,6 +146,11 @@ class Engine {
     const uint8_t* w4b;         // kPrecFp16Mx2
     const uint8_t* w4b_scale;
     int ldw4b;
+    // layers that read only the network input and run tdnn_first_kernel: compact weight planes [n_pad][kFirstK], built on
+    // the device from the packed image at construction (owned: first_buf)
+    bool first = false;
+    const uint16_t* wc_hi = nullptr;
+    const uint16_t* wc_lo = nullptr;
   };
   struct ActBuf {
     Buf act_hi, act_lo;   // frame-level: [halo + rows + halo][n_pad]; segment-level: [b_pad][n_pad]
@@ -213,6 +218,8 @@ class Engine {
   void* d_blob_ = nullptr;
   size_t blob_data_bytes_ = 0;
   std::vector<DevLayer> layers_;
+  std::vector<Buf> first_buf_;     // compact first-layer weight planes (two per such layer)
+  bool need_prep_ = true;          // some layer still reads the input planes prep_input writes
   int in_ld_ = 0;
   int stats_ld_ = 0;
   std::vector<Lane> lanes_;
@@ -231,12 +238,13 @@ struct Engine::Plan {
   std::vector<int32_t> src_off;  // [B+1]
   void* d_tables = nullptr;      // one device allocation holding all tables below (owned unless borrowed)
   bool borrowed_tables = false;  // tables live in a host slot's buffer
-  size_t o_src = 0, o_dev = 0, o_gu = 0, o_gr = 0, o_g0 = 0, o_g1 = 0, o_cn = 0, o_or = 0, o_ar = 0;  // table offsets
+  size_t o_src = 0, o_dev = 0, o_gu = 0, o_gr = 0, o_g0 = 0, o_g1 = 0, o_cn = 0, o_or = 0, o_ar = 0, o_gs = 0;  // table offsets
   int ngrp = 0;                  // 16-row groups of the batch
   const int8_t* d_act_range = nullptr;   // [layer][ngrp][2] computable rows of each group, per layer (kPrecFp16Mx)
   const int32_t* d_src_off = nullptr;
   const int32_t* d_dev_off = nullptr;
   const int32_t* d_grp_utt = nullptr;
+  const void* d_grp_src = nullptr;       // [ngrp] int4: where the frames of each 16-row group come from (kernels.h, FirstArgs)
   const int8_t* d_grp_range = nullptr;
   const int32_t* d_utt_grp0 = nullptr;
   const int32_t* d_utt_grp1 = nullptr;

@@ -258,6 +258,48 @@ bool gemm_mx2_applicable(const GemmArgs& a);   // kPrecFp16Mx2: also the 4-bit p
 void release_stream_workspace(hipStream_t s);
 unsigned sk_take_error(hipStream_t s);
 
+// First layer(s) of the network - every Append() term reads the network INPUT (run_xvector_new.sh:95: tdnn1 over
+// Append(-2,-1,0,1,2) of the 23 MFCCs; train_am.sh:32 the same for the phonetic branch) - as one kernel that replaces
+// prep_input + the generic GEMM: the fp32 feature rows are read where the caller left them (packed utterances ->
+// device rows through the plan's tables, with the edge replication of frame-level outputs), split into fp16 hi / lo in LDS,
+// and multiplied in the three-pass arithmetic against weights that stay in REGISTERS for the whole launch (K is short:
+// noff * dim columns, compacted to noff * roundup(dim, 8) <= 128 - 115 -> 120 instead of the 5 x 32 of the generic walk),
+// so the kernel's only traffic is the planes it writes.  Epilogue = the generic planes epilogue (kernels.hip).
+constexpr int kFirstK = 128;          // compact K of the weight image: k' = j * roundup(dim, 8) + d, zero elsewhere
+constexpr int kFirstRows = 64;        // frames per work unit (x all columns of a 512-column group)
+constexpr int kFirstMaxSlots = 4;     // staged elements per thread and unit
+inline bool FirstLayerApplicable(int dim, int noff, const int* off) {
+  if (noff < 1 || noff > 8 || dim < 1) return false;
+  const int dp = (dim + 7) / 8 * 8;
+  int lo = off[0], hi = off[0];
+  for (int j = 1; j < noff; ++j) {
+    lo = off[j] < lo ? off[j] : lo;
+    hi = off[j] > hi ? off[j] : hi;
+  }
+  return dp <= 32 && noff * dp <= kFirstK && hi - lo <= 30 && (kFirstRows + hi - lo) * dp <= 512 * kFirstMaxSlots;   // dp: LDS
+}
+struct FirstArgs {
+  GemmArgs g;               // the epilogue's side: n_tiles, relu, bn, bias / scale / offset, out_hi / out_lo / out_lo4 / out_lo4s,
+                            // ldo, gmax_out, out_range - all indexed by ABSOLUTE device row (no region shift)
+  const float* feats;       // as PrepArgs
+  // where the frames of every 16-row group come from (built with the plan): {source row of the group's frame 0 before
+  // the edge clamp, frames the chunk holds from there on (replicated edge frames included; 0: the group lies outside every
+  // chunk), source row of the chunk's first frame, of its last frame}
+  const int4* grp_src;
+  int rows;                 // device rows of the batch (extent of the table: rows / 16 groups)
+  int dim;
+  int row0, nrows;          // this launch computes device rows [row0, row0 + nrows), both multiples of 64
+  int noff;
+  int off[8];               // time offsets in Append() order
+  const uint16_t* wc_hi;    // compact weight planes [n_pad][kFirstK] (launch_compact_first)
+  const uint16_t* wc_lo;
+};
+// epi_prec selects what the planes epilogue writes: kPrecFp16x3 / kPrecBf16x3 (hi + lo planes), kPrecFp16x3E (fp16 plane +
+// 4-bit residual), kPrecFp16x2 (fp16 plane only); the products are three-pass in every case
+hipError_t launch_tdnn_first(const FirstArgs& a, int epi_prec, hipStream_t s);
+// [n_pad][ldw] planes of the generic K walk (segment j at column j * seg_pad) -> compact planes [n_pad][kFirstK]
+hipError_t launch_compact_first(const uint16_t* src, int ldw, int seg_pad, int n_pad, int noff, int dim, uint16_t* dst, hipStream_t s);
+
 // fp32 packed features [src rows][dim] -> 16-bit planes [dev rows][ld] (zero padded columns,
 // zero rows for alignment padding).  grp_utt[g] = utterance of 16-row group g or -1.
 struct PrepArgs {

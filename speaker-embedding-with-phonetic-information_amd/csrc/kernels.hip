@@ -36,6 +36,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -355,7 +356,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
     // h = p>>1, position inside the group (p&1)*4 + r
     const int ncol = nbase + fr_g * 8;
-    unsigned e4[4] = {0u, 0u, 0u, 0u};   // PrecEmitsLo4: scale byte of row q * 16 + fr_i (the same in the row's four lanes)
+    unsigned e4 = 0u;   // PrecEmitsLo4: scale byte of row q * 16 + fr_i in byte q (the same in the row's four lanes)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = mbase + q * 16 + fr_i;
@@ -366,11 +367,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         if constexpr (LAZY) {
           int c = pcol + fr_g * 8 + (p >> 1) * 32 + (p & 1) * 4;
           asm volatile("" : "+v"(c));   // keeps the reads inside the loop over q (hoisted they are 48 live registers again)
+          // no branch on a.bn here: whoever fills par stores scale 1 / offset 0 without BatchNorm.  (With the branch every
+          // fragment's three reads sat in a basic block of their own, each ending in a full LDS round trip: 16 serialised
+          // waits per 64 x 64 block.)
           b4 = *(const f32x4*)(par + c);
-          if (a.bn) {
-            s4 = *(const f32x4*)(par + 128 + c);
-            o4 = *(const f32x4*)(par + 256 + c);
-          }
+          s4 = *(const f32x4*)(par + 128 + c);
+          o4 = *(const f32x4*)(par + 256 + c);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -382,7 +384,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float z = acc[p][q][r] + b4[r];
-          z = (z < relu_floor) ? relu_floor : z;   // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0)
+          // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0).  (v_maximum3_f32 does the same in one
+          // instruction, but with it the 512 x 128 stream-K kernel and the per-tile kernel stopped agreeing bit for bit
+          // in the fp16mx2 mode - not understood, reverted.)
+          z = (z < relu_floor) ? relu_floor : z;
           y[p * 4 + r] = __builtin_fmaf(z, s4[r], o4[r]);   // scale 1 / offset 0 without BatchNorm
         }
       }
@@ -425,10 +430,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
           }
         }
         // y[0..7] = columns ncol..ncol+7, y[8..15] = columns ncol+32..ncol+39
+        // (the run-time tests of out_hi / out_lo4 are always true; as branches they keep hipcc from interleaving the stores,
+        // the group-maximum code and the residual block, which spilled 9-16 registers in the 512 x 128 stream-K kernel)
         uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
-        *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-        *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
-        if constexpr (PrecEmitsLo4(PREC)) {
+        if (!PrecEmitsLo4(PREC) || a.out_hi) {
+          *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+          *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+        }
+        if (PrecEmitsLo4(PREC) && a.out_lo4) {
           // what the fp16 rounding dropped, y - fp16(y), as e2m1 with one power-of-two scale per row and 64-column block
           // (this wave's 64 columns of the row: the four lanes fr_g of the row hold them).  The residual of a value in
           // [2^E, 2^(E+1)) is at most 2^(E-11); with E the exponent of the block's largest |y| the scale 2^(E-13) maps
@@ -462,7 +471,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
           uint8_t* d4 = a.out_lo4 + (long)row * (a.ldo >> 1) + (ncol >> 1);
           *(unsigned*)d4 = c0;
           *(unsigned*)(d4 + 16) = c1;
-          e4[q] = e;
+          e4 |= e << (8 * q);
         } else if constexpr (SPLIT) {
           uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
           *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
@@ -472,8 +481,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     }
     if constexpr (EPI == kEpiAct && PrecEmitsLo4(PREC)) {
       // the scale bytes of the block's 64 rows in one store: lane (fr_i, fr_g) writes the one of row fr_g * 16 + fr_i
-      const unsigned eb = fr_g == 0 ? e4[0] : fr_g == 1 ? e4[1] : fr_g == 2 ? e4[2] : e4[3];
-      a.out_lo4s[(long)(mbase + fr_g * 16 + fr_i) * Lo4ScalePitch(a.ldo) + (nbase >> 6)] = (uint8_t)eb;
+      a.out_lo4s[(long)(mbase + fr_g * 16 + fr_i) * Lo4ScalePitch(a.ldo) + (nbase >> 6)] = (uint8_t)(e4 >> (8 * fr_g));
     }
   } else {
     // kEpiStats: lane owns rows p*16 + fr_g*4 + r, column q*16 + fr_i.  The cross-lane adds leave the sums of
@@ -1063,6 +1071,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       int xs_lo = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) xs_lo |= (int)sl[i * 64] << (8 * i);
+      asm volatile("s_nop 4" ::: "memory");   // VALU-assembled scale word -> MFMA operand (see the stream-K kernel)
       static_for<0, 4>([&](auto P) {
         static_for<0, 4>([&](auto Q) {
           constexpr int p = decltype(P)::value, q = decltype(Q)::value;
@@ -1715,6 +1724,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       int xs_lo = 0;
 #pragma unroll
       for (int i = 0; i < XF; ++i) xs_lo |= (int)sl[i * 64] << (8 * i);
+      // xs_lo is assembled by VALU instructions and read by the (inline asm) MFMAs as their scale operand: the wait states
+      // hipcc would insert for a builtin are ours to provide.  (Without them a build whose scheduling happened to put the
+      // last v_or directly in front of the first MFMA lost the bit-identity with the per-tile kernel.)
+      asm volatile("s_nop 4" ::: "memory");
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         static_for<0, 4>([&](auto P) {
@@ -1794,11 +1807,16 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     islab = rslab = 0;
     n_steps = ke - kb;
     n_hi = kb >= SH ? 0 : (ke < SH ? ke : SH) - kb;
-    if (EPI != kEpiSplitK && kind != 1 && wave < (a.bn ? 6 : 2)) {
+    if (EPI != kEpiSplitK && kind != 1 && wave < 6) {
       // bias / scale / offset of the tile's columns -> LDS buffer part & 1, one 256-byte piece per wave; complete with the
-      // first wait of the part, read by its epilogue (which runs after open_part of the NEXT part: the other buffer)
-      const float* src = (wave < 2 ? a.bias : wave < 4 ? a.scale : a.offset) + n0 + (wave & 1) * 64;
-      glds4_sbase(src, (unsigned)lane * 4u, lds_base + PB + (part & 1) * 1536 + wave * 256);
+      // first wait of the part, read by its epilogue (which runs after open_part of the NEXT part: the other buffer).
+      // Without BatchNorm the scale / offset pieces are the constants 1 / 0 (the epilogues read them unconditionally).
+      if (wave < 2 || a.bn) {
+        const float* src = (wave < 2 ? a.bias : wave < 4 ? a.scale : a.offset) + n0 + (wave & 1) * 64;
+        glds4_sbase(src, (unsigned)lane * 4u, lds_base + PB + (part & 1) * 1536 + wave * 256);
+      } else {
+        *(float*)(smem + PB + (part & 1) * 1536 + wave * 256 + lane * 4) = wave < 4 ? 1.f : 0.f;
+      }
     }
     xs_uvec xg;
     if constexpr (MX) {
@@ -1922,6 +1940,18 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     // every wave is past its last LDS read: the rings may be refilled for the next part while this one's results go out
     const int e_kind = kind, e_m0 = m0, e_n0 = n0;
     const float* e_par = (const float*)(smem + PB + (part & 1) * 1536);
+    // Where the planes epilogue also emits the 4-bit residual (kPrecFp16Mx2) its first 64 x 64 half runs BEFORE the next
+    // part is opened: with all 128 accumulators still live, the next part's walk state on top of the residual code's
+    // temporaries spilled 24 registers; the pipeline fill of the next part then hides behind the second half only.
+    constexpr bool SPLIT_EPI = WIDE && EPI == kEpiAct && PrecEmitsLo4(PREC);
+    float gm_carry[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SPLIT_EPI) {
+      if (kind != 1) {
+        EpiRegs er;
+        epilogue_prefetch_lds<EPI, true>(a, e_par, e_m0 + row_w, 0, lane, er);
+        gemm_epilogue<PREC, EPI, true>(a, acc[0], e_m0 + row_w, e_n0, lane, er, gm_carry, 1, e_par, 0);
+      }
+    }
     if (part + 1 < n_parts) open_part(part + 1);
 
     if (e_kind == 1) {
@@ -1944,9 +1974,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       if constexpr (WIDE) {
         // two 64 x 64 blocks side by side: same rows, columns e_n0 and e_n0 + 64.  The group maxima of the planes
         // epilogue are carried across both (one reduction and one atomic per 16-row group and wave).
-        float gm[4] = {0.f, 0.f, 0.f, 0.f};
+        float (&gm)[4] = gm_carry;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
+        for (int h = SPLIT_EPI ? 1 : 0; h < NH; ++h) {
           constexpr bool LAZY = (EPI == kEpiAct || EPI == kEpiF32) && MX;   // where the registers are short (spills)
           EpiRegs er;
           epilogue_prefetch_lds<EPI, LAZY>(a, e_par, e_m0 + row_w, h * 64, lane, er);
@@ -2266,6 +2296,329 @@ hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipS
     case kPrecFp16x3E: return launch_prec<kPrecFp16x3E>(a, epilogue, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tdnn_first: the layers that read the network input (see kernels.h, FirstArgs).
+//  * Work unit = 64 frames x one group of up to 512 output columns; a persistent grid (one 512-thread workgroup per CU)
+//    takes contiguous ranges of units.  Wave w owns the 64 columns w * 64.. of the group.
+//  * Weights stay on the CU for the whole launch: the wave's 64 rows of the compact hi plane [n][128] in REGISTERS (4
+//    fragments x 4 K steps = 64 VGPRs), the lo plane of the group's 512 rows in LDS (128 KiB, 16-byte chunks XOR-swizzled
+//    with four row bits so that a fragment read is conflict free; both planes in registers spill), loaded once (again only
+//    when a workgroup's range crosses into the next column group), in the "weights as MFMA A operand" row order of the
+//    other kernels (swap_fields), so the generic planes epilogue applies unchanged.
+//  * Features: the unit's frames + halo, split into fp16 hi / lo, in LDS as [frame][dp] (dp = dim rounded up to 8: 24
+//    halves = 48 bytes per frame).  Column k' = j * dp + d of the compact K axis is element d of frame t + off[j]: a lane's
+//    16-byte fragment chunk (8 consecutive k') never straddles two frames, so the splice costs one address per lane and
+//    step (xo[]), computed once.  Double buffered: the next unit's rows are fetched into registers before the MFMAs of the
+//    current one and written to the other buffer after them; one workgroup barrier per unit.
+//  * 192 MFMAs per wave and unit against 32 fragment reads; the kernel is bound by the planes it writes.
+template <int EPREC>
+__global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
+  const GemmArgs& a = fa.g;
+  constexpr bool F16 = PrecF16(EPREC);
+  constexpr int XR = kFirstRows + 32;   // frames per buffer: unit + halo (offset span <= 30)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* par_all = (float*)smem;        // [4 tiles][bias 128 | scale 128 | offset 128]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr_i = lane & 15, fr_g = lane >> 4;
+  const int dp = (fa.dim + 7) & ~7;
+  int min_off = fa.off[0], max_off = fa.off[0];
+  for (int j = 1; j < fa.noff; ++j) {
+    min_off = min(min_off, fa.off[j]);
+    max_off = max(max_off, fa.off[j]);
+  }
+  const int span = max_off - min_off;
+  const int plane_bytes = XR * dp * 2;
+  char* wlo_s = smem + 4 * 384 * 4;     // [512 rows][16 chunks of 16 bytes], chunk c of row r at c ^ key(r)
+  char* xbuf = wlo_s + 512 * 256;       // [buffer][hi | lo][XR * dp halves]
+  auto wkey = [](int r) __attribute__((always_inline)) { return ((r >> 1) & 12) | (r & 3); };
+
+  const int n_pad = a.n_tiles * kBN;
+  // workgroup b works on column group b % ncg (one group for layers of up to 512 columns) and on a contiguous range of its
+  // row blocks
+  const int nrb = fa.nrows / kFirstRows, ncg = (n_pad + 511) / 512;
+  const int cg = blockIdx.x % ncg, wg = blockIdx.x / ncg, nwg = gridDim.x / ncg;
+  const int rb0 = (int)((long)nrb * wg / nwg), rb1 = (int)((long)nrb * (wg + 1) / nwg);
+  if (rb0 >= rb1 || wg >= nwg) return;
+  const int n0w = cg * 512 + wave * 64;
+  const bool cols_valid = n0w < n_pad;
+
+  // this lane's fragment chunk of K step s: columns k' = 32 s + 8 g .. + 7  ->  frame offset off[j], element d0 (bytes from
+  // the unit's first staged frame, this lane's frame fr_i included).  Beyond noff * dp the weights are zero: any finite
+  // data of the same frame will do (the last chunk of the last offset).
+  int xo[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = 32 * s + 8 * fr_g;
+    int j = k / dp, d0 = k - j * dp;
+    if (j >= fa.noff) {
+      j = fa.noff - 1;
+      d0 = dp - 8;
+    }
+    xo[s] = ((fa.off[j] - min_off + fr_i) * dp + d0) * 2;
+  }
+
+  // ---- staging: global -> registers (prefetch) -> LDS (commit) --------------------------------------------------
+  // Where the frames of a device row come from: the plan's per-group table (FirstArgs::grp_src), a window of which this
+  // workgroup keeps in LDS (looked up per unit from global memory the lookup is a dependent load in front of the feature
+  // loads; as the chain grp_utt -> dev_off / src_off it cost more than the unit's MFMAs).
+  constexpr int kTabUnits = 96;                     // row blocks per table window
+  constexpr int kTabGroups = kTabUnits * 4 + 8;     // + halo groups on both sides
+  int4* gtab = (int4*)(xbuf + 4 * plane_bytes);
+  int tab_rb0 = -(1 << 30), tab_g0 = 0;             // first row block of the window, its first group
+  auto build_table = [&](int rb_first) __attribute__((always_inline)) {
+    tab_rb0 = rb_first;
+    tab_g0 = ((fa.row0 + rb_first * kFirstRows) >> 4) - 4;
+    for (int i = tid; i < kTabGroups; i += 512) {
+      const int g = tab_g0 + i;
+      gtab[i] = (g >= 0 && g * 16 < fa.rows) ? fa.grp_src[g] : int4{0, 0, 0, 0};
+    }
+  };
+  const int n_slots = (kFirstRows + span) * dp;
+  int slot_fd[kFirstMaxSlots];   // frame (inside the staged rows) << 8 | element of this thread's slots; -1: none
+#pragma unroll
+  for (int i = 0; i < kFirstMaxSlots; ++i) {
+    const int slot = tid + 512 * i;
+    const int fr = slot / dp;
+    slot_fd[i] = slot < n_slots ? (fr << 8) | (slot - fr * dp) : -1;
+  }
+  // the loads are unconditional (a slot without a source frame reads element 0 and is zeroed at commit): a conditional load
+  // is merged with its default right where it is issued, i.e. waited for in front of the MFMAs instead of after them
+  float pv[kFirstMaxSlots] = {0.f, 0.f, 0.f, 0.f};
+  unsigned pv_ok = 0u;
+  auto prefetch = [&](int rb) __attribute__((always_inline)) {
+    const int r_first = fa.row0 + rb * kFirstRows + min_off;
+    pv_ok = 0u;
+#pragma unroll
+    for (int i = 0; i < kFirstMaxSlots; ++i) {
+      long idx = 0;
+      if (slot_fd[i] >= 0) {
+        const int d = slot_fd[i] & 255;
+        const int r = r_first + (slot_fd[i] >> 8);
+        const int4 e = gtab[(r >> 4) - tab_g0];
+        const int t = r & 15;
+        if (d < fa.dim && t < e.y) {
+          idx = (long)min(max(e.x + t, e.z), e.w) * fa.dim + d;
+          pv_ok |= 1u << i;
+        }
+      }
+      pv[i] = fa.feats[idx];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // nothing that uses the values moves up here (their wait would come with it)
+  };
+  auto commit = [&](int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    uint16_t* hi = (uint16_t*)(xbuf + buf * 2 * plane_bytes);
+    uint16_t* lo = (uint16_t*)(xbuf + buf * 2 * plane_bytes + plane_bytes);
+#pragma unroll
+    for (int i = 0; i < kFirstMaxSlots; ++i) {
+      const int slot = tid + 512 * i;
+      if (slot_fd[i] >= 0) {
+        const float v = (pv_ok >> i & 1u) ? pv[i] : 0.f;
+        const uint16_t h = to16<F16>(v);
+        hi[slot] = h;
+        lo[slot] = to16<F16>(v - from16<F16>(h));
+      }
+    }
+  };
+
+  s16x8 wh[4][4];             // [fragment p of the wave's 64 columns][K step]
+  int wl_rd[4];               // byte address of this lane's lo-plane row of fragment p, and its swizzle key
+  int wl_key[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = wave * 64 + swap_fields(p * 16 + fr_i);
+    wl_rd[p] = r * 256;
+    wl_key[p] = wkey(r);
+  }
+  // Waves 0-3 / 4-7 (one of each per SIMD) run half a unit apart: inside one barrier interval group 0 multiplies unit u and
+  // then stores it, group 1 first stores unit u - 1 (its accumulators survive the barrier) and then multiplies unit u - so
+  // on every SIMD one wave feeds the matrix pipe while the other converts and stores, and the planes leave the chip all the
+  // time instead of in bursts (in lockstep the kernel was the sum of its phases: 17 us of MFMAs + 33 us of stores).  The
+  // interval is written as two passes over ONE body {store what is pending; multiply} so that the epilogue is instantiated
+  // once (inlined at every place it is needed the kernel spilled ~100 registers).
+  const int group = wave >> 2;
+  f32x4 acc[4][4];
+  int pend_mbase = 0;
+  bool pending = false;
+
+  // parameters and lo plane -> LDS, hi plane -> registers: every global load of a batch is issued before its first LDS store
+  // (as a loop of load-store pairs this took one memory latency per pass: 16 us of an 80 us launch)
+  {
+    // thread t: column cg * 512 + t of the group (without BatchNorm: scale 1, offset 0 - the epilogue reads them unconditionally)
+    float pr[3] = {0.f, 1.f, 0.f};
+    {
+      const int c = cg * 512 + tid;
+      if (c < n_pad) {
+        pr[0] = a.bias[c];
+        if (a.bn) {
+          pr[1] = a.scale[c];
+          pr[2] = a.offset[c];
+        }
+      }
+    }
+    if (cols_valid) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const long wrow = (long)(n0w + swap_fields(p * 16 + fr_i)) * kFirstK + fr_g * 8;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) wh[p][st] = *(const s16x8*)(fa.wc_hi + wrow + st * 32);
+      }
+    }
+    u32x4 wv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = tid + 512 * k;
+      const int r = i >> 4, c = i & 15;
+      wv[k] = u32x4{0u, 0u, 0u, 0u};
+      if (cg * 512 + r < n_pad) wv[k] = *(const u32x4*)(fa.wc_lo + (long)(cg * 512 + r) * kFirstK + c * 8);
+    }
+    build_table(rb0);   // its loads travel with the weights'
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = tid + 512 * k;
+      const int r = i >> 4, c = i & 15;
+      *(u32x4*)(wlo_s + r * 256 + ((c ^ wkey(r)) << 4)) = wv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) par_all[(tid >> 7) * 384 + k * 128 + (tid & 127)] = pr[k];
+  }
+  __syncthreads();
+  prefetch(rb0);
+  commit(0);
+#pragma unroll 1
+  for (int rb = rb0; rb <= rb1; ++rb) {   // one pass more than there are units: group 1's last store
+    const bool has_unit = rb < rb1;
+    const int buf = (rb - rb0) & 1;
+    // the unit after this one must lie inside the table window (its rows are fetched during this unit)
+    if (rb + 1 < rb1 && rb + 1 >= tab_rb0 + kTabUnits) {
+      __syncthreads();
+      build_table(rb + 1);
+    }
+    __syncthreads();   // this unit's frames are in LDS; the other buffer is free
+    if (rb + 1 < rb1) prefetch(rb + 1);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if (pending && (half == 0 || group == 0)) {
+        pending = false;
+        const float* par = par_all + (wave >> 1) * 384;
+        EpiRegs er;
+        epilogue_prefetch_lds<kEpiAct, true>(a, par, pend_mbase, (wave & 1) * 64, lane, er);
+        float gm[4] = {0.f, 0.f, 0.f, 0.f};
+        gemm_epilogue<EPREC, kEpiAct, true>(a, acc, pend_mbase, n0w, lane, er, gm, 0, par, (wave & 1) * 64);
+      }
+      if (half == 0 && has_unit) {
+        if (cols_valid) {
+          {
+            const char* xh_b = xbuf + buf * 2 * plane_bytes;
+            const char* xl_b = xh_b + plane_bytes;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              s16x8 xh[4], xl[4], wl[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                xh[q] = *(const s16x8*)(xh_b + q * 16 * dp * 2 + xo[st]);
+                xl[q] = *(const s16x8*)(xl_b + q * 16 * dp * 2 + xo[st]);
+              }
+#pragma unroll
+              for (int p = 0; p < 4; ++p) wl[p] = *(const s16x8*)(wlo_s + wl_rd[p] + (((st * 4 + fr_g) ^ wl_key[p]) << 4));
+              // three products per accumulator, 16 independent MFMAs between two on the same one.  fp16: accumulators
+              // tied in place from inline asm (left to itself hipcc rotates them through copies: spills); the first MFMA
+              // of a unit is the builtin with a literal-zero addend - a v_mov clearing the accumulator right in front of
+              // an asm MFMA is a VALU-write -> MFMA-read hazard hipcc cannot see (it produced garbage)
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if (st == 0 || !F16) acc[p][q] = mfma16<F16>(wl[p], xh[q], st == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[p][q]);
+                  else mfma16_f16_inplace(wl[p], xh[q], acc[p][q]);
+                }
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if constexpr (F16) mfma16_f16_inplace(wh[p][st], xl[q], acc[p][q]);
+                  else acc[p][q] = mfma16<F16>(wh[p][st], xl[q], acc[p][q]);
+                }
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if constexpr (F16) mfma16_f16_inplace(wh[p][st], xh[q], acc[p][q]);
+                  else acc[p][q] = mfma16<F16>(wh[p][st], xh[q], acc[p][q]);
+                }
+              __builtin_amdgcn_sched_barrier(0);   // the fragments of one step at a time (hoisted, the reads of all four spill)
+            }
+            if constexpr (F16) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
+          }
+          pending = true;
+          pend_mbase = fa.row0 + rb * kFirstRows;
+        }
+        if (rb + 1 < rb1) commit(buf ^ 1);
+      }
+    }
+  }
+}
+
+hipError_t launch_tdnn_first(const FirstArgs& a, int epi_prec, hipStream_t s) {
+  if (!FirstLayerApplicable(a.dim, a.noff, a.off) || a.nrows <= 0 || a.nrows % kFirstRows || a.row0 % kFirstRows || !a.wc_hi || !a.wc_lo)
+    return hipErrorInvalidValue;
+  const int dp = (a.dim + 7) & ~7;
+  const int lds = 4 * 384 * 4 + 512 * 256 + 4 * (kFirstRows + 32) * dp * 2 + (96 * 4 + 8) * 16;
+  static std::atomic<unsigned long long> attr_done{0};
+  int attr_dev = 0;
+  if (lds_attr_needed(&attr_done, &attr_dev)) {
+    for (const void* f : {(const void*)tdnn_first_kernel<kPrecFp16x3>, (const void*)tdnn_first_kernel<kPrecBf16x3>,
+                          (const void*)tdnn_first_kernel<kPrecFp16x3E>, (const void*)tdnn_first_kernel<kPrecFp16x2>}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
+  }
+  const int ncg = (a.g.n_tiles * kBN + 511) / 512;
+  const int grid = std::max(1, std::min(device_cu_count() / ncg, a.nrows / kFirstRows)) * ncg;
+  const char* what;
+  switch (epi_prec) {
+    case kPrecFp16x3:
+      XV_LAUNCH(tdnn_first_kernel<kPrecFp16x3>, dim3(grid), dim3(512), lds, s, a);
+      what = "tdnn_first_kernel<fp16x3,act>";
+      break;
+    case kPrecBf16x3:
+      XV_LAUNCH(tdnn_first_kernel<kPrecBf16x3>, dim3(grid), dim3(512), lds, s, a);
+      what = "tdnn_first_kernel<bf16x3,act>";
+      break;
+    case kPrecFp16x3E:
+      if (!a.g.out_lo4 || !a.g.out_lo4s) return hipErrorInvalidValue;
+      XV_LAUNCH(tdnn_first_kernel<kPrecFp16x3E>, dim3(grid), dim3(512), lds, s, a);
+      what = "tdnn_first_kernel<fp16x3,act+lo4>";
+      break;
+    case kPrecFp16x2:
+      XV_LAUNCH(tdnn_first_kernel<kPrecFp16x2>, dim3(grid), dim3(512), lds, s, a);
+      what = "tdnn_first_kernel<fp16x3,act1>";
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  snprintf(g_last_kernel, sizeof g_last_kernel, "%s", what);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void compact_first_kernel(const uint16_t* src, int ldw, int seg_pad, int n_pad, int noff, int dim,
+                                                            uint16_t* dst) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_pad * kFirstK) return;
+  const int n = (int)(idx / kFirstK), k = (int)(idx - (long)n * kFirstK);
+  const int dp = (dim + 7) & ~7;
+  const int j = k / dp, d = k - j * dp;
+  dst[idx] = (j < noff && d < dim) ? src[(long)n * ldw + j * seg_pad + d] : (uint16_t)0;
+}
+
+hipError_t launch_compact_first(const uint16_t* src, int ldw, int seg_pad, int n_pad, int noff, int dim, uint16_t* dst, hipStream_t s) {
+  const long total = (long)n_pad * kFirstK;
+  hipLaunchKernelGGL(compact_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ldw, seg_pad, n_pad, noff, dim, dst);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -74,13 +74,13 @@ const char* kUsage =
     "                                   product, fp32-grade (3e-7..4e-6 from the fp32 oracle).  fp16mx2: fp16 product +\n"
     "                                   two block-scaled 4-bit products that correct the fp16 rounding of the weights\n"
     "                                   and of the activations, 1.5 passes, ~1.4x faster: 3-5.5e-5 on every model\n"
-    "                                   tried; chunks that pool < 100 frames run fp16x3.  auto: chunks that pool >= 300\n"
+    "                                   tried; chunks that pool < 160 frames run fp16x3.  auto: chunks that pool >= 300\n"
     "                                   frames run fp16mx (weights corrected only, 1.25 passes, ~1.9x faster than\n"
     "                                   fp16x3), the others fp16x3; its error is the activation rounding averaged by the\n"
     "                                   pooling - 5-8e-5 on models with Kaldi-initialisation-like weights, 1-2e-4 on\n"
     "                                   heavy-tailed ones (DESIGN.md section 3.0): check it on your model first.\n"
     "  --fast-min-pooled=<int>          auto / fp16mx2: chunks that pool at least this many frames take the fast\n"
-    "                                   kernels (default 300 / 100, or $XVEC_FAST_MIN_POOLED)\n"
+    "                                   kernels (default 300 / 160, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
