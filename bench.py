@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # precision mode -> MFMAs executed per algorithmic product in the frame-level GEMMs
-PRECISION_NOTES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "fp16mx2": 1.5, "auto": None, "bf16": 1, "fp16": 1}
+PRECISION_NOTES = {"default": None, "bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "fp16mx2": 1.5, "auto": None, "bf16": 1, "fp16": 1}
 KERNEL_PASSES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "fp16mx2": 1.5, "fp16x3e": 3, "bf16": 1, "fp16": 1}
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
@@ -223,12 +223,16 @@ def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_n
         net, line = H.synth_model(topology)
     model = P.Model(raw=net.to_bytes(True), nnet_config=line)
     ctx = P.Context(model, device=local_rank, precision=P.PRECISIONS[precision])
+    cal = None
     if ragged:
         lens = np.random.default_rng(5).integers(ragged[0], ragged[1] + 1, batch).astype(np.int64)
     else:
         lens = np.full(batch, 400, dtype=np.int64)
     feats, offs = make_inputs(torch, ctx, lens, dev, 777)
     frame_level = not ctx.info.output_is_segment
+    if precision == "default" and not frame_level:
+        n = min(64, batch)
+        cal = ctx.calibrate(feats[:int(offs[n])].cpu().numpy(), offs[:n + 1], 7.5e-5)
     out = torch.empty(int(lens.sum()) if frame_level else batch, ctx.info.output_dim, dtype=torch.float32, device=dev)
 
     def step():
@@ -250,6 +254,7 @@ def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_n
         err = H.rel_err(out[:2].cpu().numpy(), ref)
     return {"workload": "%s, %s, %d chunks x %s frames, output %s" % (topology, precision, batch,
                                                                    "%d-%d" % ragged if ragged else "400", output_node or "embedding"),
+            "arithmetic": ctx.fast_mode, "calibration": cal,
             "value": batch * steps / dt, "unit": "utt/s", "frames_per_sec": float(lens.sum()) * steps / dt,
             "ms_per_step": dt / steps * 1e3, "alg_gflop_per_utt": 2.0 * macs / 1e9,
             "alg_tflops": 2.0 * macs * batch * steps / dt / 1e12, "rel_err_vs_oracle_fp32": err}
@@ -260,7 +265,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="auto", choices=sorted(PRECISION_NOTES))
+    ap.add_argument("--precision", default="default", choices=sorted(PRECISION_NOTES),
+                    help="default = what the command-line tools ship (XV_PREC_DEFAULT): the context is packed as fp16mx2 and, like "
+                         "nnet3-xvector-compute does on the head of its table, calibrated on the first 64 chunks of the workload "
+                         "(xv_ctx_calibrate, outside the timed region): fp16mx if its error against fp16x3 is within 7.5e-5 on the worst chunk, else fp16mx2")
+    ap.add_argument("--no-calibrate", action="store_true", help="with --precision default: keep fp16mx2 whatever the model")
     ap.add_argument("--topology", default="v2_xvector")
     ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
     ap.add_argument("--frames", type=int, default=400)
@@ -336,6 +345,22 @@ def main():
         ctx = P.Context(blob=wt.numpy().tobytes(), device=local_rank)
     del wt
 
+    def calibrate_ctx(c, f_dev, o, what):
+        """The CLI's policy: rank 0 measures on the first 64 chunks, every rank runs what it chose."""
+        import numpy as _np
+        n = min(64, len(o) - 1)
+        choice = torch.tensor([-1], dtype=torch.int64, device=cdev)
+        cal = None
+        if rank == 0:
+            cal = c.calibrate(f_dev[:int(o[n])].cpu().numpy(), _np.asarray(o[:n + 1], dtype=_np.int32), 7.5e-5)
+            cal["sample"] = "%d chunks of %s" % (n, what)
+            choice[0] = P.PRECISIONS[cal["chosen"]]
+        if world > 1:
+            dist.broadcast(choice, 0)
+            if rank != 0:
+                c.set_fast_mode(P.PRECISION_NAMES[int(choice[0])])
+        return cal
+
     # ---- synthetic inputs resident in HBM (SURVEY.md §8(d): N(0,1)*sigma_d, sigma_d = 8*0.9^d) ---------------
     B, T = args.batch, args.frames
     if ragged:
@@ -347,6 +372,9 @@ def main():
     feats, offs = make_inputs(torch, ctx, lens, dev, 20180101 + rank)
     if os.environ.get("BENCH_ZERO_FEATS") == "1":   # diagnostic only (DVFS study): constant activations
         feats.zero_()
+    calibration = None
+    if args.precision == "default" and not args.no_calibrate and not frame_level:
+        calibration = calibrate_ctx(ctx, feats, offs, "this workload")
     out_rows = total_rows if frame_level else B
     outs = [torch.empty(out_rows, ctx.info.output_dim, dtype=torch.float32, device=dev) for _ in range(2 if frame_level else 4)]
     out = outs[0]
@@ -447,7 +475,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s TDNN, %d chunks x %s frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
                                    % (args.topology, B, args.ragged or T), "topology": args.topology, "batch_chunks_per_gpu": B,
-                       "frames_per_chunk": T if not ragged else None, "precision": args.precision, "kernel_precisions": kernel_precs,
+                       "frames_per_chunk": T if not ragged else None, "precision": args.precision,
+                       "arithmetic": ctx.fast_mode, "calibration": calibration, "kernel_precisions": kernel_precs,
                        "lanes": args.lanes, "alg_gflop_per_utt": 2.0 * macs / 1e9, "output_node": args.output_node or "embedding",
                        "chunk_lengths": args.ragged or str(T), "frames_per_step": total_rows},
             "frames_per_sec": world * total_rows * args.steps / dt,
@@ -466,6 +495,8 @@ def main():
             extra = {}
             os.environ["XVEC_LANES"] = "2"
             c3 = P.Context(model, device=local_rank, precision=prec)
+            if calibration:
+                c3.set_fast_mode(calibration["chosen"])
             f3 = lambda: c3.forward_batch_device(feats.data_ptr(), offs, outs[1].data_ptr(), outs[1].shape[1], None)  # noqa: E731
             prewarm(torch, f3, 0.3)
             d3 = time_steps(torch, f3, args.steps)
@@ -475,8 +506,9 @@ def main():
             del c3
             os.environ["XVEC_LANES"] = str(args.lanes)
             # the other arithmetic modes on the same workload, each with its measured error (never `value`)
-            for pname in ("fp16x3", "fp16mx2", "fp16x2", "bf16", "fp16"):
-                if pname == args.precision:
+            for pname in ("fp16x3", "fp16mx2", "auto", "fp16x2", "bf16", "fp16"):
+                if pname == args.precision or (pname == "fp16mx2" and ctx.fast_mode == "fp16mx2") or \
+                        (pname == "auto" and ctx.fast_mode == "fp16mx"):
                     continue
                 c2 = P.Context(model, device=local_rank, precision=P.PRECISIONS[pname])
                 o2 = torch.empty_like(out)
@@ -498,9 +530,17 @@ def main():
                 tu = [H.features(50 + i, 400) for i in range(4)]
                 tf, to = H.pack(tu)
                 tref = np.stack([tev.compute(u)[0] for u in tu])
-                res["parity_trained_like_model"] = {
-                    pn: H.rel_err(P.Context(tmodel, device=local_rank, precision=P.PRECISIONS[pn]).forward_batch(tf, to), tref)
-                    for pn in ("fp16x3", "fp16mx2", "fp16x2", args.precision)}
+                ptl = {pn: H.rel_err(P.Context(tmodel, device=local_rank, precision=P.PRECISIONS[pn]).forward_batch(tf, to), tref)
+                       for pn in ("fp16x3", "fp16mx2", "fp16x2", "auto")}
+                if args.precision == "default":
+                    # the shipped policy on this model: calibrate on its own utterances, then run what was chosen
+                    tc = P.Context(tmodel, device=local_rank)
+                    tcal = tc.calibrate(tf, to, 7.5e-5)
+                    ptl["default"] = H.rel_err(tc.forward_batch(tf, to), tref)
+                    ptl["default_chose"] = tcal
+                else:
+                    ptl[args.precision] = H.rel_err(P.Context(tmodel, device=local_rank, precision=prec).forward_batch(tf, to), tref)
+                res["parity_trained_like_model"] = ptl
             except Exception as e:   # noqa: BLE001
                 res["parity_trained_like_model"] = {"error": str(e)}
             # BASELINE.json configs 3 and 5 on this GPU

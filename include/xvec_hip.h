@@ -130,6 +130,31 @@ xv_status xv_ctx_synchronize(xv_ctx* c);
  * the roofline figure).  xv_ctx_profile_report synchronises, writes "label<TAB>launches<TAB>total_ms" lines for
  * everything recorded since the previous report into buf (NUL terminated), resets the record, and returns
  * the number of bytes needed; call it often enough - every recorded forward keeps a handful of events alive. */
+/* ---- calibrated arithmetic -----------------------------------------------------------------------------------------
+ * A context packed as XV_PREC_FP16MX2 (what XV_PREC_DEFAULT resolves to for a pooled output) can also run the lighter
+ * XV_PREC_FP16MX arithmetic (1.25 instead of 1.5 MFMA passes, +30 % throughput) and the three-pass XV_PREC_FP16X3 on the
+ * same packed weights.  XV_PREC_FP16MX meets the parity bar on some models only, so it is never
+ * assumed: xv_ctx_calibrate runs the caller's own chunks in all three, compares the embeddings of the two fast modes with
+ * the three-pass ones (worst max|d| / max|ref| over the chunks that pool >= 300 frames) and switches the context to
+ * XV_PREC_FP16MX only when its error stays within tol (the tools use 7.5e-5 on the worst chunk: three quarters of the 1e-4 bar; over 64 chunks the worst one lies ~20 % above the mean, so the bar is more than six standard deviations away), else leaves XV_PREC_FP16MX2
+ * (or drops to XV_PREC_FP16X3 should even that exceed 1e-4).  Contexts that cannot switch report their precision with
+ * checked = 0.  This is what `nnet3-xvector-compute --precision=default` does on the first 64 utterances of its job
+ * (no reference counterpart: Kaldi computes in fp32 throughout).  xv_ctx_set_fast_mode applies a choice made elsewhere
+ * (the other ranks of a multi-GPU job); xv_calibrate_table calibrates on the first max_utts utterances of a table. */
+typedef struct {
+  int32_t chosen;   /* xv_precision the context now runs its fast chunks in */
+  int32_t checked;  /* chunks compared */
+  float err_mx;     /* XV_PREC_FP16MX against XV_PREC_FP16X3 */
+  float err_mx2;    /* XV_PREC_FP16MX2 against XV_PREC_FP16X3 */
+} xv_calibration;
+xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out);
+xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision);
+xv_status xv_ctx_fast_mode(const xv_ctx* c, int32_t* precision);
+xv_status xv_calibrate_table(xv_ctx* c, const char* feature_rspecifier, int32_t chunk_size, int32_t min_chunk_size,
+                             int32_t pad_input, int32_t max_utts, float tol, xv_calibration* out);
+/* xv_extract_table calibrates on the head of its own table first when this is enabled (default: off) */
+xv_status xv_ctx_set_calibration(xv_ctx* c, int32_t enable, float tol);
+
 xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable);
 size_t xv_ctx_profile_report(xv_ctx* c, char* buf, size_t n);
 

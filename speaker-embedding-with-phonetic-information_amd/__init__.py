@@ -22,6 +22,7 @@ PREC_BF16X3, PREC_BF16, PREC_FP16, PREC_FP16X3, PREC_FP16X2, PREC_AUTO, PREC_FP1
 PREC_DEFAULT = -1   # XV_PREC_DEFAULT: the one policy of every entry point (fp16mx2 where the model allows, else fp16x3)
 PRECISIONS = {"default": PREC_DEFAULT, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3,
               "fp16x2": PREC_FP16X2, "auto": PREC_AUTO, "fp16mx": PREC_FP16MX, "fp16mx2": PREC_FP16MX2}
+PRECISION_NAMES = {v: k for k, v in PRECISIONS.items()}
 # MFMA issue time per algorithmic product in units of one fp16 16x16x32 pass (fp16mx: + one 4-bit 16x16x128 per four)
 MFMA_PASSES = {"bf16x3": 3, "bf16": 1, "fp16": 1, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25}
 EPI_ACT, EPI_F32, EPI_STATS = 0, 1, 2
@@ -61,13 +62,19 @@ class GemmDesc(ctypes.Structure):
                 ("out_lo4", ctypes.c_void_p), ("out_lo4_scale", ctypes.c_void_p)]
 
 
+class Calibration(ctypes.Structure):
+    """xv_calibration: what xv_ctx_calibrate measured and chose."""
+    _fields_ = [("chosen", ctypes.c_int32), ("checked", ctypes.c_int32), ("err_mx", ctypes.c_float), ("err_mx2", ctypes.c_float)]
+
+
 # every symbol include/xvec_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [
     "xv_last_error", "xv_version", "xv_model_load", "xv_model_load_rxfilename", "xv_model_free", "xv_model_info",
     "xv_model_macs", "xv_model_describe", "xv_model_pack", "xv_ctx_create", "xv_ctx_create_from_blob",
     "xv_ctx_create_from_device_blob", "xv_ctx_free",
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
-    "xv_ctx_profile_report", "xv_extract_utterances",
+    "xv_ctx_profile_report", "xv_extract_utterances", "xv_ctx_calibrate", "xv_ctx_set_fast_mode", "xv_ctx_fast_mode",
+    "xv_calibrate_table", "xv_ctx_set_calibration",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
     "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_tile_mx_scales", "xv_pack_mx_weights",
 ]
@@ -143,6 +150,13 @@ def lib():
     L.xv_ctx_create_broadcast.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_void_p)]
     L.xv_kernel_tdnn_gemm.argtypes = [ctypes.POINTER(GemmDesc)]
+    L.xv_ctx_calibrate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_float,
+                                   ctypes.POINTER(Calibration)]
+    L.xv_ctx_set_fast_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    L.xv_ctx_fast_mode.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+    L.xv_calibrate_table.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_float, ctypes.POINTER(Calibration)]
+    L.xv_ctx_set_calibration.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float]
     _lib = L
     return L
 
@@ -283,6 +297,37 @@ class Context:
                                   min_chunk_size, 1 if pad_input else 0, batch_frames, ctypes.byref(done),
                                   ctypes.byref(failed)))
         return done.value, failed.value
+
+    def calibrate(self, feats, row_offsets, tol=7.5e-5):
+        """xv_ctx_calibrate on host chunks: picks the fastest arithmetic whose embeddings stay within tol of the three-pass
+        ones ON THESE CHUNKS and switches the context to it.  Returns {"chosen": name, "checked", "err_mx", "err_mx2"}."""
+        import numpy as np
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
+        c = Calibration()
+        _check(lib().xv_ctx_calibrate(self._h, feats.ctypes.data, offs.ctypes.data, len(offs) - 1, tol, ctypes.byref(c)))
+        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
+
+    def calibrate_table(self, feature_rspecifier, chunk_size=-1, min_chunk_size=100, pad_input=True, max_utts=64, tol=7.5e-5):
+        """The same on the first chunk of the first max_utts utterances of a feature table."""
+        c = Calibration()
+        _check(lib().xv_calibrate_table(self._h, feature_rspecifier.encode(), chunk_size, min_chunk_size, 1 if pad_input else 0,
+                                        max_utts, tol, ctypes.byref(c)))
+        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
+
+    @property
+    def fast_mode(self):
+        """Name of the arithmetic the fast chunks run in right now (xv_ctx_fast_mode)."""
+        p = ctypes.c_int32()
+        _check(lib().xv_ctx_fast_mode(self._h, ctypes.byref(p)))
+        return PRECISION_NAMES.get(p.value, str(p.value))
+
+    def set_fast_mode(self, name):
+        _check(lib().xv_ctx_set_fast_mode(self._h, PRECISIONS[name]))
+
+    def set_calibration(self, enable=True, tol=7.5e-5):
+        """extract_table then calibrates on the head of its own table before the first batch."""
+        _check(lib().xv_ctx_set_calibration(self._h, 1 if enable else 0, tol))
 
     def extract_utterances(self, feats, row_offsets, chunk_size=-1, min_chunk_size=100, pad_input=True):
         import numpy as np

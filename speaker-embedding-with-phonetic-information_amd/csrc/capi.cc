@@ -22,6 +22,8 @@ struct xv_model {
 
 struct xv_ctx {
   std::unique_ptr<xv::Engine> eng;
+  bool calibrate = false;       // xv_ctx_set_calibration: table jobs calibrate on the head of their table first
+  float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
 };
 
 namespace {
@@ -220,6 +222,68 @@ xv_status xv_ctx_synchronize(xv_ctx* c) {
   });
 }
 
+static void FillCalibration(const xv::Engine::Calibration& c, xv_calibration* out) {
+  if (!out) return;
+  out->chosen = c.chosen;
+  out->checked = c.checked;
+  out->err_mx = c.err_mx;
+  out->err_mx2 = c.err_mx2;
+}
+
+xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out) {
+  if (!c || !feats || !row_offsets || B < 1) return Fail(XV_ERR_ARG, "xv_ctx_calibrate: bad argument");
+  return Guard([&] {
+    FillCalibration(c->eng->Calibrate(feats, row_offsets, B, tol), out);
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_fast_mode: null context");
+  return Guard([&] {
+    if (precision == c->eng->fast_mode()) return XV_OK;
+    if (!c->eng->can_switch_fast_mode() || (precision != XV_PREC_FP16MX2 && precision != XV_PREC_FP16MX && precision != XV_PREC_FP16X3))
+      return Fail(XV_ERR_ARG, "xv_ctx_set_fast_mode: the context must be packed as XV_PREC_FP16MX2 (pooled output) and the mode one of "
+                              "XV_PREC_FP16MX2, XV_PREC_FP16MX, XV_PREC_FP16X3");
+    c->eng->SetFastMode(precision);
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_fast_mode(const xv_ctx* c, int32_t* precision) {
+  if (!c || !precision) return Fail(XV_ERR_ARG, "xv_ctx_fast_mode: null argument");
+  *precision = c->eng->fast_mode();
+  return XV_OK;
+}
+
+xv_status xv_calibrate_table(xv_ctx* c, const char* feature_rspecifier, int32_t chunk_size, int32_t min_chunk_size, int32_t pad_input,
+                             int32_t max_utts, float tol, xv_calibration* out) {
+  if (!c || !feature_rspecifier) return Fail(XV_ERR_ARG, "xv_calibrate_table: null argument");
+  return Guard([&] {
+    xv::ExtractOptions opt;
+    opt.chunk_size = chunk_size;
+    opt.min_chunk_size = min_chunk_size;
+    opt.pad_input = pad_input != 0;
+    opt.calibrate_tol = tol;
+    if (max_utts > 0) opt.calibrate_utts = max_utts;
+    if (getenv("XVEC_CMN_WINDOW")) opt.cmn_window = atoi(getenv("XVEC_CMN_WINDOW"));
+    if (getenv("XVEC_VAD_RSPECIFIER")) opt.vad_rspecifier = getenv("XVEC_VAD_RSPECIFIER");
+    FillCalibration(xv::CalibrateOnTable(c->eng.get(), opt, feature_rspecifier,
+                                         [](const char* level, const std::string& m) {
+                                           fprintf(stderr, "%s (xvec_hip:xv_calibrate_table) %s\n", level, m.c_str());
+                                         }),
+                    out);
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_set_calibration(xv_ctx* c, int32_t enable, float tol) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_calibration: null context");
+  c->calibrate = enable != 0;
+  if (tol > 0.f) c->calibrate_tol = tol;
+  return XV_OK;
+}
+
 xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable) {
   if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_profiling: null context");
   c->eng->SetProfiling(enable != 0);
@@ -265,6 +329,8 @@ xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char
     opt.min_chunk_size = min_chunk_size;
     opt.pad_input = pad_input != 0;
     if (batch_frames > 0) opt.max_batch_rows = batch_frames;
+    opt.calibrate = c->calibrate;
+    opt.calibrate_tol = c->calibrate_tol;
     if (getenv("XVEC_CMN_WINDOW")) opt.cmn_window = atoi(getenv("XVEC_CMN_WINDOW"));
     if (getenv("XVEC_VAD_RSPECIFIER")) opt.vad_rspecifier = getenv("XVEC_VAD_RSPECIFIER");
     xv::TableExtractResult r = xv::RunTableExtraction(

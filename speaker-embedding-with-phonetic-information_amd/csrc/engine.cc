@@ -540,7 +540,10 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     // 386 pooled frames, 4.5e-5 at 123, 0.6-1.5e-4 at 11 - chunks below the threshold take the three-pass arithmetic
     const char* e = getenv("XVEC_FAST_MIN_POOLED");
     fast_min_pooled_ = (e && *e) ? atoi(e) : (info_.precision == kPrecAuto ? kDefaultFastMinPooled : kDefaultFastMinPooledMx2);
+    mx2_min_pooled_ = (e && *e) ? atoi(e) : kDefaultFastMinPooledMx2;
+    mx_min_pooled_ = (e && *e) ? atoi(e) : kDefaultFastMinPooled;
   }
+  fast_mode_ = info_.precision;
   Check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   {
     const char* e = getenv("XVEC_LANES");
@@ -710,13 +713,13 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
       }
       Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
       if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true);
-      if (fast_mx2_) {
+      if (info_.precision == kPrecFp16Mx2 && !frame_mode_) {   // whatever the current fast mode is (SetFastMode)
         Ensure(&L.act[i].act_lo4, r * (li.n_pad / 2), true);
         Ensure(&L.act[i].act_lo4s, r * Lo4ScalePitch(li.n_pad), true);
       }
     }
     // per layer: max |activation| of every 16-row group (what a kPrecFp16Mx consumer scales its 4-bit copy by)
-    if (fast_mx_) Ensure(&L.gmax, layers_.size() * (size_t)(rows / kRowAlign) * 4, true);
+    if (fast_mx_ || can_switch_fast_mode()) Ensure(&L.gmax, layers_.size() * (size_t)(rows / kRowAlign) * 4, true);
     L.gmax_stride = rows / kRowAlign;
     L.cap_rows = rows;
   }
@@ -1213,6 +1216,80 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
   Check(hipEventRecord(L.done, s), "hipEventRecord(lane)");
   L.busy = true;
   if (prof_on_) prof_runs_.push_back(std::move(prof_run));
+}
+
+void Engine::SetFastMode(int mode) {
+  if (!can_switch_fast_mode()) throw EngineError("this context cannot switch its arithmetic (it was not packed as fp16mx2 with a pooled output)");
+  if (mode != kPrecFp16Mx2 && mode != kPrecFp16Mx && mode != kPrecFp16x3) throw EngineError("SetFastMode: fp16mx2, fp16mx or fp16x3");
+  if (mode == fast_mode_) return;
+  Check(hipSetDevice(device_), "hipSetDevice");
+  Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  for (const HostSlot& S : host_slots_)
+    if (S.pending) throw EngineError("SetFastMode with a batch in flight");
+  fast_mode_ = mode;
+  fast_mx2_ = mode == kPrecFp16Mx2;
+  fast_mx_ = mode != kPrecFp16x3;
+  has_fast_ = mode != kPrecFp16x3;
+  fast_min_pooled_ = mode == kPrecFp16Mx2 ? mx2_min_pooled_ : mx_min_pooled_;
+  plan_cache_.clear();   // the row regions of a plan depend on the threshold
+}
+
+Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_offsets, int B, float tol) {
+  Calibration c;
+  c.chosen = fast_mode();
+  if (!can_switch_fast_mode() || B <= 0) return c;
+  // chunks the lighter mode would run fast: pooled frames as FillPlan counts them
+  const BlobLayerInfo& pl = info_.layers[info_.pooled_layer];
+  const int pool_first = std::max(pl.left, -info_.pool_left);
+  std::vector<int32_t> offs(1, row_offsets[0]);
+  std::vector<int> pick;
+  for (int b = 0; b < B; ++b) {
+    const int T = row_offsets[b + 1] - row_offsets[b];
+    const int cnt = std::min(T - 1 - pl.right, info_.pool_right) - pool_first + 1;
+    if (T >= info_.min_frames && cnt >= mx_min_pooled_) pick.push_back(b);
+  }
+  if (pick.empty()) return c;
+  // packed copy of the picked chunks
+  const int D = info_.input_dim, E = info_.output_dim;
+  std::vector<float> f;
+  offs.assign(1, 0);
+  for (int b : pick) {
+    f.insert(f.end(), feats + (size_t)row_offsets[b] * D, feats + (size_t)row_offsets[b + 1] * D);
+    offs.push_back(offs.back() + (row_offsets[b + 1] - row_offsets[b]));
+  }
+  const int n = (int)pick.size();
+  const int before = fast_mode_;
+  std::vector<float> ref((size_t)n * E), mx((size_t)n * E), mx2((size_t)n * E);
+  try {
+    SetFastMode(kPrecFp16x3);
+    ForwardHost(f.data(), offs.data(), n, ref.data());
+    SetFastMode(kPrecFp16Mx);
+    ForwardHost(f.data(), offs.data(), n, mx.data());
+    SetFastMode(kPrecFp16Mx2);
+    ForwardHost(f.data(), offs.data(), n, mx2.data());
+  } catch (...) {
+    SetFastMode(before);
+    throw;
+  }
+  auto worst = [&](const std::vector<float>& got) {
+    float w = 0.f;
+    for (int i = 0; i < n; ++i) {
+      float d = 0.f, m = 0.f;
+      for (int k = 0; k < E; ++k) {
+        d = std::max(d, std::fabs(got[(size_t)i * E + k] - ref[(size_t)i * E + k]));
+        m = std::max(m, std::fabs(ref[(size_t)i * E + k]));
+      }
+      const float r = m > 0.f ? d / m : (d > 0.f ? INFINITY : 0.f);
+      w = std::isnan(r) ? INFINITY : std::max(w, r);
+    }
+    return w;
+  };
+  c.checked = n;
+  c.err_mx = worst(mx);
+  c.err_mx2 = worst(mx2);
+  c.chosen = c.err_mx <= tol ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
+  SetFastMode(c.chosen);
+  return c;
 }
 
 std::string Engine::ProfileReport() {

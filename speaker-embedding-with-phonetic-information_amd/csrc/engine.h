@@ -119,6 +119,27 @@ class Engine {
   void FrontEndHost(const float* raw, const int32_t* raw_off, int n_utts, const int32_t* sel_row, const int32_t* sel_utt,
                     int n_out, int cmn_window, bool center, int min_window, float* out);
 
+  // ---- calibrated arithmetic (contexts packed as kPrecFp16Mx2, pooled output) ----------------------------------------
+  // The packed image of kPrecFp16Mx2 holds everything the lighter kPrecFp16Mx arithmetic needs (and the three-pass
+  // one), so one context can run any of the three on its fast chunks:
+  //   kPrecFp16Mx2  what the image was packed for: 1.5 MFMA passes, error independent of the model (the state after creation)
+  //   kPrecFp16Mx   1.25 passes, no activation residual planes; meets the bar on some models only - chunks that pool >= 300 frames
+  //   kPrecFp16x3   every chunk in the three-pass arithmetic
+  // Calibrate() measures, on the caller's own chunks, the embeddings of the two fast modes against the three-pass ones and
+  // switches the context to kPrecFp16Mx when its worst relative error stays within `tol`, else keeps kPrecFp16Mx2 (or drops
+  // to kPrecFp16x3 when even that exceeds 1e-4).  Only chunks that pool >= 300 frames count (the others run three-pass in
+  // kPrecFp16Mx anyway).  Synchronous; results of later calls are bit-reproducible for a given choice.
+  struct Calibration {
+    int chosen = 0;           // kPrecFp16Mx / kPrecFp16Mx2 / kPrecFp16x3 (or the context's precision when it cannot switch)
+    int checked = 0;          // chunks that entered the comparison
+    float err_mx = 0.f;       // worst max|d| / max|ref| of kPrecFp16Mx over them
+    float err_mx2 = 0.f;      // the same for kPrecFp16Mx2
+  };
+  bool can_switch_fast_mode() const { return info_.precision == kPrecFp16Mx2 && !frame_mode_; }
+  int fast_mode() const { return can_switch_fast_mode() ? fast_mode_ : info_.precision; }
+  void SetFastMode(int mode);   // throws unless can_switch_fast_mode() and mode is one of the three
+  Calibration Calibrate(const float* feats, const int32_t* row_offsets, int B, float tol);
+
   hipStream_t stream() const { return stream_; }
   int num_lanes() const { return (int)lanes_.size(); }
   // last forward's per-kernel launch list (name, m_tiles*n_tiles) for logging / tests
@@ -213,6 +234,8 @@ class Engine {
   bool fast_mx_ = false;
   bool fast_mx2_ = false;   // kPrecFp16Mx2: every frame-level layer of a fast chunk runs it (or kPrecFp16x3E on the input)
   int fast_min_pooled_ = 0;
+  int fast_mode_ = 0;       // see SetFastMode
+  int mx2_min_pooled_ = 0, mx_min_pooled_ = 0;   // thresholds of the two fast modes (XVEC_FAST_MIN_POOLED overrides both)
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;   // host-slot uploads (SubmitHost)
   void* d_blob_ = nullptr;

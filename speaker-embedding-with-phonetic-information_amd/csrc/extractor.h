@@ -44,6 +44,11 @@ struct ExtractOptions {
   int backend_t_rows = 0, backend_t_cols = 0;
   bool backend_normalize = false;
   bool backend_scaleup = true;
+  // table jobs: before the first batch, Engine::Calibrate on the first chunk of the first calibrate_utts utterances (contexts
+  // that can switch their arithmetic: packed as fp16mx2; see engine.h)
+  bool calibrate = false;
+  float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
+  int calibrate_utts = 64;
 };
 
 // feats: packed host rows; utterance u = rows row_offsets[u] .. row_offsets[u+1]-1.

@@ -217,6 +217,8 @@ __device__ __forceinline__ void mfma16_f16_inplace(s16x8 a, s16x8 b, f32x4& c) {
 struct EpiRegs {
   float bs[16], sc[16], of[16];   // act / f32: index p*4 + r;  stats: index q (one column per 16-column fragment)
   int first[4], last[4];          // stats: valid rows [first, last) of the four 16-row fragments p
+  unsigned rng[2];                // planes epilogue with group maxima: the same for the four groups q, bytes first / last of
+                                  // group q in bits 16 (q & 1) .. of word q >> 1 (one 8-byte load, two registers)
 };
 
 template <int EPI>
@@ -245,12 +247,13 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
       }
     }
     if (EPI == kEpiAct && a.gmax_out) {
-      // rows of the four 16-row groups q that count for the group maxima
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int grp = (mbase + q * 16) >> 4;
-        e.first[q] = a.out_range ? a.out_range[2 * grp] : 0;
-        e.last[q] = a.out_range ? a.out_range[2 * grp + 1] : 16;
+      // rows of the four 16-row groups q that count for the group maxima: [grp][first, last) bytes, 8 contiguous ones
+      // (mbase is a multiple of 64 rows, the table 8-byte aligned)
+      e.rng[0] = e.rng[1] = 0x10001000u;
+      if (a.out_range) {
+        const uint2 v = *(const uint2*)(a.out_range + 2 * (mbase >> 4));
+        e.rng[0] = v.x;
+        e.rng[1] = v.y;
       }
     }
   } else if constexpr (EPI == kEpiStats) {
@@ -298,11 +301,13 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
       }
     }
     if (EPI == kEpiAct && a.gmax_out) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int grp = (mbase + q * 16) >> 4;
-        e.first[q] = a.out_range ? a.out_range[2 * grp] : 0;
-        e.last[q] = a.out_range ? a.out_range[2 * grp + 1] : 16;
+      // rows of the four 16-row groups q that count for the group maxima: [grp][first, last) bytes, 8 contiguous ones
+      // (mbase is a multiple of 64 rows, the table 8-byte aligned)
+      e.rng[0] = e.rng[1] = 0x10001000u;
+      if (a.out_range) {
+        const uint2 v = *(const uint2*)(a.out_range + 2 * (mbase >> 4));
+        e.rng[0] = v.x;
+        e.rng[1] = v.y;
       }
     }
   } else if constexpr (EPI == kEpiStats) {
@@ -423,7 +428,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
           float m = fmaxf(gm[q], ymax);
           gm[q] = m;
           if (gm_phase != 1) {
-            if (fr_i < e.first[q] || fr_i >= e.last[q]) m = 0.f;
+            const int first_q = (int)((e.rng[q >> 1] >> (16 * (q & 1))) & 255u), last_q = (int)((e.rng[q >> 1] >> (16 * (q & 1) + 8)) & 255u);
+            if (fr_i < first_q || fr_i >= last_q) m = 0.f;
             const unsigned u = wave_max_u32(__builtin_bit_cast(unsigned, m));
             if (lane == 0)
               (void)__hip_atomic_fetch_max(a.gmax_out + ((mbase + q * 16) >> 4), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

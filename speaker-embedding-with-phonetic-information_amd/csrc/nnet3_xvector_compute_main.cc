@@ -68,9 +68,12 @@ const char* kUsage =
     "  --pad-input=true|false           pad short chunks by edge replication instead of skipping (default true)\n"
     "  --output-node=<name>             compute this node as the output (native form of nnet3-copy --nnet-config)\n"
     "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
-    "  --precision=fp16mx2|fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
-    "                                   arithmetic of the MFMA GEMMs.  Default: fp16mx2 where every layer can run it, else\n"
-    "                                   fp16x3 (nnet3-compute: always fp16x3).  fp16x3: split fp16, three MFMAs per\n"
+    "  --precision=default|fp16mx2|fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
+    "                                   arithmetic of the MFMA GEMMs.  default: fp16mx2 where every layer can run it, else\n"
+    "                                   fp16x3 (nnet3-compute: always fp16x3) - and, unless --calibrate=false, the lighter\n"
+    "                                   fp16mx where the job's own first utterances show it within --calibrate-tol of the\n"
+    "                                   three-pass arithmetic (one log line says what was measured and chosen).\n"
+    "                                   fp16x3: split fp16, three MFMAs per\n"
     "                                   product, fp32-grade (3e-7..4e-6 from the fp32 oracle).  fp16mx2: fp16 product +\n"
     "                                   two block-scaled 4-bit products that correct the fp16 rounding of the weights\n"
     "                                   and of the activations, 1.5 passes, ~1.4x faster: 3-5.5e-5 on every model\n"
@@ -79,6 +82,10 @@ const char* kUsage =
     "                                   fp16x3), the others fp16x3; its error is the activation rounding averaged by the\n"
     "                                   pooling - 5-8e-5 on models with Kaldi-initialisation-like weights, 1-2e-4 on\n"
     "                                   heavy-tailed ones (DESIGN.md section 3.0): check it on your model first.\n"
+    "  --calibrate=true|false --calibrate-tol=<float>\n"
+    "                                   with --precision=default (default true, 7.5e-5): before the first batch, the first chunk of\n"
+    "                                   the first 64 utterances is computed in fp16x3, fp16mx and fp16mx2; fp16mx is used\n"
+    "                                   for the job when its worst embedding error against fp16x3 is within the tolerance\n"
     "  --fast-min-pooled=<int>          auto / fp16mx2: chunks that pool at least this many frames take the fast\n"
     "                                   kernels (default 300 / 160, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
@@ -102,6 +109,8 @@ struct Options {
   std::string precision = "default";
   int batch_frames = 1 << 17;
   int fast_min_pooled = -1;
+  bool calibrate = true;
+  float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
   int device = -1;
   bool print_args = true;
   int cmn_window = 0;
@@ -172,6 +181,19 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   else if (name == "min-chunk-size") return need_int(&o->min_chunk_size);
   else if (name == "batch-frames") return need_int(&o->batch_frames);
   else if (name == "fast-min-pooled") return need_int(&o->fast_min_pooled);
+  else if (name == "calibrate") {
+    if (!ParseBool(value, &o->calibrate)) {
+      *err = "invalid boolean for --calibrate: " + value;
+      return false;
+    }
+  } else if (name == "calibrate-tol") {
+    char* end = nullptr;
+    o->calibrate_tol = strtof(value.c_str(), &end);
+    if (!has_value || end == value.c_str() || *end || !(o->calibrate_tol > 0.f)) {
+      *err = "invalid value for --calibrate-tol: " + value;
+      return false;
+    }
+  }
   else if (name == "device") return need_int(&o->device);
   else if (name == "cmn-window") return need_int(&o->cmn_window);
   else if (name == "vad-rspecifier") o->vad_rspecifier = value;
@@ -332,8 +354,9 @@ int main(int argc, char** argv) {
     }
     if (device >= ndev) device %= ndev;
     if (opt.fast_min_pooled >= 0) setenv("XVEC_FAST_MIN_POOLED", std::to_string(opt.fast_min_pooled).c_str(), 1);   // read by the engine
+    const bool policy_default = opt.precision == "default";
     const std::vector<uint8_t> blob = xv::PackModelPolicy(prog, precision, &precision);
-    if (opt.precision == "default") opt.precision = std::string("default = ") + xv::PrecisionName(precision);
+    if (policy_default) opt.precision = std::string("default = ") + xv::PrecisionName(precision);
     xv::Engine engine(blob.data(), blob.size(), device);
     XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
@@ -382,6 +405,8 @@ int main(int argc, char** argv) {
     eo.cmn_window = opt.cmn_window;
     eo.cmn_center = opt.cmn_center;
     eo.vad_rspecifier = opt.vad_rspecifier;
+    eo.calibrate = policy_default && opt.calibrate && !g_frame_job;   // no-op unless the context can switch (fp16mx2)
+    eo.calibrate_tol = opt.calibrate_tol;
     if (!opt.backend_mean.empty()) xv::ReadVectorObject(opt.backend_mean, &eo.backend_mean);
     if (!opt.backend_transform.empty()) {
       xv::Matrix t;

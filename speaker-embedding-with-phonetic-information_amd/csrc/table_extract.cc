@@ -29,6 +29,82 @@ struct Batch {
 };
 }  // namespace
 
+Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& opt, const std::vector<CalibUtt>& utts,
+                                          const LogFn& log) {
+  Engine::Calibration c;
+  c.chosen = engine->fast_mode();
+  if (!engine->can_switch_fast_mode()) return c;
+  const int D = engine->info().input_dim;
+  std::unique_ptr<RandomAccessVectorReader> vad;
+  if (!opt.vad_rspecifier.empty()) vad.reset(new RandomAccessVectorReader(opt.vad_rspecifier));
+  const bool use_frontend = opt.cmn_window > 0 || vad;
+  std::vector<float> feats;
+  std::vector<int32_t> offs(1, 0);
+  for (size_t i = 0; i < utts.size() && (int)i < opt.calibrate_utts; ++i) {   // the first calibrate_utts utterances of the list, whoever calls
+    const CalibUtt& u = utts[i];
+    if (u.rows <= 0 || u.cols != D) continue;
+    std::vector<float> tmp;
+    const float* rows = u.data;
+    int T = u.rows;
+    if (use_frontend) {
+      const std::vector<float>* v = nullptr;
+      if (vad) {
+        if (!vad->HasKey(*u.key)) continue;
+        v = &vad->Value(*u.key);
+        if ((int)v->size() != T) continue;
+      }
+      std::vector<int32_t> sel_row, sel_utt, raw_off = {0, T};
+      for (int t = 0; t < T; ++t)
+        if (!v || (*v)[t] != 0.f) {
+          sel_row.push_back(t);
+          sel_utt.push_back(0);
+        }
+      if (sel_row.empty()) continue;
+      tmp.resize(sel_row.size() * (size_t)D);
+      engine->FrontEndHost(u.data, raw_off.data(), 1, sel_row.data(), sel_utt.data(), (int)sel_row.size(), opt.cmn_window,
+                           opt.cmn_center, opt.cmn_min_window, tmp.data());
+      rows = tmp.data();
+      T = (int)sel_row.size();
+    }
+    const int len = (opt.chunk_size > 0 && T > opt.chunk_size) ? opt.chunk_size : T;   // the utterance's first chunk
+    if (len < engine->info().min_frames || (long)offs.back() + len > opt.max_batch_rows) continue;
+    feats.insert(feats.end(), rows, rows + (size_t)len * D);
+    offs.push_back(offs.back() + len);
+  }
+  const int n = (int)offs.size() - 1;
+  if (n > 0) c = engine->Calibrate(feats.data(), offs.data(), n, opt.calibrate_tol);
+  std::ostringstream m;
+  m.precision(3);
+  if (c.checked == 0) {
+    m << "calibration: none of the first " << utts.size() << " utterances has a chunk long enough for the fp16mx arithmetic; keeping "
+      << PrecisionName(c.chosen);
+  } else {
+    m << "calibration on " << c.checked << " chunks against the three-pass arithmetic: fp16mx " << c.err_mx << ", fp16mx2 " << c.err_mx2
+      << " (tolerance " << opt.calibrate_tol << ") -> " << PrecisionName(c.chosen);
+  }
+  log("LOG", m.str());
+  return c;
+}
+
+Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec, const LogFn& log) {
+  std::vector<std::string> keys;
+  std::vector<Matrix> mats;
+  {
+    SequentialMatrixReader rd(feat_rspec);
+    std::string key, e;
+    Matrix m;
+    while ((int)keys.size() < opt.calibrate_utts && rd.Next(&key, &m, &e)) {
+      if (!e.empty()) continue;
+      keys.push_back(key);
+      mats.push_back(std::move(m));
+    }
+    // (the reader is closed here; for a pipe that ends the producer early, which is what a "head" of the list wants)
+  }
+  std::vector<CalibUtt> utts;
+  for (size_t i = 0; i < keys.size(); ++i) utts.push_back(CalibUtt{&keys[i], mats[i].data.data(), mats[i].rows, mats[i].cols});
+  return CalibrateOnUtterances(engine, opt, utts, log);
+}
+
 TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec,
                                       const std::string& vec_wspec, const LogFn& log) {
   TableExtractResult res;
@@ -141,6 +217,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   Work work[Engine::kNumHostSlots];
   int cur = 0;
   long seq = 0;
+  bool calibrated = false;
   constexpr int NS = Engine::kNumHostSlots;
   // stage timing of the consumer thread (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
   const bool timing = getenv("XVEC_TIMING") != nullptr;
@@ -187,18 +264,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
     w.b = Batch();
   };
 
-  for (;;) {
-    Batch b;
-    const auto tw0 = now();
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return !queue.empty(); });
-      b = std::move(queue.front());
-      queue.pop_front();
-      cv.notify_all();
-    }
-    t_wait += secs(tw0, now());
-    const bool last = b.last;
+  auto process = [&](Batch&& b) {
     if (!b.utts.empty() && fatal.empty()) {
       try {
         const auto tp0 = now();
@@ -316,6 +382,45 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       } catch (const std::exception& ex) {
         fatal = ex.what();  // keep draining the queue so the reader can finish
       }
+    }
+  };
+  // With calibration the arithmetic of the whole job is chosen on the first calibrate_utts utterances of the TABLE, before
+  // anything is submitted: batches are held back until that many utterances have arrived (whatever the batch size, so
+  // that the choice - and with it every embedding - does not depend on --batch-frames).
+  std::deque<Batch> held;
+  size_t held_utts = 0;
+  for (;;) {
+    Batch b;
+    const auto tw0 = now();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !queue.empty(); });
+      b = std::move(queue.front());
+      queue.pop_front();
+      cv.notify_all();
+    }
+    t_wait += secs(tw0, now());
+    const bool last = b.last;
+    if (opt.calibrate && !calibrated) {
+      held_utts += b.utts.size();
+      held.push_back(std::move(b));
+      if (held_utts >= (size_t)opt.calibrate_utts || last) {
+        calibrated = true;
+        if (fatal.empty()) {
+          try {
+            std::vector<CalibUtt> cu;
+            for (const Batch& hb : held)
+              for (const Utt& u : hb.utts) cu.push_back(CalibUtt{&u.key, u.feats.data.data(), u.feats.rows, u.feats.cols});
+            if (!cu.empty()) CalibrateOnUtterances(engine, opt, cu, log);
+          } catch (const std::exception& ex) {
+            fatal = ex.what();
+          }
+        }
+        for (Batch& hb : held) process(std::move(hb));
+        held.clear();
+      }
+    } else {
+      process(std::move(b));
     }
     if (last) break;
   }

@@ -25,6 +25,21 @@ typedef std::function<void(const char* level, const std::string& msg)> LogFn;
 TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
                                       const std::string& vector_wspecifier, const LogFn& log);
 
+// Engine::Calibrate on the first chunk of up to opt.calibrate_utts utterances: (key, rows, row-major data) triples as the
+// readers deliver them.  The device front-end of opt (sliding CMN, VAD selection) is applied first, like the job will.
+// Utterances the job would skip (wrong dimension, no VAD entry) are skipped here.  Logs one line with the outcome.
+struct CalibUtt {
+  const std::string* key;
+  const float* data;
+  int rows, cols;
+};
+Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& opt, const std::vector<CalibUtt>& utts,
+                                          const LogFn& log);
+// The same on the first opt.calibrate_utts utterances of a feature table (multi-GPU jobs: one rank calibrates on the head of
+// the WHOLE list and the choice is applied on every rank, so that an N-way sharded job computes what the 1-way job does).
+Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
+                                     const LogFn& log);
+
 // nnet3-compute style job: one output MATRIX per utterance (a row per input frame) from a frame-level model
 // (reference call sites: sid/nnet3_cvector/cvector/extract_log_post.sh:77-84, sid/nnet3_cvector/am/extract_bn.sh:68,
 // steps/nnet3/make_bottleneck_features_new.sh:109).  apply_exp turns log-posteriors into posteriors (--apply-exp).

@@ -53,6 +53,11 @@ def main(argv=None):
                     choices=["default", "bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "fp16mx2", "auto"],
                     help="default = the policy of nnet3-xvector-compute (XV_PREC_DEFAULT): fp16mx2 where every layer can run it, "
                          "else fp16x3; the others are opt-in")
+    ap.add_argument("--calibrate", default="true",
+                    help="with --precision default: rank 0 measures fp16mx / fp16mx2 against fp16x3 on the first chunk of the first 64 "
+                         "utterances of the WHOLE list and every rank runs the arithmetic it chose (what nnet3-xvector-compute does "
+                         "on its own list; an N-way job therefore computes what the 1-way job computes)")
+    ap.add_argument("--calibrate-tol", type=float, default=7.5e-5)
     ap.add_argument("--force-device", type=int, default=None,
                     help="HIP device every rank uses instead of LOCAL_RANK (ranks sharing one GPU: the recipes' nj > #GPUs "
                          "launch mode, and how the N > 1 path is exercised on a one-GPU box with --backend gloo)")
@@ -134,19 +139,41 @@ def main(argv=None):
     ark = os.path.join(args.out_dir, "xvector_%s.%d.ark" % (args.name, job))
     scp = os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, job))
     done = failed = error = 0
+    ctx = None
+    mode = torch.tensor([-1], dtype=torch.int64, device=dev)
     try:
-        if args.dry_run:
+        if not args.dry_run:
+            if use_cuda:
+                # the image the broadcast left in this GPU's memory is used where it is: no host round trip
+                ctx = P.Context(device_blob=(wt.data_ptr(), wt.numel()), device=local_rank)
+            else:
+                ctx = P.Context(blob=wt.numpy().tobytes(), device=local_rank)
+            if rank == 0 and args.precision == "default" and args.calibrate.lower() in ("true", "t", "1") and lines:
+                head = os.path.join(args.out_dir, "feats_%s.head.scp" % args.name)
+                with open(head, "w") as f:
+                    f.writelines(lines[:64])
+                hspec = ("ark:" + args.feat_pipe.replace("SCP", head)) if args.feat_pipe else ("scp:" + head)
+                cal = ctx.calibrate_table(hspec, args.chunk_size, args.min_chunk_size, args.pad_input.lower() in ("true", "t", "1"),
+                                          64, args.calibrate_tol)
+                print("rank 0 calibration: %s" % cal, flush=True)
+                mode[0] = P.PRECISIONS[cal["chosen"]]
+    except Exception as e:   # noqa: BLE001 - counted below with the extraction errors
+        print("ERROR (dist_extract) rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
+        error = 1
+    if grouped and not args.dry_run:
+        dist.broadcast(mode, 0)          # one integer: the arithmetic rank 0 chose (bookkeeping, not a data-path collective)
+    try:
+        if ctx is not None and not error and int(mode[0]) >= 0 and rank != 0:
+            ctx.set_fast_mode(P.PRECISION_NAMES[int(mode[0])])
+        if error:
+            pass
+        elif args.dry_run:
             import hashlib
             host = wt.cpu().numpy().tobytes()
             print("rank %d/%d: blob %d bytes sha1 %s, utterances [%d, %d)" % (rank, world, len(host),
                                                                           hashlib.sha1(host).hexdigest(), lo, hi), flush=True)
             open(scp, "w").writelines("%s DRYRUN\n" % l.split()[0] for l in lines[lo:hi])
         elif hi > lo:
-            if use_cuda:
-                # the image the broadcast left in this GPU's memory is used where it is: no host round trip
-                ctx = P.Context(device_blob=(wt.data_ptr(), wt.numel()), device=local_rank)
-            else:
-                ctx = P.Context(blob=wt.numpy().tobytes(), device=local_rank)
             done, failed = ctx.extract_table(rspec, "ark,scp:%s,%s" % (ark, scp), args.chunk_size, args.min_chunk_size,
                                              args.pad_input.lower() in ("true", "t", "1"))
         else:

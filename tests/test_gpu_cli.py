@@ -187,7 +187,8 @@ def test_cli_precision_modes(job):
     n2 = ev.net
     ev64 = H.xo.GraphEvaluator(n2, np.float64)
     res = {}
-    for tag, extra in (("default", []), ("fp16mx2", ["--precision=fp16mx2"]), ("auto", ["--precision=auto"]),
+    logs = {}
+    for tag, extra in (("default", []), ("default_nocal", ["--calibrate=false"]), ("fp16mx2", ["--precision=fp16mx2"]), ("auto", ["--precision=auto"]),
                        ("fp16x3", ["--precision=fp16x3"]),
                        ("bf16x3", ["--precision=bf16x3"]), ("fp16mx", ["--precision=fp16mx"]),
                        ("auto_all_slow", ["--precision=auto", "--fast-min-pooled=100000"]),
@@ -197,21 +198,28 @@ def test_cli_precision_modes(job):
                   "--output-node=tdnn6.affine"] + extra + [str(d / "final.raw"), "ark:%s/feats.ark" % d, "ark:%s" % ark])
         assert r.returncode == 0, r.stderr.decode()
         res[tag] = dict(kio.read_ark(str(ark), "vector"))
+        logs[tag] = r.stderr.decode()
     for k, x in utts:
         ref = H.xo.extract_xvector(ev64, x, 10000, 25, True)
         if ref is None:
             continue
         for tag in ("auto", "fp16x3", "bf16x3", "default"):
             assert H.rel_err(res[tag][k][None], ref[None]) < TOL, (tag, k)
-        assert H.rel_err(res["default"][k][None], ref[None]) < 6e-5, k
+        assert H.rel_err(res["default"][k][None], ref[None]) < 9e-5, k
+        assert H.rel_err(res["default_nocal"][k][None], ref[None]) < 6e-5, k
+    # the default on this (initialisation-like) model: calibrated on the head of the table, fp16mx is within 7.5e-5 of the
+    # three-pass arithmetic there and is what the job runs (= --precision=auto); --calibrate=false keeps fp16mx2
+    assert "calibration on" in logs["default"] and "-> fp16mx" in logs["default"] and "-> fp16mx2" not in logs["default"], logs["default"]
+    assert "calibration" not in logs["fp16mx2"]
     for k, x in utts:
         if k not in res["fp16x3"]:
             continue
-        assert np.array_equal(res["default"][k], res["fp16mx2"][k])               # the default IS fp16mx2 ...
+        assert np.array_equal(res["default"][k], res["auto"][k])
+        assert np.array_equal(res["default_nocal"][k], res["fp16mx2"][k])
         if 25 <= x.shape[0] < 170:
-            assert np.array_equal(res["default"][k], res["fp16x3"][k])            # ... whose short chunks (< 160 pooled frames) take fp16x3
+            assert np.array_equal(res["fp16mx2"][k], res["fp16x3"][k])            # short chunks (< 160 pooled frames) take fp16x3
         if x.shape[0] >= 180:
-            assert not np.array_equal(res["default"][k], res["fp16x3"][k])
+            assert not np.array_equal(res["fp16mx2"][k], res["fp16x3"][k])
     long_k = [k for k, x in utts if x.shape[0] >= 330]          # 400, 1000, 333 frames: fast kernels in auto
     short_k = [k for k, x in utts if 25 <= x.shape[0] < 300]    # 137, 25 frames: three-pass in auto
     assert long_k and short_k

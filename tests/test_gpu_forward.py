@@ -360,3 +360,39 @@ def test_full_size_batch_properties(topology, mode):
     if mode == "default":
         assert ctx.precision == P.PREC_FP16MX2
         assert "tdnn_gemm_kernel_sk<fp16mx2,stats,8>" in ran, ran
+
+
+def test_calibration_picks_the_lighter_mode_only_where_it_is_accurate():
+    """XV_PREC_DEFAULT + xv_ctx_calibrate (what the command-line tools do on the head of their table): on the
+    initialisation-like model fp16mx stays within 7.5e-5 of the three-pass arithmetic and is chosen; on the heavy-tailed,
+    BatchNorm-calibrated model it is at 1 - 2e-4 and the context stays in fp16mx2.  After the call the context computes
+    exactly what a context of the chosen mode computes, and every embedding is within the parity bar of the fp64 oracle."""
+    P = H.pkg()
+    for which, want in (("init", "fp16mx"), ("trained", "fp16mx2")):
+        net, line = H.synth_model("v2_xvector", 123) if which == "init" else H.trained_like_model("v2_xvector", 11)
+        model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+        utts = [H.features(60 + i, T) for i, T in enumerate([400, 400, 333, 400, 120, 400])]
+        feats, offs = H.pack(utts)
+        ctx = P.Context(model)                          # XV_PREC_DEFAULT -> packed as fp16mx2
+        assert ctx.precision == P.PREC_FP16MX2 and ctx.fast_mode == "fp16mx2"
+        cal = ctx.calibrate(feats, offs)                # default tolerance: 7.5e-5 on the worst chunk
+        print(which, cal)
+        assert cal["chosen"] == want and ctx.fast_mode == want, cal
+        assert cal["checked"] == 5                      # the 120-frame chunk pools < 300 frames: not compared
+        assert cal["err_mx2"] < 6e-5 and (cal["err_mx"] <= 7.5e-5) == (want == "fp16mx"), cal
+        out = ctx.forward_batch(feats, offs)
+        same = P.Context(model, precision=P.PRECISIONS["auto" if want == "fp16mx" else "fp16mx2"]).forward_batch(feats, offs)
+        assert np.array_equal(out, same)
+        ev64 = _oracle(net, line, np.float64)
+        for i, u in enumerate(utts):
+            assert H.rel_err(out[i:i + 1], ev64.compute(u)) < TOL_PARITY, (which, i)
+        # a choice made elsewhere (the other ranks of a multi-GPU job) is applied with set_fast_mode
+        other = P.Context(model)
+        other.set_fast_mode(want)
+        assert np.array_equal(other.forward_batch(feats, offs), out)
+    # contexts that cannot switch say so and stay what they are
+    c3 = P.Context(model, precision=P.PREC_FP16X3)
+    cal = c3.calibrate(feats, offs)
+    assert cal["checked"] == 0 and cal["chosen"] == "fp16x3"
+    with pytest.raises(P.XvError):
+        c3.set_fast_mode("fp16mx")
