@@ -36,15 +36,17 @@ def main():
         if not os.path.exists(p):
             continue
         rows = [r for r in csv.DictReader(open(p)) if "xv::" in r["Kernel_Name"]]
-        # dispatches of the last complete step: find the last prep_input
-        idx = max(i for i, r in enumerate(rows) if "prep_input" in r["Kernel_Name"])
-        step = rows[idx:]
+        # dispatches of the last complete step: a forward pass ends with the split-K reduction of the embedding layer or, for
+        # frame-level outputs, with frame_output
+        ends = [i for i, r in enumerate(rows) if "splitk_reduce" in r["Kernel_Name"] or "frame_output" in r["Kernel_Name"]]
+        step = rows[ends[-2] + 1:ends[-1] + 1]
         per[c] = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), float(r["Counter_Value"]),
                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in step]
     if len(per) == 2:
         lines = ["# HBM traffic per kernel, one bench step (%s)" % tag, "",
                  "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes; reads x2 (gfx950 FETCH_SIZE",
-                 "counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM; prep_input reads a known 9.42 MB and reports 4.7 MB).", "",
+                 "counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM; checked in round 1 on prep_input, which read a known 9.42 MB",
+                 "and reported 4.7 MB).", "",
                  "| # | kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes (2*fetch+write) | duration us |", "|---|---|---|---|---|---|"]
         # per kernel instantiation, under the name bench.py's roofline uses (engine profile labels, kernels.hip note_kernel)
         prec = ["bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e"]   # kernels.hip prec_name
@@ -60,9 +62,11 @@ def main():
                 by.setdefault(name, []).append(b)
         open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
         if by:
-            json.dump({"hbm_bytes_per_launch": {k: sum(v) / len(v) for k, v in by.items()},
-                       "launches_per_step": {k: len(v) for k, v in by.items()}, "source": tag + "_pmc_hbm.md"},
-                      open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+            out = {"hbm_bytes_per_launch": {k: sum(v) / len(v) for k, v in by.items()},
+                   "launches_per_step": {k: len(v) for k, v in by.items()}, "source": tag + "_pmc_hbm.md"}
+            json.dump(out, open(os.path.join(prof, tag + "_pmc_traffic.json"), "w"), indent=1)
+            if len(sys.argv) > 3 and sys.argv[3] == "main":   # what bench.py's roofline.traffic reads
+                json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     sq = os.path.join(d, "pmc_sq", "bench_counter_collection.csv")
     if os.path.exists(sq):
         import collections
@@ -74,7 +78,9 @@ def main():
                                                   "vgpr": r["VGPR_Count"], "lds": r["LDS_Block_Size"], "grid": r["Grid_Size"]})
             e[r["Counter_Name"]] = float(r["Counter_Value"])
         last = list(disp.values())
-        idx = max(i for i, e in enumerate(last) if "prep_input" in e["name"])
+        ends = [i for i, e in enumerate(last) if "splitk_reduce" in e["name"] or "frame_output" in e["name"]]
+        idx = ends[-2] + 1
+        last = last[:ends[-1] + 1]
         lines = ["# SQ counters per kernel, one bench step (%s)" % tag, "",
                  "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES",
                  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, no tracing).",

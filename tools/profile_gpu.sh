@@ -1,23 +1,21 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one bench configuration on the GPU box (run through gpurun):
-#   tools/profile_gpu.sh [kt] [hbm] [sq] [bench]     (default: all)
-# Output under gpurun_out/prof/; summarise with  python tools/parse_rocprof.py gpurun_out/prof <tag>.
+#   tools/profile_gpu.sh <name> [bench.py arguments of the configuration ...]
+# Output under gpurun_out/prof_<name>/; summarise with  python tools/parse_rocprof.py gpurun_out/prof_<name> <tag>.
 # Counters are collected in their own passes, never together with tracing (MI355X_MICROARCH.md, HBM section).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-P=$R/gpurun_out/prof
+name=${1:-main}; shift
+P=$R/gpurun_out/prof_$name
 mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
-what=${*:-kt hbm sq bench}
-B="$R/bench.py --no-cpu-baseline --no-extra-modes"
-for w in $what; do
-  case $w in
-    kt) rocprofv3 --kernel-trace --stats --output-format csv -d "$P/kt" -o bench -- python3 $B --steps 20 --warmup 4 > "$P/kt_bench.log" 2>&1 ;;
-    hbm) for c in FETCH_SIZE WRITE_SIZE; do
-           rocprofv3 --pmc $c --output-format csv -d "$P/pmc_$c" -o bench -- python3 $B --steps 3 --warmup 1 > "$P/pmc_$c.log" 2>&1
-         done ;;
-    sq) rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
-          --output-format csv -d "$P/pmc_sq" -o bench -- python3 $B --steps 3 --warmup 1 > "$P/pmc_sq.log" 2>&1 ;;
-    bench) python3 $R/bench.py > "$P/bench_default.json" 2> "$P/bench_default.err" ;;
-  esac
+B="$R/bench.py --no-cpu-baseline --no-extra-modes $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$P/kt" -o bench -- python3 $B --steps 20 --warmup 4 > "$P/kt_bench.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$P/pmc_$c" -o bench -- python3 $B --steps 3 --warmup 1 > "$P/pmc_$c.log" 2>&1
 done
-ls -R "$P" | head -40
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+  --output-format csv -d "$P/pmc_sq" -o bench -- python3 $B --steps 3 --warmup 1 > "$P/pmc_sq.log" 2>&1
+if [ "$name" = main ]; then python3 $R/bench.py "$@" > "$P/bench_default.json" 2> "$P/bench_default.err"; fi
+# the raw traces are large: keep the summaries only
+find "$P" -name "*kernel_trace.csv" -size +8M -delete
+ls -R "$P" | head -30
