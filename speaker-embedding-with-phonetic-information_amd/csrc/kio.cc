@@ -1,6 +1,8 @@
 // kio - Kaldi table / object I/O without Kaldi.  See kio.h for what it replaces and why.
 #include "kio.h"
 
+#include <sys/stat.h>
+
 #include <ctype.h>
 #include <errno.h>
 #include <math.h>
@@ -70,6 +72,21 @@ void Input::Seek(long offset) {
     return;
   }
   if (!f_ || is_pipe_ || is_stdin_ || fseek(f_, offset, SEEK_SET) != 0) throw KioError("cannot seek in " + name_);
+}
+
+bool Input::IsRegularFile() const {
+  if (!f_ || is_pipe_ || is_stdin_) return false;
+  struct stat st;
+  return fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+long Input::FileTell() {
+  if (!IsRegularFile()) throw KioError("not a regular file: " + name_);
+  return ftell(f_);
+}
+
+void Input::Skip(long n) {
+  if (!IsRegularFile() || fseek(f_, n, SEEK_CUR) != 0) throw KioError("cannot seek in " + name_);
 }
 
 void Input::OpenMemory(const void* data, size_t n) {
@@ -393,6 +410,30 @@ static void ReadCompressed(Input& in, const std::string& tok, Matrix* m) {
   }
 }
 
+void SkipBinaryMatrix(Input& in, int* rows, int* cols) {
+  std::string tok;
+  ReadToken(in, true, &tok);
+  if (tok == "CM" || tok == "CM2" || tok == "CM3") {
+    struct {
+      float min_value, range;
+      int32_t rows, cols;
+    } h;
+    in.Read(&h, 16);
+    if (h.rows < 0 || h.cols < 0) throw KioError("bad compressed-matrix header");
+    *rows = h.rows;
+    *cols = h.cols;
+    const long total = (long)h.rows * h.cols;
+    in.Skip(tok == "CM" ? (long)h.cols * 8 + total : tok == "CM2" ? total * 2 : total);
+    return;
+  }
+  if (tok != "FM" && tok != "DM") throw KioError("expected FM/DM/CM, got " + tok + " in " + in.Name());
+  const int32_t r = ReadInt32(in, true), c = ReadInt32(in, true);
+  if (r < 0 || c < 0) throw KioError("negative matrix dimension");
+  *rows = r;
+  *cols = c;
+  in.Skip((long)r * c * (tok == "FM" ? 4 : 8));
+}
+
 void ReadMatrix(Input& in, bool binary, Matrix* m) {
   if (binary) {
     std::string tok;
@@ -651,6 +692,99 @@ bool SequentialMatrixReader::Next(std::string* key, Matrix* m, std::string* erro
 }
 
 int SequentialMatrixReader::Close() { return in_.Close(); }
+
+// "path:123" -> (path, 123); anything else -> offset -1
+static long SplitOffset(const std::string& rx, std::string* path) {
+  *path = rx;
+  size_t colon = rx.rfind(':');
+  if (!rx.empty() && rx.back() != '|' && colon != std::string::npos && colon + 1 < rx.size() &&
+      std::all_of(rx.begin() + colon + 1, rx.end(), [](char ch) { return isdigit((unsigned char)ch); })) {
+    *path = rx.substr(0, colon);
+    return strtol(rx.c_str() + colon + 1, nullptr, 10);
+  }
+  return -1;
+}
+
+MatrixTableIndexer::MatrixTableIndexer(const std::string& rspecifier) {
+  opts_ = ParseRspecifier(rspecifier);
+  const std::string rx = Trim(opts_.rxfilename);
+  if (rx.empty() || rx == "-" || rx.back() == '|') return;   // a stream: not addressable
+  in_.Open(opts_.rxfilename);
+  if (!in_.IsRegularFile()) return;
+  if (opts_.is_scp) {
+    usable_ = true;
+    return;
+  }
+  // archive: binary objects only (the first one decides; a text object later on is an error of the index pass)
+  const long start = in_.FileTell();
+  int c;
+  while ((c = in_.Peek()) >= 0 && isspace(c)) in_.Get();
+  while ((c = in_.Peek()) >= 0 && !isspace(c)) in_.Get();
+  if (c >= 0) in_.Get();
+  usable_ = in_.Peek() == 0 || in_.Peek() < 0;   // "\0B" follows the first key (or the archive is empty)
+  in_.Seek(start);
+}
+
+bool MatrixTableIndexer::Next(Entry* e) {
+  *e = Entry();
+  if (!ReadKey(in_, &e->key)) return false;
+  if (!opts_.is_scp) {
+    e->rx = in_.Name();
+    {
+      std::string p;
+      if (SplitOffset(e->rx, &p) >= 0) e->rx = p;   // "ark:file:offset" was opened at that offset
+    }
+    e->offset = in_.FileTell();
+    if (!ReadBinaryHeader(in_)) throw KioError("text object in a binary archive (key " + e->key + ") in " + in_.Name());
+    SkipBinaryMatrix(in_, &e->rows, &e->cols);
+    return true;
+  }
+  std::string rx;
+  int c;
+  while ((c = in_.Get()) >= 0 && c != '\n') rx.push_back((char)c);
+  rx = Trim(rx);
+  if (rx.empty()) {
+    e->error = "empty rxfilename for key " + e->key;
+    return true;
+  }
+  std::string path;
+  const long offset = SplitOffset(rx, &path);
+  e->rx = rx;
+  if (offset < 0) return true;   // pipe or whole file: the reading thread opens it
+  try {
+    if (!(path == data_path_ && data_in_.IsOpen())) {
+      data_in_.Open(path);
+      data_path_ = path;
+    }
+    data_in_.Seek(offset);
+    e->rx = path;
+    e->offset = offset;
+    if (ReadBinaryHeader(data_in_)) SkipBinaryMatrix(data_in_, &e->rows, &e->cols);   // text objects keep rows = -1
+  } catch (const KioError& ex) {
+    e->error = ex.what();
+    data_in_.Close();
+    data_path_.clear();
+  }
+  return true;
+}
+
+void ReadIndexedMatrix(const MatrixTableIndexer::Entry& e, Input* in, std::string* in_path, Matrix* m) {
+  if (e.offset < 0) {
+    Input one;
+    one.Open(e.rx);
+    const bool binary = ReadBinaryHeader(one);
+    ReadMatrix(one, binary, m);
+    one.Close();
+    return;
+  }
+  if (!(in->IsOpen() && *in_path == e.rx)) {
+    in->Open(e.rx);
+    *in_path = e.rx;
+  }
+  in->Seek(e.offset);
+  const bool binary = ReadBinaryHeader(*in);
+  ReadMatrix(*in, binary, m);
+}
 
 RandomAccessVectorReader::RandomAccessVectorReader(const std::string& rspecifier) {
   RspecifierOptions o = ParseRspecifier(rspecifier);

@@ -34,6 +34,9 @@ class Input {
   void Open(const std::string& rxfilename);
   void OpenMemory(const void* data, size_t n);
   void Seek(long offset);           // regular files / memory only
+  bool IsRegularFile() const;       // an fopen'ed regular file (seekable): not a pipe, FIFO, device or standard input
+  long FileTell();                  // regular files: current offset
+  void Skip(long n);                // regular files: move n bytes ahead without reading them
   bool IsOpen() const { return f_ != nullptr || mem_ != nullptr; }
   // Close; for pipes returns the child's exit status (0 otherwise).
   int Close();
@@ -99,6 +102,9 @@ struct Matrix {
 
 // Reads FM / DM / CM / CM2 / CM3 (binary) or " [ ... ]" (text).
 void ReadMatrix(Input& in, bool binary, Matrix* m);
+// Regular files, positioned behind the "\0B" of a binary matrix (FM / DM / CM / CM2 / CM3): reads the header only, reports the
+// dimensions and moves to the end of the object (the index pass of the parallel table readers).
+void SkipBinaryMatrix(Input& in, int* rows, int* cols);
 // Reads FV / DV (binary) or " [ ... ]" (text).
 void ReadVector(Input& in, bool binary, std::vector<float>* v);
 void WriteToken(Output& out, bool binary, const char* tok);
@@ -142,6 +148,34 @@ class SequentialMatrixReader {
   Input data_in_;    // scp mode: currently open data file
   std::string data_path_;
 };
+
+// Index pass over a matrix table whose objects can be addressed individually: binary archives in a regular file ("ark:file")
+// and script files whose entries are "path:offset" (or plain files).  Next() yields one entry without reading its data - key,
+// where the object starts, and (binary objects) its dimensions - so that several threads can read a table's matrices in
+// parallel and batches can be formed before the data is touched (table_extract.cc).  usable() is false for what can only
+// be read front to back (pipes, standard input, text archives): use SequentialMatrixReader there.
+class MatrixTableIndexer {
+ public:
+  struct Entry {
+    std::string key;
+    std::string rx;      // what to open: "path" (+ offset below) or a whole rxfilename (pipe, plain file) when offset < 0
+    long offset = -1;    // byte offset of the object (its "\0B") inside rx, or -1
+    int rows = -1, cols = -1;   // -1: not known without reading (text object, pipe)
+    std::string error;   // the entry could not be located (scp mode): skip it with a warning
+  };
+  explicit MatrixTableIndexer(const std::string& rspecifier);
+  bool usable() const { return usable_; }
+  bool Next(Entry* e);
+
+ private:
+  RspecifierOptions opts_;
+  Input in_;          // the archive, or the script file
+  Input data_in_;     // scp mode: the data file of the previous entry (consecutive entries usually share it)
+  std::string data_path_;
+  bool usable_ = false;
+};
+// Reads the matrix an index entry points to.  `in` / `in_path` cache the open data file between calls of one thread.
+void ReadIndexedMatrix(const MatrixTableIndexer::Entry& e, Input* in, std::string* in_path, Matrix* m);
 
 // Sequential reader of a table of float vectors ("ark:..." or "scp:...").  A corrupt archive is fatal (KioError),
 // an unreadable scp entry is reported through `error` and reading continues.

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <thread>
@@ -131,7 +132,33 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   bool stop = false;   // under mu: the consumer is gone, the reader must not block on a full queue
   auto warn = [&](const std::string& m) { log("WARNING", m); };
 
-  std::thread reader([&] {
+  // ---- feature ingestion --------------------------------------------------------------------------------------------
+  // Tables whose objects can be addressed (binary archive in a regular file, script file of path:offset entries) are read by
+  // several threads: one index pass forms the batches from the headers alone (MatrixTableIndexer: no data touched), the
+  // readers fill whole batches, a sequencer hands them to the consumer in table order.  One thread parsing 7 GB/s of
+  // archive was what the loop waited for 42 % of the time (round 2).  Streams (pipes, standard input - the feature
+  // pipeline of extract_xvectors_new.sh:79) can only be read front to back: one reader thread, as before.
+  // Everything that can fail on a user error happens before a thread exists (the indexer opens the table here).
+  const bool opt_is_scp = ParseRspecifier(feat_rspec).is_scp;
+  int n_readers = 4;
+  if (const char* e = getenv("XVEC_READERS")) n_readers = std::max(1, std::min(16, atoi(e)));
+  std::unique_ptr<MatrixTableIndexer> indexer;
+  if (n_readers > 1) {
+    indexer.reset(new MatrixTableIndexer(feat_rspec));
+    if (!indexer->usable()) indexer.reset();
+  }
+  struct PlanBatch {
+    long seq = 0;
+    std::vector<MatrixTableIndexer::Entry> entries;
+    bool last = false;
+  };
+  std::deque<PlanBatch> plans;          // under mu: index pass -> readers
+  std::map<long, Batch> filled;         // under mu: readers -> sequencer (by batch number)
+  long next_plan = 0, next_out = 0;     // batches planned / moved to the consumer's queue
+  long n_consumed = 0;                  // batches the consumer has taken (bounds what is held in memory)
+  std::vector<std::thread> threads;
+
+  auto sequential_reader = [&] {
     try {
       SequentialMatrixReader rd(feat_rspec);
       Batch cur;
@@ -176,22 +203,123 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       queue.push_back(std::move(b));
       cv.notify_all();
     }
-  });
+  };
+  // index pass: batches by the same rule as the sequential reader, from the headers (objects whose size is not known
+  // without reading them - text, pipes - count as 0 rows: such batches are bounded by max_batch_chunks only, and the
+  // extractor splits what does not fit one forward pass)
+  auto index_pass = [&] {
+    PlanBatch cur;
+    long rows = 0;
+    auto push = [&](bool last) {
+      cur.last = last;
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return next_plan - n_consumed < 2 * n_readers + 2 || stop; });
+      if (stop) return;
+      cur.seq = next_plan++;
+      plans.push_back(std::move(cur));
+      cur = PlanBatch();
+      rows = 0;
+      cv.notify_all();
+    };
+    try {
+      MatrixTableIndexer::Entry e;
+      while (indexer->Next(&e)) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          if (stop) break;
+        }
+        if (!e.error.empty()) {
+          warn("failed to read features for " + e.key + ": " + e.error);
+          std::unique_lock<std::mutex> lk(mu);
+          ++num_fail_read;
+          continue;
+        }
+        const int r = std::max(e.rows, 0);
+        if (!cur.entries.empty() && (rows + r > opt.max_batch_rows || (int)cur.entries.size() >= opt.max_batch_chunks)) push(false);
+        rows += r;
+        cur.entries.push_back(std::move(e));
+      }
+    } catch (const std::exception& ex) {
+      std::unique_lock<std::mutex> lk(mu);
+      if (reader_error.empty()) reader_error = ex.what();
+    }
+    push(true);
+  };
+  auto parallel_reader = [&] {
+    Input in;
+    std::string in_path;
+    for (;;) {
+      PlanBatch pb;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !plans.empty() || stop; });
+        if (stop) return;
+        pb = std::move(plans.front());
+        plans.pop_front();
+        if (pb.last) {   // the other readers must see the end as well
+          PlanBatch again;
+          again.seq = -1;
+          again.last = true;
+          plans.push_back(std::move(again));
+          cv.notify_all();
+          if (pb.seq < 0) return;
+        }
+      }
+      Batch b;
+      b.last = pb.last;
+      for (MatrixTableIndexer::Entry& e : pb.entries) {
+        Utt u;
+        try {
+          ReadIndexedMatrix(e, &in, &in_path, &u.feats);
+        } catch (const std::exception& ex) {
+          if (e.offset >= 0 && !opt_is_scp) {   // a damaged archive is fatal, as in the sequential reader
+            std::unique_lock<std::mutex> lk(mu);
+            if (reader_error.empty()) reader_error = ex.what();
+            continue;
+          }
+          warn("failed to read features for " + e.key + ": " + ex.what());
+          std::unique_lock<std::mutex> lk(mu);
+          ++num_fail_read;
+          continue;
+        }
+        u.key = std::move(e.key);
+        b.utts.push_back(std::move(u));
+      }
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        filled.emplace(pb.seq, std::move(b));
+        // sequencer: whatever is next in table order goes to the consumer's queue
+        for (auto it = filled.find(next_out); it != filled.end(); it = filled.find(next_out)) {
+          queue.push_back(std::move(it->second));
+          filled.erase(it);
+          ++next_out;
+        }
+        cv.notify_all();
+        if (pb.last) return;
+      }
+    }
+  };
+  if (indexer) {
+    threads.emplace_back(index_pass);
+    for (int i = 0; i < n_readers; ++i) threads.emplace_back(parallel_reader);
+  } else {
+    threads.emplace_back(sequential_reader);
+  }
   struct ReaderGuard {
-    std::thread& t;
+    std::vector<std::thread>& ts;
     std::mutex& mu;
     std::condition_variable& cv;
     bool& stop;
     ~ReaderGuard() {
-      if (!t.joinable()) return;
       {
         std::unique_lock<std::mutex> lk(mu);
         stop = true;
         cv.notify_all();
       }
-      t.join();
+      for (std::thread& t : ts)
+        if (t.joinable()) t.join();
     }
-  } reader_guard{reader, mu, cv, stop};
+  } reader_guard{threads, mu, cv, stop};
 
   const auto t0 = std::chrono::steady_clock::now();
   const bool has_backend = !opt.backend_mean.empty() || !opt.backend_transform.empty() || opt.backend_normalize;
@@ -397,6 +525,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       cv.wait(lk, [&] { return !queue.empty(); });
       b = std::move(queue.front());
       queue.pop_front();
+      ++n_consumed;
       cv.notify_all();
     }
     t_wait += secs(tw0, now());
@@ -440,7 +569,12 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       << " s, finish+write " << t_fin << " s";
     log("LOG", m.str());
   }
-  reader.join();
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    stop = true;   // every reader has delivered its last batch; the flag releases any that still waits for work
+    cv.notify_all();
+  }
+  for (std::thread& t : threads) t.join();
   writer.Close();
   if (!fatal.empty()) throw std::runtime_error(fatal);
   if (!reader_error.empty()) throw KioError(reader_error);
