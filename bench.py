@@ -56,14 +56,19 @@ def cpu_baseline(topology, frames, seconds):
     from oracle import kaldi_io as kio
     from oracle.export_program import export_program
     # cores this process may actually use: the affinity mask and the cgroup CPU quota, not the host's core count
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    host = os.cpu_count() or 1
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host
+    cores, why = aff, ("every CPU of the host" if aff == host else
+                       "sched_getaffinity: this process may run on %d of the host's %d CPUs" % (aff, host))
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
-            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+            quota = max(1, int(float(q) / float(per) + 0.5))
+            if quota < cores:
+                cores, why = quota, "cgroup cpu.max = %s %s: a quota of %d CPUs (affinity mask: %d, host: %d)" % (q, per, quota, aff, host)
     except Exception:   # noqa: BLE001 - no cgroup v2 quota file
         pass
-    res = {"unit": "utt/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port"}
+    res = {"unit": "utt/s", "cores": cores, "host_cpus": host, "cores_limited_by": why, "kind": "port"}
     d = tempfile.mkdtemp(prefix="xvb0", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)   # archives (memory)
     dx = tempfile.mkdtemp(prefix="xvb0x")      # the host-built executable (/dev/shm may be mounted noexec)
     try:
