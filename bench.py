@@ -10,12 +10,14 @@ Rank 0 prints ONE JSON line.
   workload BASELINE.json configs[1]: v2 x-vector TDNN, batch = 256 chunks x 400 frames per GPU ("weak" scaling:
            per-GPU work is fixed, utterances are sharded, the only collective is ONE RCCL broadcast of the packed
            weights at start-up - SURVEY.md §8(e))
-  dtype    "auto" by default: chunks that pool >= 300 frames (the 400-frame workload does) run fp16mx = fp16 activations
-           x fp16 weights (fp16 MFMA) + a block-scaled 4-bit product of the weight residual (MX MFMA at 4x the rate),
-           1.25 MFMA passes per product, fp32 accumulate; shorter chunks run fp16x3 (split fp16, three MFMAs).  Both
-           meet the 1e-4 parity bar on this model - Kaldi's initialisation distribution, what BASELINE.json asks for -
-           and the measured error is in the line; `parity_trained_like_model` reports the same modes on a heavy-tailed,
-           BatchNorm-calibrated model, where only fp16x3 stays below 1e-4.
+  dtype    the arithmetic the dominant kernel computed in.  Default `--precision default` = what every entry point of the
+           library ships (XV_PREC_DEFAULT): the model is packed for fp16mx2 (fp16 MFMA + two block-scaled 4-bit products for the
+           rounding residuals of weights and activations, 1.5 passes) and - like nnet3-xvector-compute does on the head of its
+           table - calibrated on the first 64 chunks of the workload, outside the timed region: the lighter fp16mx (1.25 passes)
+           runs only if its worst embedding stays within 7.5e-5 of the three-pass fp16x3 result, which it does on this model
+           (Kaldi's initialisation distribution, what BASELINE.json asks for) and does not on the heavy-tailed model of
+           `parity_trained_like_model`, where the same policy keeps fp16mx2.  `config.calibration` holds what was measured and
+           chosen; `other_modes` the other arithmetics on the same workload, each with its error.
   roofline dominant kernel = the GEMM instantiation with the largest share of the step (name as the engine's profile
            report observed it); achieved = algorithmic FLOPs of its launches / their duration, HIP events stamped by the
            dispatches on the launch stream over the same K steps repeated right after the timed region (the event
