@@ -7,6 +7,8 @@
 //
 // 1. parses the model, lowers it, re-emits it and parses the copy again;
 // 2. reads the archive and re-writes it through the table writer in binary and text form;
+// 2b. binary archives: the index pass of the parallel table readers (MatrixTableIndexer + ReadIndexedMatrix) must deliver
+//     exactly what the sequential reader delivers, through the archive itself and through a script file of its offsets;
 // 3. replays both files truncated at `variants` positions and with 1.5 x `variants` single bits flipped: every variant must either parse or
 //    throw KioError - never crash, hang or trip a sanitizer.
 #include <stdio.h>
@@ -75,6 +77,47 @@ int TryArchive(const std::string& bytes) {
   }
 }
 
+// The indexed readers against the sequential one: same keys, same matrices, same order.  Returns 0 ok, 1 mismatch,
+// 2 "not addressable" (text archive: the caller checks that this is what usable() says).
+int CheckIndexer(const std::string& rspec, const std::string& seq_rspec) {
+  xv::MatrixTableIndexer idx(rspec);
+  if (!idx.usable()) return 2;
+  xv::SequentialMatrixReader rd(seq_rspec);
+  xv::Input in;
+  std::string in_path, key, err;
+  xv::Matrix want, got;
+  xv::MatrixTableIndexer::Entry e;
+  for (;;) {
+    const bool a = idx.Next(&e), b = rd.Next(&key, &want, &err);
+    if (a != b) return 1;
+    if (!a) return 0;
+    if (!e.error.empty() || !err.empty() || e.key != key) return 1;
+    xv::ReadIndexedMatrix(e, &in, &in_path, &got);
+    if (got.rows != want.rows || got.cols != want.cols || got.data != want.data) return 1;
+    if (e.rows >= 0 && (e.rows != want.rows || e.cols != want.cols)) return 1;
+  }
+}
+
+// a damaged archive through the index pass: every variant either indexes + reads or throws KioError
+int TryIndexedFile(const std::string& path) {
+  try {
+    xv::MatrixTableIndexer idx("ark:" + path);
+    if (!idx.usable()) return 1;
+    xv::Input in;
+    std::string in_path;
+    xv::MatrixTableIndexer::Entry e;
+    xv::Matrix m;
+    for (int n = 0; n < 100000 && idx.Next(&e); ++n) xv::ReadIndexedMatrix(e, &in, &in_path, &m);
+    return 0;
+  } catch (const xv::KioError&) {
+    return 1;
+  } catch (const std::bad_alloc&) {
+    return 1;
+  } catch (const std::length_error&) {
+    return 1;
+  }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -126,6 +169,39 @@ int main(int argc, char** argv) {
     if (TryArchive(Slurp(tb)) != 0 || TryArchive(Slurp(tt)) != 0) {
       fprintf(stderr, "host_selftest: re-written archive does not parse\n");
       return 1;
+    }
+    // 2b. the index pass: the binary copy through the archive and through a script file of its offsets; the text copy
+    // is not addressable and must say so
+    {
+      const std::string ts = std::string(argv[3]) + ".selftest.scp";
+      {
+        xv::TableWriter ws("ark,scp:" + tb + "," + ts);
+        xv::SequentialMatrixReader rd2(std::string("ark:") + argv[3]);
+        std::string key, err;
+        xv::Matrix m;
+        while (rd2.Next(&key, &m, &err)) ws.WriteMat(key, m);
+      }
+      if (CheckIndexer("ark:" + tb, "ark:" + tb) != 0 || CheckIndexer("scp:" + ts, "ark:" + tb) != 0 ||
+          CheckIndexer("ark:" + tt, "ark:" + tt) != 2) {
+        fprintf(stderr, "host_selftest: the indexed table readers disagree with the sequential reader\n");
+        return 1;
+      }
+      // damaged copies of the binary archive through the index pass (truncations and bit flips, on disk: the indexer seeks)
+      const std::string good = Slurp(tb), td = std::string(argv[3]) + ".selftest.dmg";
+      unsigned state = 777;
+      for (int i = 0; i < variants; ++i) {
+        std::string bad = good;
+        state = state * 1664525u + 1013904223u;
+        if (i % 2) bad.resize(good.size() * (size_t)(i + 1) / (variants + 2));
+        else bad[state % bad.size()] = (char)(bad[state % bad.size()] ^ (1u << ((state >> 20) & 7)));
+        {
+          std::ofstream f(td, std::ios::binary);
+          f.write(bad.data(), (std::streamsize)bad.size());
+        }
+        (void)TryIndexedFile(td);
+      }
+      remove(td.c_str());
+      remove(ts.c_str());
     }
     remove(tb.c_str());
     remove(tt.c_str());
