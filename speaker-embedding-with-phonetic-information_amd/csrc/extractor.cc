@@ -1,5 +1,10 @@
 // Chunk loop + weighted average.  See extractor.h.
 #include "extractor.h"
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <functional>
 
 #include <math.h>
 #include <string.h>
@@ -7,6 +12,77 @@
 #include <sstream>
 
 namespace xv {
+
+namespace {
+// A few helper threads for the bulk host copies of table jobs (started on first use, alive until exit).  ParallelFor splits
+// [0, n) into contiguous ranges, the caller takes one of them and returns when all are done.  XVEC_COPY_THREADS (default 3
+// helpers, 0 = the caller alone).
+class CopyPool {
+ public:
+  static CopyPool& Get() {
+    static CopyPool* p = new CopyPool();   // never destroyed: the threads may outlive static destructors otherwise
+    return *p;
+  }
+  void Run(int n, const std::function<void(int, int)>& fn) {
+    const int parts = std::min((int)workers_.size() + 1, n);
+    if (parts <= 1 || n < 8) {
+      fn(0, n);
+      return;
+    }
+    std::unique_lock<std::mutex> run_lock(run_mu_);   // one ParallelFor at a time
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      fn_ = &fn;
+      n_ = n;
+      parts_ = parts;
+      next_ = 1;          // part 0 is the caller's
+      pending_ = parts - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    fn(0, n / parts);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  CopyPool() {
+    int t = 3;
+    if (const char* e = getenv("XVEC_COPY_THREADS")) t = std::max(0, std::min(15, atoi(e)));
+    for (int i = 0; i < t; ++i) workers_.emplace_back([this] { Loop(); });
+    for (std::thread& w : workers_) w.detach();
+  }
+  void Loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      int part;
+      const std::function<void(int, int)>* fn;
+      int n, parts;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen && fn_ && next_ < parts_; });
+        part = next_++;
+        if (next_ >= parts_) seen = gen_;
+        fn = fn_;
+        n = n_;
+        parts = parts_;
+      }
+      (*fn)((int)((long)n * part / parts), (int)((long)n * (part + 1) / parts));
+      std::unique_lock<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int, int)>* fn_ = nullptr;
+  int n_ = 0, parts_ = 0, next_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+};
+void ParallelFor(int n, const std::function<void(int, int)>& fn) { CopyPool::Get().Run(n, fn); }
+}  // namespace
+
 
 bool PlanChunks(int utt, int num_rows, int chunk_size, int min_chunk_size, bool pad_input, int min_net_frames,
                 std::vector<Chunk>* out, std::string* why) {
@@ -186,15 +262,22 @@ void ExtractJob::StartPtrs(Engine* eng, const ExtractOptions& opt, int slot, lon
   const int D = eng->info().input_dim;
   float* pack = eng->HostFeats(slot, (size_t)total);
   std::vector<int32_t> offs(1, 0);
-  size_t r = 0;
-  for (const Chunk& c : chunks_) {
-    const float* src = utt[c.utt] + (size_t)c.start * D;
-    for (int p = 0; p < c.left_pad; ++p, ++r) memcpy(pack + r * D, src, (size_t)D * 4);
-    memcpy(pack + r * D, src, (size_t)c.len * D * 4);
-    r += c.len;
-    for (int p = 0; p < c.right_pad; ++p, ++r) memcpy(pack + r * D, src + (size_t)(c.len - 1) * D, (size_t)D * 4);
-    offs.push_back((int32_t)r);
-  }
+  for (const Chunk& c : chunks_) offs.push_back(offs.back() + c.left_pad + c.len + c.right_pad);
+  // the one host copy per byte of a table job (reader's buffers -> pinned staging), spread over a few threads: done by the
+  // consumer thread alone it was what the loop waited for once the readers were parallel (0.19 s of 0.34 s per 80 000
+  // utterances)
+  const int n_chunks = (int)chunks_.size();
+  ParallelFor(n_chunks, [&](int k0, int k1) {
+    for (int k = k0; k < k1; ++k) {
+      const Chunk& c = chunks_[k];
+      const float* src = utt[c.utt] + (size_t)c.start * D;
+      size_t r = (size_t)offs[k];
+      for (int p = 0; p < c.left_pad; ++p, ++r) memcpy(pack + r * D, src, (size_t)D * 4);
+      memcpy(pack + r * D, src, (size_t)c.len * D * 4);
+      r += c.len;
+      for (int p = 0; p < c.right_pad; ++p, ++r) memcpy(pack + r * D, src + (size_t)(c.len - 1) * D, (size_t)D * 4);
+    }
+  });
   eng->SubmitHost(slot, seq, offs.data(), (int)chunks_.size());
   async_ = true;
 }
