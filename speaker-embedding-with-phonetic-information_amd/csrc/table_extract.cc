@@ -345,7 +345,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   Work work[Engine::kNumHostSlots];
   int cur = 0;
   long seq = 0;
-  bool calibrated = false;
+  bool calibrated = !(opt.calibrate && engine->can_switch_fast_mode());   // nothing to choose: no batch is held back
   constexpr int NS = Engine::kNumHostSlots;
   // stage timing of the consumer thread (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
   const bool timing = getenv("XVEC_TIMING") != nullptr;
@@ -530,7 +530,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
     }
     t_wait += secs(tw0, now());
     const bool last = b.last;
-    if (opt.calibrate && !calibrated) {
+    if (!calibrated) {
       held_utts += b.utts.size();
       held.push_back(std::move(b));
       if (held_utts >= (size_t)opt.calibrate_utts || last) {
