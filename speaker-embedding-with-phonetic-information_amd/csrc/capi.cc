@@ -81,7 +81,7 @@ xv_status LoadCommon(xv::RawNnet& net, const char* nnet_config, const char* outp
 extern "C" {
 
 const char* xv_last_error(void) { return g_err.c_str(); }
-const char* xv_version(void) { return "xvec_hip 0.3 (gfx950)"; }
+const char* xv_version(void) { return "xvec_hip 0.4 (gfx950)"; }
 
 xv_status xv_model_load(const void* raw, size_t n, const char* nnet_config, const char* output_node, xv_model** out) {
   if (!raw || !out) return Fail(XV_ERR_ARG, "xv_model_load: null argument");

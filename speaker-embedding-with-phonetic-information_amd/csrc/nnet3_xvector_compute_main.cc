@@ -38,7 +38,7 @@ bool g_apply_exp = false;
 int g_verbose = 0;
 
 void LogLine(const char* level, int line, const std::string& msg) {
-  fprintf(stderr, "%s (%s[xvec-hip-0.3]:main():nnet3_xvector_compute_main.cc:%d) %s\n", level, kProg, line, msg.c_str());
+  fprintf(stderr, "%s (%s[xvec-hip-0.4]:main():nnet3_xvector_compute_main.cc:%d) %s\n", level, kProg, line, msg.c_str());
 }
 #define XLOG(msg)                        \
   do {                                   \
@@ -426,7 +426,7 @@ int main(int argc, char** argv) {
     write_profile(res);
     return res.num_success != 0 ? 0 : 1;
   } catch (const std::exception& e) {
-    fprintf(stderr, "ERROR (%s[xvec-hip-0.3]:main()) %s\n", kProg, e.what());
+    fprintf(stderr, "ERROR (%s[xvec-hip-0.4]:main()) %s\n", kProg, e.what());
     return -1;
   }
 }

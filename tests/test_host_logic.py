@@ -318,3 +318,23 @@ def test_mx_weight_image_packing():
             a = np.abs(x / s)
             half_gap = np.where(a >= 4, 1.0, np.where(a >= 2, 0.5, 0.25))
             assert np.all(np.abs(val[:, t, g, :] * s - x) / s <= half_gap + 1e-9)
+
+
+def test_default_precision_policy_is_one_rule_for_every_entry_point():
+    """XV_PREC_DEFAULT (what the command line, dist_extract.py, bench.py and Context() use without being told anything
+    else; engine.cc PackModelPolicy): fp16mx2 for a pooled output whose layers can all run it, fp16x3 for frame-level
+    outputs - resolved when the model is packed, so the image a rank broadcasts already says what it is."""
+    import struct
+    def packed_precision(blob):     # BlobHeader: char magic[8]; uint32 version; int32 precision
+        assert blob[:8] == b"XVHIPBLB"
+        return struct.unpack_from("<i", blob, 12)[0]
+    net, line = H.synth_model("v2_xvector")
+    pooled = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    assert pooled.pack() == pooled.pack(P.PREC_DEFAULT) == pooled.pack(P.PRECISIONS["fp16mx2"])
+    assert packed_precision(pooled.pack()) == P.PREC_FP16MX2
+    frames = P.Model(raw=net.to_bytes(True), nnet_config="output-node name=output input=tdnn4.batchnorm")
+    assert frames.info.output_is_segment == 0
+    assert packed_precision(frames.pack()) == P.PREC_FP16X3
+    cnet, cline = H.synth_model("v5_cvector")     # the c-vector network's 650-wide branch is padded to whole 128-column blocks
+    assert packed_precision(P.Model(raw=cnet.to_bytes(True), nnet_config=cline).pack()) == P.PREC_FP16MX2
+    assert P.PRECISIONS["default"] == P.PREC_DEFAULT == -1 and P.PRECISION_NAMES[P.PREC_FP16MX2] == "fp16mx2"
