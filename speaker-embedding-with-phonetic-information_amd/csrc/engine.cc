@@ -652,7 +652,6 @@ Engine::~Engine() {
     fr(L.out_f32);
     fr(L.splitk_ws);
     fr(L.frame_f32);
-    fr(L.lsm_partial);
     if (L.done) (void)hipEventDestroy(L.done);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
@@ -710,7 +709,6 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
       }
       if (frame_mode_ && (int)i == info_.output_layer) {
         Ensure(&L.frame_f32, (size_t)rows * li.n_pad * 4, false);
-        if (li.log_softmax) Ensure(&L.lsm_partial, (size_t)rows * (li.n_pad / 64) * 2 * 4, false);
         continue;
       }
       Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
@@ -1042,10 +1040,6 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         ga.out_f32 = (float*)L.frame_f32.p;
         ga.ldf = li.n_pad;
         ga.m_valid = plan.rows;
-        if (li.log_softmax) {   // the row statistics of the LogSoftmax come out of the GEMM's epilogue
-          ga.lsm_partial = (float*)L.lsm_partial.p;
-          ga.lsm_cols = li.out_dim;
-        }
       } else {
         epi = kEpiAct;
         ga.out_hi = ActBase(L.act[i].act_hi, li.n_pad);
@@ -1148,7 +1142,6 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         if (region != 0)
           for (int j = 0; j < gr.nseg; ++j) gr.seg[j].gmax = nullptr;
         if (gr.out_f32) gr.out_f32 += r0 * gr.ldf;
-        if (gr.lsm_partial) gr.lsm_partial += r0 * (gr.n_tiles * 2) * 2;
         if (gr.partial) gr.partial += (r0 / kRowAlign) * 2 * gr.ldp;
         if (gr.grp_range) gr.grp_range += (r0 / kRowAlign) * 2;
         gr.m_valid = (int)(r1 - r0);
@@ -1198,8 +1191,6 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     fo.log_softmax = ol.log_softmax;
     fo.out = out_dev;
     fo.out_ld = out_ld;
-    fo.partial = ol.log_softmax ? (const float*)L.lsm_partial.p : nullptr;
-    fo.n_blk = ol.n_pad / 64;
     arm("frame_output");
     Check(launch_frame_output(fo, s), "frame_output launch");
     disarm();
@@ -1214,8 +1205,6 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     fo.log_softmax = 1;
     fo.out = out_dev;
     fo.out_ld = out_ld;
-    fo.partial = nullptr;
-    fo.n_blk = 0;
     arm("frame_output");
     Check(launch_frame_output(fo, s), "frame_output launch");
     disarm();

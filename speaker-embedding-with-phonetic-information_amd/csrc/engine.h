@@ -186,7 +186,6 @@ class Engine {
     bool busy = false;
     std::vector<ActBuf> act;     // per layer
     Buf in_hi, in_lo, partial, stats_hi, stats_lo, out_f32, splitk_ws, frame_f32;
-    Buf lsm_partial;       // frame-level LogSoftmax output: per row and 64-column block (max, sum exp) from the head GEMM
     Buf gmax;              // [layer][gmax_stride] group maxima of the activation planes (kPrecFp16Mx)
     int gmax_stride = 0;
     int cap_rows = 0, cap_b = 0;

@@ -215,11 +215,6 @@ struct GemmArgs {
   float* out_f32;
   int ldf;
   int m_valid;           // rows >= m_valid are not stored (kEpiF32 only)
-  // kEpiF32 feeding a LogSoftmaxComponent (senone log-posteriors, prepare_nnet3_xconfig.sh:53-59): besides the fp32 rows the
-  // epilogue writes, per row and 64-column block, (max, sum of exp(x - max)) over the block's columns < lsm_cols into
-  // lsm_partial[row][n_pad / 64][2]; frame_output then normalises in ONE pass over the rows (launch_frame_output).  Null: off
-  float* lsm_partial;
-  int lsm_cols;
   // kEpiStats
   float* partial;        // [rows/16][2][ldp]
   int ldp;
@@ -343,7 +338,8 @@ struct PoolArgs {
 hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s);
 
 // Frame-level output: gathers the rows that correspond to input frames out of the [rows][ld] fp32 result of the last
-// GEMM into the caller's packed matrix, optionally applying LogSoftmaxComponent row-wise.
+// GEMM into the caller's packed matrix, optionally applying LogSoftmaxComponent row-wise (rows of up to 16384 columns are
+// kept in registers: one read, one write).
 struct FrameOutArgs {
   const float* src;         // [device rows][ld]
   int ld;
@@ -353,10 +349,6 @@ struct FrameOutArgs {
   int log_softmax;
   float* out;               // [n_out][out_ld]
   int out_ld;
-  // log_softmax with the row statistics already reduced per 64-column block by the producing GEMM (GemmArgs::lsm_partial):
-  // [device rows][n_blk][2]; null = the kernel makes its own two passes over the row for them
-  const float* partial;
-  int n_blk;
 };
 hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s);
 

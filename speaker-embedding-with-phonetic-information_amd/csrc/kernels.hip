@@ -403,47 +403,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
           for (int p = 0; p < 4; ++p)
             *(f32x4*)(dst + (p >> 1) * 32 + (p & 1) * 4) = f32x4{y[p * 4], y[p * 4 + 1], y[p * 4 + 2], y[p * 4 + 3]};
         }
-        if (a.lsm_partial) {
-          // LogSoftmax statistics of this row over the wave's 64 columns (the row's four lanes fr_g hold 16 each): max, then
-          // sum of exp(x - max); columns beyond the layer's dimension do not count.  A block without a valid column gives
-          // (-inf, 0), which the combining pass ignores.
-          float m = -__builtin_inff();
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (ncol + (p >> 1) * 32 + (p & 1) * 4 + r < a.lsm_cols) m = fmaxf(m, y[p * 4 + r]);
-          {
-            float ma = m, mb = m;
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
-            m = fmaxf(ma, mb);
-            ma = m;
-            mb = m;
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
-            m = fmaxf(ma, mb);
-          }
-          float sum = 0.f;
-          const float mm = (m == -__builtin_inff()) ? 0.f : m;
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (ncol + (p >> 1) * 32 + (p & 1) * 4 + r < a.lsm_cols) sum += __expf(y[p * 4 + r] - mm);
-          {
-            float sa = sum, sb = sum;
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(sa), "+v"(sb));
-            sum = sa + sb;
-            sa = sum;
-            sb = sum;
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(sa), "+v"(sb));
-            sum = sa + sb;
-          }
-          if (fr_g == 0 && row < a.m_valid) {
-            float* pp = a.lsm_partial + ((long)row * (a.n_tiles * 2) + (nbase >> 6)) * 2;
-            pp[0] = m;
-            pp[1] = sum;
-          }
-        }
       } else {
         unsigned int hw[8], lw[8];
 #pragma unroll
@@ -2791,10 +2750,71 @@ hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// frame_output: one workgroup per output row.  LogSoftmaxComponent: y = x - max - log(sum exp(x - max)).  With the row
-// statistics per 64-column block from the producing GEMM (a.partial) the row is read once: block statistics -> log-sum-exp
-// (first wave), then one streaming pass x - lse with 16-byte loads / stores where the rows allow; without them the kernel
-// makes its own max and sum passes first (pooled outputs taken after a LogSoftmax: a few rows only).
+// frame_output: one workgroup per output row.  LogSoftmaxComponent: y = x - max - log(sum exp(x - max)).
+// frame_output_lsm_kernel<N, VEC> keeps the whole row in registers (N floats per thread: rows of up to 256 N columns): one
+// read of the logits, block-wide max and sum of exp(x - max) with the accurate expf / logf, one write of x - lse - 3.2 GB
+// of traffic for the 102 k x 3856 log-posteriors of BASELINE config 5 instead of the three read passes + one write of the
+// first version (1.23 -> 0.6 ms), and no statistics work in the head GEMM's epilogue (tried: +0.15 ms there).  VEC: 16-byte
+// loads / stores (row length, row pitches and pointers multiples of four floats), else coalesced 4-byte accesses.
+// frame_output_kernel is the plain gather, and the three-pass fallback for rows that do not fit the registers.
+template <int N, bool VEC>
+__global__ __launch_bounds__(256) void frame_output_lsm_kernel(const FrameOutArgs a) {
+  const int o = blockIdx.x;
+  const long srow = a.out_row ? a.out_row[o] : o;
+  const float* src = a.src + srow * a.ld;
+  float* dst = a.out + (long)o * a.out_ld;
+  const int tid = threadIdx.x;
+  __shared__ float red[8];
+  float v[N];
+  float m = -INFINITY;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const int c = (tid + 256 * i) * 4;
+      f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (c < a.dim) x = *(const f32x4*)(src + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[4 * i + k] = x[k];
+        m = fmaxf(m, x[k]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + 256 * i;
+      v[i] = c < a.dim ? src[c] : -INFINITY;
+      m = fmaxf(m, v[i]);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) sum += expf(v[i] - m);   // columns beyond the row: exp(-inf) = 0
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float lse = m + logf((red[4] + red[5]) + (red[6] + red[7]));
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const int c = (tid + 256 * i) * 4;
+      if (c < a.dim) *(f32x4*)(dst + c) = f32x4{v[4 * i] - lse, v[4 * i + 1] - lse, v[4 * i + 2] - lse, v[4 * i + 3] - lse};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + 256 * i;
+      if (c < a.dim) dst[c] = v[i] - lse;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a) {
   const int o = blockIdx.x;
   const long srow = a.out_row ? a.out_row[o] : o;
@@ -2806,36 +2826,6 @@ __global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a)
     return;
   }
   __shared__ float red[4];
-  float lse;
-  if (a.partial) {
-    if (tid < 64) {
-      const float* p = a.partial + srow * a.n_blk * 2;
-      float m = -INFINITY;
-      for (int j = tid; j < a.n_blk; j += 64) m = fmaxf(m, p[2 * j]);
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-      float sum = 0.f;
-      for (int j = tid; j < a.n_blk; j += 64) {
-        const float mj = p[2 * j], sj = p[2 * j + 1];
-        if (sj > 0.f) sum += sj * expf(mj - m);
-      }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-      if (tid == 0) red[0] = m + logf(sum);
-    }
-    __syncthreads();
-    lse = red[0];
-    if (((a.dim | a.out_ld | a.ld) & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
-      for (int c = tid * 4; c < a.dim; c += 1024) {
-        f32x4 v = *(const f32x4*)(src + c);
-        v -= lse;
-        *(f32x4*)(dst + c) = v;
-      }
-    } else {
-      for (int c = tid; c < a.dim; c += 256) dst[c] = src[c] - lse;
-    }
-    return;
-  }
   float m = -INFINITY;
   for (int c = tid; c < a.dim; c += 256) m = fmaxf(m, src[c]);
 #pragma unroll
@@ -2850,13 +2840,30 @@ __global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a)
   for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
   if ((tid & 63) == 0) red[tid >> 6] = sum;
   __syncthreads();
-  lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+  const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
   for (int c = tid; c < a.dim; c += 256) dst[c] = src[c] - lse;
 }
 
 hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
-  XV_LAUNCH(frame_output_kernel, dim3(a.n_out), dim3(256), 0, s, a);
+  const dim3 grid(a.n_out), block(256);
+  if (a.log_softmax && a.dim <= 256 * 64) {
+    const bool vec = ((a.dim | a.out_ld | a.ld) & 3) == 0 && (((uintptr_t)a.out | (uintptr_t)a.src) & 15) == 0;
+    const int n = (a.dim + 255) / 256;   // floats per thread
+    if (vec) {
+      if (n <= 8) XV_LAUNCH((frame_output_lsm_kernel<8, true>), grid, block, 0, s, a);
+      else if (n <= 16) XV_LAUNCH((frame_output_lsm_kernel<16, true>), grid, block, 0, s, a);
+      else if (n <= 32) XV_LAUNCH((frame_output_lsm_kernel<32, true>), grid, block, 0, s, a);
+      else XV_LAUNCH((frame_output_lsm_kernel<64, true>), grid, block, 0, s, a);
+    } else {
+      if (n <= 8) XV_LAUNCH((frame_output_lsm_kernel<8, false>), grid, block, 0, s, a);
+      else if (n <= 16) XV_LAUNCH((frame_output_lsm_kernel<16, false>), grid, block, 0, s, a);
+      else if (n <= 32) XV_LAUNCH((frame_output_lsm_kernel<32, false>), grid, block, 0, s, a);
+      else XV_LAUNCH((frame_output_lsm_kernel<64, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+  }
+  XV_LAUNCH(frame_output_kernel, grid, block, 0, s, a);
   return hipGetLastError();
 }
 
