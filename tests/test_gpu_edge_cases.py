@@ -94,3 +94,51 @@ def test_compressed_feature_archive_through_the_cli(tmp_path, v2):
     for k, m in expect.items():
         ref = H.xo.extract_xvector(ev, m, 10000, 25, True)
         assert H.rel_err(got[k][None], ref[None]) < TOL, k
+
+
+@pytest.mark.parametrize("feat_dim,offsets,w1", [
+    (5, (-2, -1, 0, 1, 2), 8),        # the tiny net: dp = 8, K = 40 of 128
+    (24, (-2, -1, 0, 1, 2), 600),     # dp = 24, K = 120; 600 -> 640 columns: two column groups of the first-layer kernel
+    (30, (-2, 0), 72),                # dp = 32, non-unit spacing: the splice address is per K chunk, not a contiguous window
+    (30, (-3, 0, 3), 72),             # (64 + 6) x 32 staged floats > 4 per thread: prep_input + the generic GEMM
+    (16, (-7, -1, 0, 2, 4, 5, 6, 8), 40),   # eight irregular offsets, K = 128 exactly, span 15
+    (40, (-1, 0, 1), 64),             # dp = 40 > 32: not for the first-layer kernel - prep_input + the generic GEMM
+    (23, (-15, 0, 15), 64),           # the widest span a model may have (+-15 frames): (64 + 30) x 24 staged floats: generic path
+    (16, (-15, 0, 15), 64),           # the same span with 16-float rows fits
+])
+def test_first_layer_shapes(feat_dim, offsets, w1):
+    """The layers that read the network input run tdnn_first_kernel where its layout allows (feature rows of <= 32 floats,
+    noff x roundup(dim, 8) <= 128 compact K columns, at most four staged floats per thread and unit) and prep_input + the generic kernel elsewhere:
+    every shape against the oracle in the three-pass arithmetic and in the default (fp16mx2 planes + 4-bit residual, or the
+    hi-only planes of fp16mx), with chunks in both row regions, and the profile report says which kernel ran."""
+    P = H.pkg()
+    app = "Append(%s)" % ", ".join("input" if o == 0 else "Offset(input, %d)" % o for o in offsets)
+    # wider layers behind the first one so that the 4-bit modes apply to them (multiples of 128 columns of K per source)
+    cfg = H.tiny_config(feat_dim=feat_dim, w1=w1, w2=128, pool=128, emb=16)
+    old = "Append(Offset(input, -2), Offset(input, -1), input, Offset(input, 1), Offset(input, 2))"
+    assert old in cfg
+    cfg = cfg.replace(old, app).replace("input-dim=%d output-dim=%d" % (5 * feat_dim, w1), "input-dim=%d output-dim=%d" % (len(offsets) * feat_dim, w1))
+    net = H.nm.synthesize(cfg, seed=21)
+    line = "output-node name=output input=tdnn6.affine"
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    ev = H.xo.GraphEvaluator(n2, np.float64)
+    rng = np.random.default_rng(4)
+    lens = [400, 61, 333, 80, 200]
+    utts = [(rng.standard_normal((T, feat_dim)) * 3).astype(np.float32) for T in lens]
+    feats, offs = H.pack(utts)
+    ref = np.stack([ev.compute(u)[0] for u in utts])
+    dp = (feat_dim + 7) // 8 * 8
+    span = max(offsets) - min(offsets)
+    fits = dp <= 32 and len(offsets) * dp <= 128 and span <= 30 and (64 + span) * dp <= 4 * 512   # kernels.h FirstLayerApplicable
+    for prec, tol in (("fp16x3", 2e-5), ("default", 1e-4)):
+        ctx = P.Context(model, precision=P.PRECISIONS[prec])
+        out = ctx.forward_batch(feats, offs)
+        errs = [H.rel_err(out[i:i + 1], ref[i:i + 1]) for i in range(len(utts))]
+        assert max(errs) < tol, (prec, errs)
+        ctx.set_profiling(True)
+        ctx.forward_batch(feats, offs)
+        labels = " | ".join(l for (l, _, _) in ctx.profile_report())
+        assert ("tdnn_first_kernel" in labels) == fits, labels
+        assert ("prep_input" in labels) == (not fits), labels
