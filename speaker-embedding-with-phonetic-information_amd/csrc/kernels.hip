@@ -49,6 +49,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define XV_AS1 __attribute__((address_space(1)))
@@ -115,6 +116,27 @@ __device__ __forceinline__ float from16(uint16_t u) {
     return (float)__builtin_bit_cast(_Float16, u);
   } else {
     return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+  }
+}
+
+// Kaldi's ApplyFloor: x < floor ? floor : x, i.e. a NaN stays a NaN (fmaxf / v_max_f32 would return the floor).  gfx950's
+// v_maximum3_f32 is the IEEE-754-2019 maximum - NaN-propagating - in one instruction instead of compare + select; the only
+// difference to the comparison is the sign of an exact zero (maximum(-0, +0) = +0), which no later sum or product can see.
+// A floor of -inf = no ReLU.
+__device__ __forceinline__ float apply_floor(float x, float floor) {
+  float r;
+  asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(x), "v"(floor));
+  return r;
+}
+// Two fp32 values -> one dword of two 16-bit floats, round to nearest even (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32).
+template <bool F16>
+__device__ __forceinline__ unsigned int to16x2(f32x2 x) {
+  if constexpr (F16) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(x, h2));
+  } else {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(x, b2));
   }
 }
 
@@ -212,6 +234,18 @@ __device__ __forceinline__ void mfma16_f16_inplace(s16x8 a, s16x8 b, f32x4& c) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// The eight [first, last) bytes of a 64-row block's four 16-row groups (wave-uniform address) through the scalar cache.
+// As the vector load hipcc makes of a plain read (it cannot prove the table read-only), the value was waited for with
+// vmcnt(0) right where it was requested - and that counter also holds every LDS-DMA / prefetch load the kernel has issued
+// for its NEXT part or unit to hide behind this epilogue: the epilogue began with a full memory latency.
+__device__ __forceinline__ void load_out_range(const uint8_t* p, unsigned (&rng)[2]) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  rng[0] = v[0];
+  rng[1] = v[1];
+}
+
 // Per-lane epilogue parameters (bias / scale / offset, and for the statistics epilogue the valid-row table), fetched
 // by epilogue_prefetch: before the K loop where the registers are affordable (see variant 2), else right before use.
 struct EpiRegs {
@@ -250,11 +284,7 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
       // rows of the four 16-row groups q that count for the group maxima: [grp][first, last) bytes, 8 contiguous ones
       // (mbase is a multiple of 64 rows, the table 8-byte aligned)
       e.rng[0] = e.rng[1] = 0x10001000u;
-      if (a.out_range) {
-        const uint2 v = *(const uint2*)(a.out_range + 2 * (mbase >> 4));
-        e.rng[0] = v.x;
-        e.rng[1] = v.y;
-      }
+      if (a.out_range) load_out_range((const uint8_t*)a.out_range + 2 * (mbase >> 4), e.rng);
     }
   } else if constexpr (EPI == kEpiStats) {
 #pragma unroll
@@ -304,11 +334,7 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
       // rows of the four 16-row groups q that count for the group maxima: [grp][first, last) bytes, 8 contiguous ones
       // (mbase is a multiple of 64 rows, the table 8-byte aligned)
       e.rng[0] = e.rng[1] = 0x10001000u;
-      if (a.out_range) {
-        const uint2 v = *(const uint2*)(a.out_range + 2 * (mbase >> 4));
-        e.rng[0] = v.x;
-        e.rng[1] = v.y;
-      }
+      if (a.out_range) load_out_range((const uint8_t*)a.out_range + 2 * (mbase >> 4), e.rng);
     }
   } else if constexpr (EPI == kEpiStats) {
 #pragma unroll
@@ -365,7 +391,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = mbase + q * 16 + fr_i;
-      float y[16];
+      // y[p * 4 + r] as pairs y2[p * 2 + j] = (r = 2j, 2j + 1): bias and BatchNorm on both values of a pair at once
+      // (v_pk_add_f32 / v_pk_fma_f32; the accumulators, the parameter quads and the converted words are register pairs in
+      // exactly this order - left to itself hipcc paired the values across fragments and spent two moves and one
+      // shift / mask / or per element on getting them there and back)
+      f32x2 y2[8];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         f32x4 b4, s4 = {1.f, 1.f, 1.f, 1.f}, o4 = {0.f, 0.f, 0.f, 0.f};
@@ -387,14 +417,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float z = acc[p][q][r] + b4[r];
-          // Kaldi ApplyFloor(0): a NaN stays a NaN (fmaxf would turn it into 0).  (v_maximum3_f32 does the same in one
-          // instruction, but with it the 512 x 128 stream-K kernel and the per-tile kernel stopped agreeing bit for bit
-          // in the fp16mx2 mode - not understood, reverted.)
-          z = (z < relu_floor) ? relu_floor : z;
-          y[p * 4 + r] = __builtin_fmaf(z, s4[r], o4[r]);   // scale 1 / offset 0 without BatchNorm
+        for (int j = 0; j < 2; ++j) {
+          f32x2 z = f32x2{acc[p][q][2 * j], acc[p][q][2 * j + 1]} + f32x2{b4[2 * j], b4[2 * j + 1]};
+          z = f32x2{apply_floor(z[0], relu_floor), apply_floor(z[1], relu_floor)};
+          // one rounding per value (fma); scale 1 / offset 0 without BatchNorm
+          y2[p * 2 + j] = __builtin_elementwise_fma(z, f32x2{s4[2 * j], s4[2 * j + 1]}, f32x2{o4[2 * j], o4[2 * j + 1]});
         }
+      }
+      float y[16];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        y[2 * v] = y2[v][0];
+        y[2 * v + 1] = y2[v][1];
       }
       if constexpr (EPI == kEpiF32) {
         if (row < a.m_valid) {
@@ -407,13 +441,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         unsigned int hw[8], lw[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
-          const uint16_t h0 = to16<F16>(y[2 * v]);
-          const uint16_t h1 = to16<F16>(y[2 * v + 1]);
-          hw[v] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+          hw[v] = to16x2<F16>(y2[v]);
           if constexpr (SPLIT) {
-            const uint16_t l0 = to16<F16>(y[2 * v] - from16<F16>(h0));
-            const uint16_t l1 = to16<F16>(y[2 * v + 1] - from16<F16>(h1));
-            lw[v] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+            const f32x2 back = {from16<F16>((uint16_t)hw[v]), from16<F16>((uint16_t)(hw[v] >> 16))};
+            lw[v] = to16x2<F16>(y2[v] - back);
           }
         }
         float ymax = 0.f;   // max |y| of this lane's 16 values (its share of the row's 64 columns)
@@ -501,31 +532,44 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       // are the same in every lane, so the branch is wave-uniform; the arithmetic is that of the masked path (the
       // square is rounded on its own there, hence __fmul_rn here).
       const int first = __builtin_amdgcn_readfirstlane(e.first[p]), last = __builtin_amdgcn_readfirstlane(e.last[p]);
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      // a lane's four rows r of a column as two pairs (r = 0, 1) and (2, 3): bias, BatchNorm, square and sums on both values
+      // of a pair at once (v_pk_*_f32); the sum of a column is ((z0 + z2) + (z1 + z3)) in both branches
+      float s1[4], s2[4];
       if (first == 0 && last == 16) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float z = acc[p][q][r] + e.bs[q];
-            z = (z < relu_floor) ? relu_floor : z;
-            z = __builtin_fmaf(z, e.sc[q], e.of[q]);
-            s1[q] += z;
-            s2[q] += __fmul_rn(z, z);
+        for (int q = 0; q < 4; ++q) {
+          const f32x2 b2 = {e.bs[q], e.bs[q]}, c2 = {e.sc[q], e.sc[q]}, o2 = {e.of[q], e.of[q]};
+          f32x2 za = f32x2{acc[p][q][0], acc[p][q][1]} + b2, zb = f32x2{acc[p][q][2], acc[p][q][3]} + b2;
+          za = f32x2{apply_floor(za[0], relu_floor), apply_floor(za[1], relu_floor)};
+          zb = f32x2{apply_floor(zb[0], relu_floor), apply_floor(zb[1], relu_floor)};
+          za = __builtin_elementwise_fma(za, c2, o2);
+          zb = __builtin_elementwise_fma(zb, c2, o2);
+          const f32x2 t1 = za + zb;
+          f32x2 t2;
+          {
+#pragma clang fp contract(off)   // the squares are rounded on their own, as in the masked branch (__fmul_rn)
+            const f32x2 qa = za * za, qb = zb * zb;
+            t2 = qa + qb;
           }
+          s1[q] = t1[0] + t1[1];
+          s2[q] = t2[0] + t2[1];
+        }
       } else {
+        bool ok[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = fr_g * 4 + r;
-          const bool ok = (rr >= first) && (rr < last);
+        for (int r = 0; r < 4; ++r) ok[r] = (fr_g * 4 + r >= first) && (fr_g * 4 + r < last);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float z = acc[p][q][r] + e.bs[q];
-            z = (z < relu_floor) ? relu_floor : z;
-            z = __builtin_fmaf(z, e.sc[q], e.of[q]);
-            s1[q] += ok ? z : 0.f;
-            s2[q] += ok ? __fmul_rn(z, z) : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          float z[4], zz[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = apply_floor(acc[p][q][r] + e.bs[q], relu_floor);
+            t = __builtin_fmaf(t, e.sc[q], e.of[q]);
+            z[r] = ok[r] ? t : 0.f;
+            zz[r] = ok[r] ? __fmul_rn(t, t) : 0.f;
           }
+          s1[q] = (z[0] + z[2]) + (z[1] + z[3]);
+          s2[q] = (zz[0] + zz[2]) + (zz[1] + zz[3]);
         }
       }
 #pragma unroll
@@ -2417,6 +2461,10 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
   };
   auto commit = [&](int buf) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
+    // the conversions below depend on nothing but pv: without this hipcc hoists them out of the loop over the two halves of
+    // the interval, to right behind the loads - and waits for the next unit's features in front of this unit's MFMAs
+#pragma unroll
+    for (int i = 0; i < kFirstMaxSlots; ++i) asm volatile("" : "+v"(pv[i]));
     uint16_t* hi = (uint16_t*)(xbuf + buf * 2 * plane_bytes);
     uint16_t* lo = (uint16_t*)(xbuf + buf * 2 * plane_bytes + plane_bytes);
 #pragma unroll
@@ -2521,16 +2569,29 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
           {
             const char* xh_b = xbuf + buf * 2 * plane_bytes;
             const char* xl_b = xh_b + plane_bytes;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-              s16x8 xh[4], xl[4], wl[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                xh[q] = *(const s16x8*)(xh_b + q * 16 * dp * 2 + xo[st]);
-                xl[q] = *(const s16x8*)(xl_b + q * 16 * dp * 2 + xo[st]);
-              }
+            // Fragment reads rotate through the three products of a step (w_lo x_hi, w_hi x_hi, w_hi x_lo): a fragment set is
+            // re-read for step st + 1 right behind the last 16 MFMAs that use it in step st, at least 16 MFMAs before its next use.  In this kernel a
+            // wave multiplies ALONE on its SIMD (its partner converts and stores meanwhile), so a read waited for in front of a
+            // step's MFMAs is matrix-pipe idle time: with the reads of a step issued together at its head the two multiply
+            // phases of an interval took 2 x 3.5 us against 1.5 us of MFMA issue each.
+            s16x8 xh[4], xl[4], wl[4];
+            auto rd_wl = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
               for (int p = 0; p < 4; ++p) wl[p] = *(const s16x8*)(wlo_s + wl_rd[p] + (((st * 4 + fr_g) ^ wl_key[p]) << 4));
+            };
+            auto rd_xh = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) xh[q] = *(const s16x8*)(xh_b + q * 16 * dp * 2 + xo[st]);
+            };
+            auto rd_xl = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) xl[q] = *(const s16x8*)(xl_b + q * 16 * dp * 2 + xo[st]);
+            };
+            rd_wl(0);
+            rd_xh(0);
+            rd_xl(0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
               // three products per accumulator, 16 independent MFMAs between two on the same one.  fp16: accumulators
               // tied in place from inline asm (left to itself hipcc rotates them through copies: spills); the first MFMA
               // of a unit is the builtin with a literal-zero addend - a v_mov clearing the accumulator right in front of
@@ -2542,13 +2603,9 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
                   if (st == 0 || !F16) acc[p][q] = mfma16<F16>(wl[p], xh[q], st == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[p][q]);
                   else mfma16_f16_inplace(wl[p], xh[q], acc[p][q]);
                 }
-#pragma unroll
-              for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  if constexpr (F16) mfma16_f16_inplace(wh[p][st], xl[q], acc[p][q]);
-                  else acc[p][q] = mfma16<F16>(wh[p][st], xl[q], acc[p][q]);
-                }
+              __builtin_amdgcn_sched_barrier(0);
+              if (st < 3) rd_wl(st + 1);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -2556,7 +2613,19 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
                   if constexpr (F16) mfma16_f16_inplace(wh[p][st], xh[q], acc[p][q]);
                   else acc[p][q] = mfma16<F16>(wh[p][st], xh[q], acc[p][q]);
                 }
-              __builtin_amdgcn_sched_barrier(0);   // the fragments of one step at a time (hoisted, the reads of all four spill)
+              __builtin_amdgcn_sched_barrier(0);
+              if (st < 3) rd_xh(st + 1);   // needed by the next step's first product: 16 MFMAs (>= 256 cycles) ahead of it
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if constexpr (F16) mfma16_f16_inplace(wh[p][st], xl[q], acc[p][q]);
+                  else acc[p][q] = mfma16<F16>(wh[p][st], xl[q], acc[p][q]);
+                }
+              __builtin_amdgcn_sched_barrier(0);
+              if (st < 3) rd_xl(st + 1);
+              __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (F16) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
           }
