@@ -294,11 +294,14 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
       e.sc[q] = a.bn ? a.scale[col] : 1.f;
       e.of[q] = a.bn ? a.offset[col] : 0.f;
     }
+    // valid rows of the block's four 16-row groups: 8 contiguous bytes at a wave-uniform, 8-byte aligned address (mbase is
+    // a multiple of 64) -> one scalar load (see load_out_range: as byte loads they queued behind the next part's LDS-DMA)
+    unsigned gr[2];
+    load_out_range((const uint8_t*)a.grp_range + 2 * (mbase >> 4), gr);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int grp = (mbase + p * 16) >> 4;
-      e.first[p] = a.grp_range[2 * grp];
-      e.last[p] = a.grp_range[2 * grp + 1];
+      e.first[p] = (int)(int8_t)(gr[p >> 1] >> (16 * (p & 1)));
+      e.last[p] = (int)(int8_t)(gr[p >> 1] >> (16 * (p & 1) + 8));
     }
   }
 }
@@ -344,11 +347,14 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
       e.sc[q] = a.bn ? par[128 + c] : 1.f;
       e.of[q] = a.bn ? par[256 + c] : 0.f;
     }
+    // valid rows of the block's four 16-row groups: 8 contiguous bytes at a wave-uniform, 8-byte aligned address (mbase is
+    // a multiple of 64) -> one scalar load (see load_out_range: as byte loads they queued behind the next part's LDS-DMA)
+    unsigned gr[2];
+    load_out_range((const uint8_t*)a.grp_range + 2 * (mbase >> 4), gr);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int grp = (mbase + p * 16) >> 4;
-      e.first[p] = a.grp_range[2 * grp];
-      e.last[p] = a.grp_range[2 * grp + 1];
+      e.first[p] = (int)(int8_t)(gr[p >> 1] >> (16 * (p & 1)));
+      e.last[p] = (int)(int8_t)(gr[p >> 1] >> (16 * (p & 1) + 8));
     }
   }
 }
@@ -1930,7 +1936,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     // one-barrier-per-step form (group 0: LOAD_j, COMPUTE_j; group 1: COMPUTE_{j-1}, LOAD_j) was measured 6 % slower:
     // without the second barrier the groups drift into loading at the same time.
     // (open_part leaves no compiler-tracked memory load behind: a vmcnt(0) of hipcc's in front of a first use INSIDE
-    // the K loop would drain the LDS-DMA queue on every pass.)
+    // the K loop would drain the LDS-DMA queue on every pass.  The exchange loads above ARE tracked, and the wait inside
+    // wait_and_barrier is inline asm hipcc does not look into: without the builtin wait here - the same instruction, but
+    // one its scoreboard sees - the first COMPUTE segment of every four-step block carried vmcnt(31) ... vmcnt(0) in front
+    // of the MFMAs that first touch each accumulator, i.e. a full drain of the LDS-DMA queue once per block.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt / lgkmcnt untouched)
     wait_and_barrier(0);               // the first two steps have landed (and the previous epilogue's stores are out)
     if (group == 1) plain_barrier();
     Frags f;
