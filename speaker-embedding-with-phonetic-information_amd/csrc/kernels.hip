@@ -2570,9 +2570,12 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
         pending = false;
         const float* par = par_all + (wave >> 1) * 384;
         EpiRegs er;
-        epilogue_prefetch_lds<kEpiAct, true>(a, par, pend_mbase, (wave & 1) * 64, lane, er);
+        // the parameters of the block's 16 columns per lane: held in registers (48) where the block's fragments are dead and
+        // nothing else competes for them, re-read from LDS per 16-row group where the 4-bit residual is emitted as well
+        constexpr bool LZ = PrecEmitsLo4(EPREC);
+        epilogue_prefetch_lds<kEpiAct, LZ>(a, par, pend_mbase, (wave & 1) * 64, lane, er);
         float gm[4] = {0.f, 0.f, 0.f, 0.f};
-        gemm_epilogue<EPREC, kEpiAct, true>(a, acc, pend_mbase, n0w, lane, er, gm, 0, par, (wave & 1) * 64);
+        gemm_epilogue<EPREC, kEpiAct, LZ>(a, acc, pend_mbase, n0w, lane, er, gm, 0, par, (wave & 1) * 64);
       }
       if (half == 0 && has_unit) {
         if (cols_valid) {
