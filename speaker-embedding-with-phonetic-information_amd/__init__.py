@@ -229,10 +229,14 @@ class Context:
         _check(L.xv_ctx_info(self._h, ctypes.byref(mi), ctypes.byref(p), ctypes.byref(d)))
         self.info, self.precision, self.device = mi, p.value, d.value
 
-    def __del__(self):
+    def close(self):
+        """Frees the context's device and pinned memory now (otherwise when the object is collected)."""
         if getattr(self, "_h", None) and self._h.value and lib is not None:
             lib().xv_ctx_free(self._h)
             self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        self.close()
 
     def forward_batch(self, feats, row_offsets):
         """feats: float32 numpy [rows, input_dim]; row_offsets: int32 [B+1] -> numpy [B, output_dim]."""

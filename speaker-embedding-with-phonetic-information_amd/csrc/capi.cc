@@ -542,7 +542,7 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
     a.out_lo4s = (uint8_t*)d->out_lo4_scale;
     if (d->precision == xv::kPrecFp16Mx2 && !xv::gemm_mx2_applicable(a))
       return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX2 needs what XV_PREC_FP16MX needs and the 4-bit planes of the "
-                              "weights and of every source (whole 128-column steps, sources of at most 512 columns)");
+                              "weights and of every source (whole 128-column steps)");
     if (d->precision == xv::kPrecFp16Mx && !xv::gemm_mx_applicable(a))
       return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX needs the residual plane, a group-max table per source, "
                               "K groups of whole 128-column blocks and an even number of 128-row tiles");

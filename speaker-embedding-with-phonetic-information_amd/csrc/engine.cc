@@ -202,7 +202,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);   // both tile orders (TileMxScales)
       }
       if (precision == kPrecFp16Mx2) {
-        // second K walk: every source a whole number of 128-column steps, at most 512 columns wide (kernels.hip,
+        // second K walk: every source another layer's output padded to whole 128-column steps (kernels.hip,
         // gemm_mx2_applicable).  A layer that cannot run it must read the network input only (it then runs kPrecFp16x3E
         // on the two planes prep_input writes): the other layers' outputs have no fp16 residual plane in this mode
         bool lo_ok = b.w4 != kNone, input_only = true;

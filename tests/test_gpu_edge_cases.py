@@ -66,6 +66,28 @@ def test_non_finite_features_stay_in_their_utterance(v2):
         assert np.array_equal(out[i], base[i]), i      # neighbours are bit-identical: no cross-utterance arithmetic
 
 
+def test_contexts_give_their_device_memory_back(v2):
+    # the 4-bit residual planes of the default arithmetic were allocated per lane and never freed.  Ten contexts
+    # created, run (activation buffers of both lanes, tables, pinned slots) and destroyed must not keep device memory.
+    import torch
+    P, net, line, model, ctx, ev = v2
+    feats, offs = H.pack([H.features(600 + i, 400) for i in range(8)])
+
+    def cycle():
+        c = P.Context(model)
+        c.forward_batch(feats, offs)
+        c.close()
+
+    cycle()                                 # one-time allocations of the runtime (code objects, streams)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)     # one context of this size holds ~60 MB
+
+
 def test_repeatability_and_single_utterance_batch(v2):
     P, net, line, model, ctx, ev = v2
     x = H.features(77, 400)
