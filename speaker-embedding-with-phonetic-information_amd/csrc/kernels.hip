@@ -544,12 +544,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       if (first == 0 && last == 16) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x2 b2 = {e.bs[q], e.bs[q]}, c2 = {e.sc[q], e.sc[q]}, o2 = {e.of[q], e.of[q]};
-          f32x2 za = f32x2{acc[p][q][0], acc[p][q][1]} + b2, zb = f32x2{acc[p][q][2], acc[p][q][3]} + b2;
-          za = f32x2{apply_floor(za[0], relu_floor), apply_floor(za[1], relu_floor)};
-          zb = f32x2{apply_floor(zb[0], relu_floor), apply_floor(zb[1], relu_floor)};
-          za = __builtin_elementwise_fma(za, c2, o2);
-          zb = __builtin_elementwise_fma(zb, c2, o2);
+          // bias and ReLU per value (as pairs they need the column's bias / scale / offset splat into register pairs: six
+          // more registers, which cost the single-pass per-tile kernel its second workgroup per CU), BatchNorm, squares and
+          // sums as pairs
+          float z0 = apply_floor(acc[p][q][0] + e.bs[q], relu_floor), z1 = apply_floor(acc[p][q][1] + e.bs[q], relu_floor);
+          float z2 = apply_floor(acc[p][q][2] + e.bs[q], relu_floor), z3 = apply_floor(acc[p][q][3] + e.bs[q], relu_floor);
+          z0 = __builtin_fmaf(z0, e.sc[q], e.of[q]);
+          z1 = __builtin_fmaf(z1, e.sc[q], e.of[q]);
+          z2 = __builtin_fmaf(z2, e.sc[q], e.of[q]);
+          z3 = __builtin_fmaf(z3, e.sc[q], e.of[q]);
+          const f32x2 za = {z0, z1}, zb = {z2, z3};
           const f32x2 t1 = za + zb;
           f32x2 t2;
           {
@@ -839,6 +843,9 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier_n(int n) {   // n wave-uni
   }
 }
 
+// The single-pass instantiations run two workgroups per CU (4 waves per SIMD): 128 registers.  hipcc lands on 128-130 for
+// them depending on epilogue details, and at 130 the second workgroup does not fit (tdnn5, fp16: 0.19 -> 0.28 ms): the
+// minimum is stated rather than hoped for.
 template <int PREC, int EPI>
 __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
