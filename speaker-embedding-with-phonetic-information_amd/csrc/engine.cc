@@ -1052,9 +1052,12 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       }
     } else {
       ga.m_tiles = plan.b_pad / kBM;
-      // few rows, long K (3000 for the embedding layer): split K over up to 8 slices, >= 12 steps each (measured on the
-      // 256-chunk embedding layer: 4 steps x 24 slices 32.7 us for GEMM + reduction, 6 x 16 26.8, 12 x 8 25.9)
-      const int per = std::max(12, (ksteps + 7) / 8);
+      // few rows, long K (3000 for the embedding layer): K is split over up to 24 slices of at least 4 steps - a rule that does
+      // not depend on the batch, so an utterance's sums are formed in the same order whatever it is batched with.  Measured
+      // on the 256-chunk embedding layer (94 steps, 2 x 4 tiles), GEMM + reduction: 12 steps x 8 slices 23.3 us, 8 x 12 20.4,
+      // 6 x 16 19.4, 4 x 24 18.8, 3 x 32 19.3, 2 x 47 25.2 (with the workgroups spread over all XCDs, kernels.hip; while they
+      // all sat on two of them more slices only queued: 25.9 / 31.6 / 36.8 us for 8 / 12 / 24 slices)
+      const int per = std::max(4, (ksteps + 23) / 24);
       ga.ksteps_per_slice = per;
       ga.ksplit = (ksteps + per - 1) / per;
       if (ga.ksplit > 1) {

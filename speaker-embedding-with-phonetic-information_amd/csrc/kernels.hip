@@ -601,6 +601,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
   }
 }
 
+// (defined with the v2 kernel below: LDS-DMA from inline asm, invisible to hipcc's wait-count scoreboard)
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_addr);
+constexpr int kSplitKStages = 4;   // LDS ring of the split-K instantiation of tdnn_gemm_kernel
+
 template <int PREC, int EPI>
 __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   constexpr bool SPLIT = PrecXPlanes(PREC) == 2;   // activations carry a residual plane
@@ -620,10 +624,19 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   // XCD-aware tile order: block b lands on XCD b%8 (observed dispatch); the column tiles of one
   // row tile are consecutive on the same XCD so the activation rows are re-read from its L2.
   const int bid = blockIdx.x;
-  const int xcd = bid & 7;
-  const int slot = bid >> 3;
-  const int nt = slot % a.n_tiles;
-  const int mt = (slot / a.n_tiles) * 8 + xcd;
+  int nt, mt;
+  if constexpr (EPI == kEpiSplitK) {
+    // a segment-level layer has one or two row tiles: with the mapping below all its workgroups sat on XCD 0 and 1 (64 of
+    // them on 64 CUs behind two L2s, and with more K slices they queued there: 24 slices took 32 us against 21 for 8).
+    // Plain order instead: consecutive workgroups go to consecutive XCDs.
+    nt = bid % a.n_tiles;
+    mt = bid / a.n_tiles;
+  } else {
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    nt = slot % a.n_tiles;
+    mt = (slot / a.n_tiles) * 8 + xcd;
+  }
   if (mt >= a.m_tiles) return;
   const int m0 = mt * kBM;
   const int n0 = nt * kBN;
@@ -709,6 +722,65 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
       if (--seg_left == 0 && ld_seg + 1 < a.nseg) open_seg(++ld_seg);
     }
     S = s_end - s_begin;
+  }
+  if constexpr (EPI == kEpiSplitK) {
+    // A K slice of a segment-level layer (the embedding affine: 256 rows, K = 3000, 8 slices of 12 steps on 64 workgroups)
+    // is a chain of memory latencies: its weights are cold (the frame-level layers have turned the caches over) and with
+    // one step of lookahead every step waits ~1.5 us for its tile - 21 us for 0.8 GFLOP.  Here the ring is kSplitKStages
+    // deep and three steps are in flight; the DMA is issued from inline asm and counted by hand (left to hipcc, every
+    // fragment read that may alias a pending LDS-DMA gets a vmcnt(0)).
+    constexpr int NST = kSplitKStages;
+    constexpr int PER = 2 * (NPX + NPW);   // DMA instructions per wave and stage
+    static_assert(PER * (NST - 2) < 64, "vmcnt is six bits");
+    const unsigned lds0 = (unsigned)(size_t)(XV_AS3 char*)smem;
+    auto stage_loads_asm = [&](int stage) __attribute__((always_inline)) {
+      const unsigned st = lds0 + stage * STAGE + wave * 2048;   // chunk c = 2 * wave + u at c * 1024
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        glds16_asm(xp_hi[u], st + u * 1024);
+        if constexpr (SPLIT) glds16_asm(xp_lo[u], st + kTileBytes + u * 1024);
+        glds16_asm(wp_hi[u], st + NPX * kTileBytes + u * 1024);
+        if constexpr (WSPLIT) glds16_asm(wp_lo[u], st + (NPX + 1) * kTileBytes + u * 1024);
+        xp_hi[u] += kBK;
+        wp_hi[u] += kBK;
+        if constexpr (SPLIT) xp_lo[u] += kBK;
+        if constexpr (WSPLIT) wp_lo[u] += kBK;
+      }
+      if (--seg_left == 0 && ld_seg + 1 < a.nseg) open_seg(++ld_seg);
+    };
+    for (int t = 0; t < NST - 1 && t < S; ++t) stage_loads_asm(t);
+    for (int s = 0; s < S; ++s) {
+      // stage s has landed once at most the stages issued after it are outstanding; everyone is past its reads of stage
+      // s - 1, whose slot the loads issued below overwrite
+      const int later = min(S - 1 - s, NST - 2);
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PER) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const char* st = smem + (s % NST) * STAGE;
+      s16x8 xh[4], xl[4], wh[4], wl[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        xh[f] = *(const s16x8*)(st + x_rd + f * 1024);
+        wh[f] = *(const s16x8*)(st + w_rd + f * 1024);
+        if constexpr (SPLIT) xl[f] = *(const s16x8*)(st + x_rd + kTileBytes + f * 1024);
+        if constexpr (WSPLIT) wl[f] = *(const s16x8*)(st + w_rd + kTileBytes + f * 1024);
+      }
+      if (s + NST - 1 < S) stage_loads_asm((s + NST - 1) % NST);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // the products in the order of the two-stage loop below: same bits
+          if constexpr (WSPLIT) acc[p][q] = mfma16<F16>(wl[p], xh[q], acc[p][q]);
+          if constexpr (SPLIT) acc[p][q] = mfma16<F16>(wh[p], xl[q], acc[p][q]);
+          acc[p][q] = mfma16<F16>(wh[p], xh[q], acc[p][q]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    EpiRegs er0;
+    float gm0[4] = {0.f, 0.f, 0.f, 0.f};
+    gemm_epilogue<PREC, EPI>(a, acc, m0 + wave_m * 64, n0 + wave_n * 64, lane, er0, gm0, 0);
+    return;
   }
   stage_loads(0);
   __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and orders the LDS writes
@@ -2276,7 +2348,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
   const int col = (int)(idx - (long)row * per_row) * 4;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   const long slab = (long)rows * n_pad;
-  for (int k = 0; k < a.ksplit; ++k) v += *(const f32x4*)(a.splitk_ws + k * slab + (long)row * n_pad + col);
+  // the slices are added in slice order (one fixed order: same bits for any number of resident workgroups), but fetched
+  // eight at a time: one load per pass of a loop of unknown length is a chain of memory latencies (0.6-0.9 us per slice)
+  const float* src = a.splitk_ws + (long)row * n_pad + col;
+  int k = 0;
+  for (; k + 8 <= a.ksplit; k += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = *(const f32x4*)(src + (k + j) * slab);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += t[j];
+  }
+  {
+    f32x4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (k + j < a.ksplit) ? *(const f32x4*)(src + (k + j) * slab) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k + j < a.ksplit) v += t[j];
+  }
   const f32x4 b = *(const f32x4*)(a.bias + col);
   float y[4];
 #pragma unroll
@@ -2305,7 +2395,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 
 template <int PREC, int EPI>
 static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
+  constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * kSplitKStages;
   static std::atomic<unsigned long long> attr_done{0};
   int attr_dev = 0;
   if (lds_attr_needed(&attr_done, &attr_dev)) {
@@ -2314,8 +2404,7 @@ static hipError_t launch_splitk(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
   }
-  const int mt8 = (a.m_tiles + 7) / 8 * 8;
-  dim3 grid(mt8 * a.n_tiles, a.ksplit), block(256);
+  dim3 grid(a.m_tiles * a.n_tiles, a.ksplit), block(256);
   note_kernel("", PREC, kEpiSplitK, 0);
   XV_LAUNCH((tdnn_gemm_kernel<PREC, kEpiSplitK>), grid, block, lds, s, a);
   hipError_t e = hipGetLastError();
