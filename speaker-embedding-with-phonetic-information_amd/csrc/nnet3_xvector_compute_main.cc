@@ -237,9 +237,18 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   else if (name == "nnet-config") o->nnet_config = value;
   else if (name == "precision") o->precision = value;
   else if (name == "config") return ReadConfigFile(value, o, err);
-  else {
-    // the rest of upstream's surface (compiler / optimisation / cached-compiler options) has no meaning
-    // here: accept and ignore, like the contract in SURVEY.md §8(b) asks
+  else if (name == "ivectors" || name == "online-ivectors" ||
+           (name == "frame-subsampling-factor" && value != "1") || (name == "use-priors" && value != "false")) {
+    // options of upstream's nnet3-compute that CHANGE the result (steps/nnet3/compute_output.sh:117,
+    // make_bottleneck_features_new.sh:109 with an ivector directory): ignoring them would write different numbers under
+    // the same command line
+    *err = "option --" + name + (has_value ? "=" + value : "") + " is not supported (it changes the output; this tool has no i-vector input, "
+           "output subsampling or prior subtraction)";
+    return false;
+  } else {
+    // the rest of upstream's surface (compiler / optimisation / cached-compiler options, chunking of the recurrent-network
+    // tools: --frames-per-chunk, --extra-left-context ...) has no meaning for these feed-forward networks: accept and
+    // ignore, like the contract in SURVEY.md §8(b) asks
     XWARN("ignoring option --" << name << (has_value ? "=" + value : ""));
   }
   return true;

@@ -225,6 +225,14 @@ def test_cli_contract_without_gpu(tmp_path):
     assert r.returncode == 1 and b"invalid integer" in r.stderr
     r = _run("nnet3-xvector-compute", "--use-gpu=no", "/nonexistent.raw", "ark:/dev/null", "ark:/dev/null")
     assert r.returncode == 255 and b"cannot open" in r.stderr
+    # upstream options that only tune the computation are ignored with a warning (compute_output.sh:117 passes them to
+    # nnet3-compute); options that change the numbers are refused rather than ignored
+    r = _run("nnet3-compute", "--frames-per-chunk=50", "--extra-left-context=10", "--frame-subsampling-factor=1", "/nonexistent.raw",
+             "ark:/dev/null", "ark:/dev/null")
+    assert r.returncode == 255 and r.stderr.count(b"ignoring option") == 3
+    for opt in ("--frame-subsampling-factor=3", "--online-ivectors=scp:iv.scp", "--ivectors=scp:iv.scp", "--use-priors=true"):
+        r = _run("nnet3-compute", opt, "/nonexistent.raw", "ark:/dev/null", "ark:/dev/null")
+        assert r.returncode == 1 and b"not supported" in r.stderr, opt
     import torch
     if not torch.cuda.is_available():
         net, line = H.synth_model("v2_xvector")
