@@ -538,8 +538,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
       // are the same in every lane, so the branch is wave-uniform; the arithmetic is that of the masked path (the
       // square is rounded on its own there, hence __fmul_rn here).
       const int first = __builtin_amdgcn_readfirstlane(e.first[p]), last = __builtin_amdgcn_readfirstlane(e.last[p]);
-      // a lane's four rows r of a column as two pairs (r = 0, 1) and (2, 3): bias, BatchNorm, square and sums on both values
-      // of a pair at once (v_pk_*_f32); the sum of a column is ((z0 + z2) + (z1 + z3)) in both branches
+      // a lane's four rows r of a column as two pairs (r = 0, 1) and (2, 3): squares and sums on both values of a pair at once
+      // (v_pk_*_f32); the sum of a column is ((z0 + z2) + (z1 + z3)) in both branches
       float s1[4], s2[4];
       if (first == 0 && last == 16) {
 #pragma unroll
@@ -724,11 +724,11 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     S = s_end - s_begin;
   }
   if constexpr (EPI == kEpiSplitK) {
-    // A K slice of a segment-level layer (the embedding affine: 256 rows, K = 3000, 8 slices of 12 steps on 64 workgroups)
-    // is a chain of memory latencies: its weights are cold (the frame-level layers have turned the caches over) and with
-    // one step of lookahead every step waits ~1.5 us for its tile - 21 us for 0.8 GFLOP.  Here the ring is kSplitKStages
-    // deep and three steps are in flight; the DMA is issued from inline asm and counted by hand (left to hipcc, every
-    // fragment read that may alias a pending LDS-DMA gets a vmcnt(0)).
+    // A K slice of a segment-level layer (the embedding affine: 256 rows, K = 3000, 24 slices of 4 steps on 192 workgroups)
+    // is a short chain of memory latencies: its weights are cold (the frame-level layers have turned the caches over) and
+    // with one step of lookahead every step waits for its tile.  Here the ring is kSplitKStages deep and three steps are in
+    // flight; the DMA is issued from inline asm and counted by hand (left to hipcc, every fragment read that may alias a
+    // pending LDS-DMA gets a vmcnt(0)).
     constexpr int NST = kSplitKStages;
     constexpr int PER = 2 * (NPX + NPW);   // DMA instructions per wave and stage
     static_assert(PER * (NST - 2) < 64, "vmcnt is six bits");
