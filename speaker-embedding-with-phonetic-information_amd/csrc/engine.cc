@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <sstream>
+#include <thread>
 
 namespace xv {
 
@@ -246,7 +248,9 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
   memcpy(blob.data(), &h, sizeof h);
   memcpy(blob.data() + sizeof h, bl.data(), (size_t)nl * sizeof(BlobLayer));
   uint8_t* data = blob.data() + h.data_offset;
-  for (int i = 0; i < nl; ++i) {
+  // one worker per layer (disjoint regions of the image): packing the v2 x-vector as fp16mx2 - three images per matrix - took
+  // 0.14 s on one thread, a third of the start-up of a job that then needs 12 ms of device time for its 300 utterances
+  auto pack_layer = [&](int i) {
     const AffineLayer& L = prog.layers[i];
     const BlobLayer& b = bl[i];
     uint16_t* whi = (uint16_t*)(data + b.w_hi);
@@ -347,6 +351,26 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
       offset[n] = L.bn ? L.bn_offset[n] : 0.f;
     }
     // padded output columns: bias 0, scale 0, offset 0 -> they stay exactly 0 downstream
+  };
+  {
+    std::vector<std::thread> workers;
+    std::vector<std::exception_ptr> errs((size_t)nl);
+    for (int i = 1; i < nl; ++i)
+      workers.emplace_back([&, i]() {
+        try {
+          pack_layer(i);
+        } catch (...) {
+          errs[(size_t)i] = std::current_exception();
+        }
+      });
+    try {
+      if (nl > 0) pack_layer(0);
+    } catch (...) {
+      errs[0] = std::current_exception();
+    }
+    for (std::thread& t : workers) t.join();
+    for (const std::exception_ptr& e : errs)
+      if (e) std::rethrow_exception(e);
   }
   return blob;
 }

@@ -334,6 +334,11 @@ int main(int argc, char** argv) {
             "(the option is accepted so that unchanged recipes work)");
 
     // ---- model ---------------------------------------------------------------------------------
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    if (opt.fast_min_pooled >= 0) setenv("XVEC_FAST_MIN_POOLED", std::to_string(opt.fast_min_pooled).c_str(), 1);   // read by the engine
+    // (Bringing the HIP runtime up on a second thread meanwhile was tried: its 0.1-0.2 s of mmap / ioctl traffic hold the
+    // address-space lock the page faults of the 28 MB model read wait for - the read went from 0.09 to 0.30 s.)
     xv::RawNnet net;
     net.ReadFrom(nnet_rx);
     if (!opt.nnet_config.empty()) {
@@ -351,7 +356,11 @@ int main(int argc, char** argv) {
     if (g_frame_job && prog.output_is_segment)
       throw xv::KioError("the output node follows the statistics pooling; nnet3-compute expects a frame-level output");
 
+    const double t_model = since_start();
     // ---- device --------------------------------------------------------------------------------
+    const bool policy_default = opt.precision == "default";
+    const std::vector<uint8_t> blob = xv::PackModelPolicy(prog, precision, &precision);
+    const double t_pack = since_start();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
       throw xv::EngineError("no HIP device available and this build has no CPU path");
@@ -362,11 +371,13 @@ int main(int argc, char** argv) {
       device = job > 0 ? (job - 1) % ndev : 0;
     }
     if (device >= ndev) device %= ndev;
-    if (opt.fast_min_pooled >= 0) setenv("XVEC_FAST_MIN_POOLED", std::to_string(opt.fast_min_pooled).c_str(), 1);   // read by the engine
-    const bool policy_default = opt.precision == "default";
-    const std::vector<uint8_t> blob = xv::PackModelPolicy(prog, precision, &precision);
+    const double t_hip = since_start();
     if (policy_default) opt.precision = std::string("default = ") + xv::PrecisionName(precision);
     xv::Engine engine(blob.data(), blob.size(), device);
+    if (getenv("XVEC_TIMING"))
+      XLOG("start-up stages: model read + lowered " << t_model << " s, weights packed " << (t_pack - t_model)
+                                                       << " s, HIP runtime up " << (t_hip - t_pack)
+                                                       << " s, engine (upload, buffers, streams) " << (since_start() - t_hip) << " s");
     XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
                    << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
                    << opt.precision << ", " << (engine.weight_bytes() >> 20) << " MiB of packed weights");
