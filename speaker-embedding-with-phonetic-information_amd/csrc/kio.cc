@@ -141,6 +141,16 @@ void Input::Read(void* dst, size_t n) {
   if (!f_ || fread(dst, 1, n, f_) != n) throw KioError("unexpected end of file in " + name_);
 }
 
+size_t Input::ReadUpTo(void* dst, size_t n) {
+  if (mem_) {
+    const size_t got = std::min(n, mem_n_ - mem_pos_);
+    memcpy(dst, mem_ + mem_pos_, got);
+    mem_pos_ += got;
+    return got;
+  }
+  return f_ ? fread(dst, 1, n, f_) : 0;
+}
+
 // ------------------------------------------------------------------------------------- Output
 Output::~Output() {
   try {

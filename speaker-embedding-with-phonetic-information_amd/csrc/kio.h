@@ -43,6 +43,7 @@ class Input {
   int Peek();                       // next byte or EOF (-1), not consumed
   int Get();                        // next byte or EOF
   void Read(void* dst, size_t n);   // throws on short read
+  size_t ReadUpTo(void* dst, size_t n);   // up to n bytes, fewer only at the end of the input
   bool Eof() { return Peek() < 0; }
   // memory sources only: look-ahead and position (used by the model parser)
   int PeekAt(size_t k) const { return (mem_ && mem_pos_ + k < mem_n_) ? mem_[mem_pos_ + k] : -1; }

@@ -263,19 +263,14 @@ void RawNnet::ReadFrom(const std::string& rxfilename) {
   Input in;
   in.Open(rxfilename);
   std::string bytes;
-  char buf[1 << 16];
-  // slurp: the model is the only object behind this rxfilename in every call site of the reference
+  // slurp: the model is the only object behind this rxfilename in every call site of the reference.  (Block reads: byte by
+  // byte through fgetc the 28 MB of the x-vector model took 40 ms - 0.5 s on a slow host - of a job's start-up.)
   for (;;) {
-    int c = in.Peek();
-    if (c < 0) break;
-    size_t got = 0;
-    while (got < sizeof buf) {
-      int ch = in.Get();
-      if (ch < 0) break;
-      buf[got++] = (char)ch;
-    }
-    bytes.append(buf, got);
-    if (got < sizeof buf) break;
+    const size_t have = bytes.size(), want = std::max<size_t>(1 << 20, have);
+    bytes.resize(have + want);
+    const size_t got = in.ReadUpTo(&bytes[have], want);
+    bytes.resize(have + got);
+    if (got < want) break;
   }
   int status = in.Close();
   if (bytes.empty()) throw KioError("no model data read from '" + rxfilename + "'" +
