@@ -21,13 +21,19 @@ from oracle import kaldi_io as kio  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-    T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    targ = sys.argv[2] if len(sys.argv) > 2 else "400"   # frames per utterance: "400", or "200-600" = uniform over the range
+    if "-" in targ:
+        lo, hi = (int(v) for v in targ.split("-"))
+        lens = np.random.default_rng(5).integers(lo, hi + 1, 64)
+    else:
+        lens = np.full(64, int(targ))
+    T = float(lens.mean())
     extra = [a for a in sys.argv[3:] if a.startswith("--")]
     wspec = ([a for a in sys.argv[3:] if not a.startswith("--")] or [None])[0]
     d = tempfile.mkdtemp(prefix="xvcli", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     net, line = H.synth_model("v2_xvector")
     open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
-    pool = [H.features(1000 + i, T) for i in range(64)]
+    pool = [H.features(1000 + i, int(lens[i])) for i in range(64)]
     with open(os.path.join(d, "feats.ark"), "wb") as f:
         for i in range(n):
             f.write(("utt%07d " % i).encode() + b"\0B")
@@ -43,7 +49,7 @@ def main():
     loop = float(m.group(1)) if m else None
     print(json.dumps({"utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
                       "loop_s": loop, "loop_utt_per_s": n / loop if loop else None,
-                      "feature_GB": n * T * 23 * 4 / 1e9, "tail": [l for l in err.strip().splitlines() if "stages" in l or "Done" in l or "WaitHost" in l]}))
+                      "feature_GB": n * T * 23 * 4 / 1e9, "frames_per_s": n * T / loop if loop else None, "tail": [l for l in err.strip().splitlines() if "stages" in l or "Done" in l or "WaitHost" in l]}))
     for fn in os.listdir(d):
         os.remove(os.path.join(d, fn))
     os.rmdir(d)
