@@ -238,7 +238,7 @@ __device__ __forceinline__ void mfma16_f16_inplace(s16x8 a, s16x8 b, f32x4& c) {
 // As the vector load hipcc makes of a plain read (it cannot prove the table read-only), the value was waited for with
 // vmcnt(0) right where it was requested - and that counter also holds every LDS-DMA / prefetch load the kernel has issued
 // for its NEXT part or unit to hide behind this epilogue: the epilogue began with a full memory latency.
-__device__ __forceinline__ void load_out_range(const uint8_t* p, unsigned (&rng)[2]) {
+__device__ __forceinline__ void load_group_ranges(const uint8_t* p, unsigned (&rng)[2]) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   u32x2 v;
   asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
@@ -284,7 +284,7 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
       // rows of the four 16-row groups q that count for the group maxima: [grp][first, last) bytes, 8 contiguous ones
       // (mbase is a multiple of 64 rows, the table 8-byte aligned)
       e.rng[0] = e.rng[1] = 0x10001000u;
-      if (a.out_range) load_out_range((const uint8_t*)a.out_range + 2 * (mbase >> 4), e.rng);
+      if (a.out_range) load_group_ranges((const uint8_t*)a.out_range + 2 * (mbase >> 4), e.rng);
     }
   } else if constexpr (EPI == kEpiStats) {
 #pragma unroll
@@ -295,9 +295,9 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& a, const int m
       e.of[q] = a.bn ? a.offset[col] : 0.f;
     }
     // valid rows of the block's four 16-row groups: 8 contiguous bytes at a wave-uniform, 8-byte aligned address (mbase is
-    // a multiple of 64) -> one scalar load (see load_out_range: as byte loads they queued behind the next part's LDS-DMA)
+    // a multiple of 64) -> one scalar load (see load_group_ranges: as byte loads they queued behind the next part's LDS-DMA)
     unsigned gr[2];
-    load_out_range((const uint8_t*)a.grp_range + 2 * (mbase >> 4), gr);
+    load_group_ranges((const uint8_t*)a.grp_range + 2 * (mbase >> 4), gr);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       e.first[p] = (int)(int8_t)(gr[p >> 1] >> (16 * (p & 1)));
@@ -337,7 +337,7 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
       // rows of the four 16-row groups q that count for the group maxima: [grp][first, last) bytes, 8 contiguous ones
       // (mbase is a multiple of 64 rows, the table 8-byte aligned)
       e.rng[0] = e.rng[1] = 0x10001000u;
-      if (a.out_range) load_out_range((const uint8_t*)a.out_range + 2 * (mbase >> 4), e.rng);
+      if (a.out_range) load_group_ranges((const uint8_t*)a.out_range + 2 * (mbase >> 4), e.rng);
     }
   } else if constexpr (EPI == kEpiStats) {
 #pragma unroll
@@ -348,9 +348,9 @@ __device__ __forceinline__ void epilogue_prefetch_lds(const GemmArgs& a, const f
       e.of[q] = a.bn ? par[256 + c] : 0.f;
     }
     // valid rows of the block's four 16-row groups: 8 contiguous bytes at a wave-uniform, 8-byte aligned address (mbase is
-    // a multiple of 64) -> one scalar load (see load_out_range: as byte loads they queued behind the next part's LDS-DMA)
+    // a multiple of 64) -> one scalar load (see load_group_ranges: as byte loads they queued behind the next part's LDS-DMA)
     unsigned gr[2];
-    load_out_range((const uint8_t*)a.grp_range + 2 * (mbase >> 4), gr);
+    load_group_ranges((const uint8_t*)a.grp_range + 2 * (mbase >> 4), gr);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       e.first[p] = (int)(int8_t)(gr[p >> 1] >> (16 * (p & 1)));
