@@ -2219,8 +2219,19 @@ static bool sk_applicable(const GemmArgs& a) {
   if (rows % (64 * MF)) return false;
   const int grid = device_cu_count() / 8 * 8;
   if (grid < 8) return false;
-  // every workgroup gets at least one tile's worth of K steps (XCD blocks are whole row tiles)
-  return (long)(rows / (64 * MF) / 8) * a.n_tiles >= grid / 8;
+  // every workgroup gets at least one tile's worth of K steps (XCD blocks are whole row tiles) ...
+  if ((long)(rows / (64 * MF) / 8) * a.n_tiles >= grid / 8) return true;
+  // ... or, on fewer workgroups (sk_groups), launches between the two regimes: at least four row tiles per XCD block, and
+  // more 256-row tiles than the per-tile kernel finishes in one round (48 and 64 chunks of 400 frames: 300 / 400 tiles of
+  // tdnn2 on 256 CUs = two rounds, 82 us for both, where one round is 42)
+  return MF == 8 && rows / (64 * MF) / 8 >= 4 && (long)(a.m_tiles / 2) * a.n_tiles > device_cu_count();
+}
+
+// Workgroup groups per XCD block and column lane: as many as the CUs allow, but not more than the block has tiles per lane
+template <int MF>
+static int sk_groups(const GemmArgs& a, int grid, int lanes) {
+  const int tiles_min = std::max(1, (a.m_tiles * kBM / (64 * MF) / 8) * (a.n_tiles / lanes));
+  return std::min(grid / 8 / lanes, tiles_min);
 }
 
 template <int PREC, int EPI, int MF>
@@ -2237,7 +2248,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
       if (e != hipSuccess) return e;
       attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
     }
-    const int grid = device_cu_count() / 8 * 8;
+    int grid = device_cu_count() / 8 * 8;
     GemmArgs b = a;
     build_groups(&b);
     if constexpr (PrecMx2(PREC)) build_lo_groups(&b);
@@ -2253,6 +2264,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
       int l = max_lanes;
       while (l > 1 && (a.n_tiles % l || (grid / 8) % l)) l >>= 1;
       b.sk_lanes = l;
+      grid = 8 * l * sk_groups<MF>(a, grid, l);
     }
     SkWorkspace w;
     hipError_t e = sk_workspace(s, grid, (size_t)grid * 64 * MF * kBN * sizeof(float), &w, &b.sk_epoch, &b.sk_error);
