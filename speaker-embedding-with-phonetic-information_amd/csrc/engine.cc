@@ -732,7 +732,7 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
         continue;
       }
       if (frame_mode_ && (int)i == info_.output_layer) {
-        Ensure(&L.frame_f32, (size_t)rows * li.n_pad * 4, false);
+        Ensure(&L.frame_f32, (size_t)rows * li.n_pad * (logits16() ? 2 : 4), false);
         continue;
       }
       Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
@@ -1059,6 +1059,11 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         ga.partial = (float*)L.partial.p;
         ga.ldp = li.n_pad;
         ga.grp_range = plan.d_grp_range;
+      } else if (frame_mode_ && (int)i == info_.output_layer && logits16()) {
+        epi = kEpiAct;   // the head's logits as an fp16 plane (no halo rows: nothing splices them)
+        ga.out_hi = (uint16_t*)L.frame_f32.p;
+        ga.out_lo = nullptr;
+        ga.ldo = li.n_pad;
       } else if (frame_mode_ && (int)i == info_.output_layer) {
         epi = kEpiF32;
         ga.out_f32 = (float*)L.frame_f32.p;
@@ -1210,7 +1215,8 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
   const BlobLayerInfo& ol = info_.layers[info_.output_layer];
   if (frame_mode_) {
     FrameOutArgs fo;
-    fo.src = (const float*)L.frame_f32.p;
+    fo.src = logits16() ? nullptr : (const float*)L.frame_f32.p;
+    fo.src16 = logits16() ? (const uint16_t*)L.frame_f32.p : nullptr;
     fo.ld = ol.n_pad;
     fo.out_row = plan.d_out_row;
     fo.n_out = plan.n_out;
@@ -1225,6 +1231,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     // pooled output taken after a LogSoftmaxComponent (e.g. the speaker posteriors of the unedited x-vector net)
     FrameOutArgs fo;
     fo.src = (const float*)L.out_f32.p;
+    fo.src16 = nullptr;
     fo.ld = ol.n_pad;
     fo.out_row = nullptr;
     fo.n_out = plan.B;

@@ -233,6 +233,11 @@ class Engine {
   bool has_fast_ = false;
   bool fast_mx_ = false;
   bool fast_mx2_ = false;   // kPrecFp16Mx2: every frame-level layer of a fast chunk runs it (or kPrecFp16x3E on the input)
+  // Frame-level log-posteriors in the single-pass fp16 mode: the head's logits stay a 16-bit plane like every other layer's
+  // output of that mode (2 instead of 4 bytes per logit written by the head GEMM and read by the LogSoftmax pass: the two
+  // were store- and bandwidth-bound on 1.6 GB each way); the log-posteriors themselves are fp32.  Every other mode keeps
+  // fp32 logits.
+  bool logits16() const { return frame_mode_ && info_.precision == kPrecFp16 && info_.layers[info_.output_layer].log_softmax; }
   int fast_min_pooled_ = 0;
   int fast_mode_ = 0;       // see SetFastMode
   int mx2_min_pooled_ = 0, mx_min_pooled_ = 0;   // thresholds of the two fast modes (XVEC_FAST_MIN_POOLED overrides both)

@@ -342,6 +342,7 @@ hipError_t launch_pool_finalise(const PoolArgs& a, int precision, hipStream_t s)
 // kept in registers: one read, one write).
 struct FrameOutArgs {
   const float* src;         // [device rows][ld]
+  const uint16_t* src16;    // or the same as fp16 (log_softmax only; the single-pass fp16 mode keeps its logits in 16 bits)
   int ld;
   const int32_t* out_row;   // [n_out] device row of every output row
   int n_out;

@@ -2947,11 +2947,12 @@ hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s) {
 // first version (1.23 -> 0.6 ms), and no statistics work in the head GEMM's epilogue (tried: +0.15 ms there).  VEC: 16-byte
 // loads / stores (row length, row pitches and pointers multiples of four floats), else coalesced 4-byte accesses.
 // frame_output_kernel is the plain gather, and the three-pass fallback for rows that do not fit the registers.
-template <int N, bool VEC>
+template <int N, bool VEC, bool IN16 = false>
 __global__ __launch_bounds__(256) void frame_output_lsm_kernel(const FrameOutArgs a) {
   const int o = blockIdx.x;
   const long srow = a.out_row ? a.out_row[o] : o;
-  const float* src = a.src + srow * a.ld;
+  const float* src = IN16 ? nullptr : a.src + srow * a.ld;
+  const _Float16* src16 = IN16 ? (const _Float16*)a.src16 + srow * a.ld : nullptr;
   float* dst = a.out + (long)o * a.out_ld;
   const int tid = threadIdx.x;
   __shared__ float red[8];
@@ -2962,7 +2963,14 @@ __global__ __launch_bounds__(256) void frame_output_lsm_kernel(const FrameOutArg
     for (int i = 0; i < N / 4; ++i) {
       const int c = (tid + 256 * i) * 4;
       f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (c < a.dim) x = *(const f32x4*)(src + c);
+      if (c < a.dim) {
+        if constexpr (IN16) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          x = __builtin_convertvector(*(const f16x4*)(src16 + c), f32x4);
+        } else {
+          x = *(const f32x4*)(src + c);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[4 * i + k] = x[k];
@@ -2973,7 +2981,7 @@ __global__ __launch_bounds__(256) void frame_output_lsm_kernel(const FrameOutArg
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int c = tid + 256 * i;
-      v[i] = c < a.dim ? src[c] : -INFINITY;
+      v[i] = c < a.dim ? (IN16 ? (float)src16[c] : src[c]) : -INFINITY;
       m = fmaxf(m, v[i]);
     }
   }
@@ -3037,6 +3045,23 @@ __global__ __launch_bounds__(256) void frame_output_kernel(const FrameOutArgs a)
 hipError_t launch_frame_output(const FrameOutArgs& a, hipStream_t s) {
   if (a.n_out <= 0) return hipSuccess;
   const dim3 grid(a.n_out), block(256);
+  if (a.src16) {   // fp16 logits (engine: single-pass fp16 mode with a LogSoftmax behind the head)
+    if (!a.log_softmax || a.dim > 256 * 64) return hipErrorInvalidValue;
+    const bool vec = ((a.dim | a.out_ld | a.ld) & 3) == 0 && ((uintptr_t)a.out & 15) == 0 && ((uintptr_t)a.src16 & 7) == 0;
+    const int n = (a.dim + 255) / 256;
+    if (vec) {
+      if (n <= 8) XV_LAUNCH((frame_output_lsm_kernel<8, true, true>), grid, block, 0, s, a);
+      else if (n <= 16) XV_LAUNCH((frame_output_lsm_kernel<16, true, true>), grid, block, 0, s, a);
+      else if (n <= 32) XV_LAUNCH((frame_output_lsm_kernel<32, true, true>), grid, block, 0, s, a);
+      else XV_LAUNCH((frame_output_lsm_kernel<64, true, true>), grid, block, 0, s, a);
+    } else {
+      if (n <= 8) XV_LAUNCH((frame_output_lsm_kernel<8, false, true>), grid, block, 0, s, a);
+      else if (n <= 16) XV_LAUNCH((frame_output_lsm_kernel<16, false, true>), grid, block, 0, s, a);
+      else if (n <= 32) XV_LAUNCH((frame_output_lsm_kernel<32, false, true>), grid, block, 0, s, a);
+      else XV_LAUNCH((frame_output_lsm_kernel<64, false, true>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+  }
   if (a.log_softmax && a.dim <= 256 * 64) {
     const bool vec = ((a.dim | a.out_ld | a.ld) & 3) == 0 && (((uintptr_t)a.out | (uintptr_t)a.src) & 15) == 0;
     const int n = (a.dim + 255) / 256;   // floats per thread
