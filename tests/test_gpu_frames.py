@@ -60,6 +60,10 @@ def test_frame_level_fp16_mode_config5():
     # single-pass fp16: not the parity mode; bound loosely, the measured value is what bench reports
     assert H.rel_err(out, ref) < 5e-3
     assert (out.argmax(1) == ref.argmax(1)).mean() > 0.97
+    # in this mode the head's logits are a 16-bit plane (engine.h logits16); the normalisation itself is fp32: every row of
+    # log-posteriors sums to one as exactly as fp32 allows, whatever the rounding of the logits
+    lse = np.log(np.exp(out.astype(np.float64)).sum(1))
+    assert np.max(np.abs(lse)) < 2e-5, np.max(np.abs(lse))
 
 
 def test_pooled_log_softmax_output():
