@@ -34,10 +34,14 @@ typedef enum {
 
 typedef enum {
   XV_PREC_DEFAULT = -1, /* the policy of the command-line tools, and what every entry point of this library defaults to:
-                          XV_PREC_FP16MX2 for a pooled (x-vector) output whose layers can all run it, XV_PREC_FP16X3
-                          otherwise (a layer the 4-bit walk cannot cover, frame-level outputs).  Never an opt-in mode:
-                          the arithmetic it picks meets the parity bar on every model tried, heavy-tailed ones included
-                          (DESIGN.md section 3.0).  xv_ctx_info reports the mode that was chosen */
+                          the context is PACKED as XV_PREC_FP16MX2 for a pooled (x-vector) output whose layers can all
+                          run it, XV_PREC_FP16X3 otherwise (a layer the 4-bit walk cannot cover, frame-level outputs);
+                          xv_ctx_info reports that mode.  On its own this meets the parity bar on every model tried,
+                          heavy-tailed ones included.  A context packed this way can be
+                          CALIBRATED (xv_ctx_calibrate / xv_calibrate_table; the command-line tools and dist_extract.py
+                          do it by default, xv_forward_batch users only when they call it): it then runs the lighter,
+                          model-dependent XV_PREC_FP16MX where - and only where - that was measured within the
+                          tolerance on a sample of the job's own data; xv_ctx_fast_mode reports what it runs */
   XV_PREC_BF16X3 = 0,  /* split-bf16 MFMA (3 products, fp32 accumulate): fp32-grade, the first version's parity mode */
   XV_PREC_BF16 = 1,    /* single-pass bf16 MFMA */
   XV_PREC_FP16 = 2,    /* single-pass fp16 MFMA */
@@ -135,24 +139,28 @@ xv_status xv_ctx_synchronize(xv_ctx* c);
  * XV_PREC_FP16MX arithmetic (1.25 instead of 1.5 MFMA passes, +30 % throughput) and the three-pass XV_PREC_FP16X3 on the
  * same packed weights.  XV_PREC_FP16MX meets the parity bar on some models only, so it is never
  * assumed: xv_ctx_calibrate runs the caller's own chunks in all three, compares the embeddings of the two fast modes with
- * the three-pass ones (worst max|d| / max|ref| over the chunks that pool >= 300 frames) and switches the context to
- * XV_PREC_FP16MX only when its error stays within tol (the tools use 7.5e-5 on the worst chunk: three quarters of the 1e-4 bar; over 64 chunks the worst one lies ~20 % above the mean, so the bar is more than six standard deviations away), else leaves XV_PREC_FP16MX2
+ * the three-pass ones (worst max|d| / max|ref|; XV_PREC_FP16MX over the chunks that pool >= 300 frames - the others run
+ * three-pass in that mode -, XV_PREC_FP16MX2 over every chunk it runs fast, from 160 pooled frames) and switches the context to
+ * XV_PREC_FP16MX only when at least 16 such chunks were compared and its error stays within tol (the tools use 7.5e-5 on the worst chunk: three quarters of the 1e-4 bar; over 64 chunks the worst one lies ~20 % above the mean, so the bar is more than six standard deviations away), else leaves XV_PREC_FP16MX2
  * (or drops to XV_PREC_FP16X3 should even that exceed 1e-4).  Contexts that cannot switch report their precision with
- * checked = 0.  This is what `nnet3-xvector-compute --precision=default` does on the first 64 utterances of its job
+ * checked = 0.  This is what `nnet3-xvector-compute --precision=default` does on 64 utterances of its job
  * (no reference counterpart: Kaldi computes in fp32 throughout).  xv_ctx_set_fast_mode applies a choice made elsewhere
- * (the other ranks of a multi-GPU job); xv_calibrate_table calibrates on the first max_utts utterances of a table. */
+ * (the other ranks of a multi-GPU job); xv_calibrate_table calibrates on max_utts utterances of a table: spread evenly
+ * over the whole list where its objects can be addressed (archive file, script file - the reference's lists are sorted
+ * by speaker, utils/data/split_data.sh:18-21, so the head of a list is one or two speakers), the head of a stream. */
 typedef struct {
   int32_t chosen;   /* xv_precision the context now runs its fast chunks in */
   int32_t checked;  /* chunks compared */
   float err_mx;     /* XV_PREC_FP16MX against XV_PREC_FP16X3 */
   float err_mx2;    /* XV_PREC_FP16MX2 against XV_PREC_FP16X3 */
+  int32_t checked_mx;  /* of them, chunks XV_PREC_FP16MX would run fast (what err_mx was measured on; fewer than 16: not chosen) */
 } xv_calibration;
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out);
 xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision);
 xv_status xv_ctx_fast_mode(const xv_ctx* c, int32_t* precision);
 xv_status xv_calibrate_table(xv_ctx* c, const char* feature_rspecifier, int32_t chunk_size, int32_t min_chunk_size,
                              int32_t pad_input, int32_t max_utts, float tol, xv_calibration* out);
-/* xv_extract_table calibrates on the head of its own table first when this is enabled (default: off) */
+/* xv_extract_table calibrates on a sample of its own table first (as xv_calibrate_table) when this is enabled (default: off) */
 xv_status xv_ctx_set_calibration(xv_ctx* c, int32_t enable, float tol);
 
 xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable);

@@ -64,7 +64,8 @@ class GemmDesc(ctypes.Structure):
 
 class Calibration(ctypes.Structure):
     """xv_calibration: what xv_ctx_calibrate measured and chose."""
-    _fields_ = [("chosen", ctypes.c_int32), ("checked", ctypes.c_int32), ("err_mx", ctypes.c_float), ("err_mx2", ctypes.c_float)]
+    _fields_ = [("chosen", ctypes.c_int32), ("checked", ctypes.c_int32), ("err_mx", ctypes.c_float), ("err_mx2", ctypes.c_float),
+                ("checked_mx", ctypes.c_int32)]
 
 
 # every symbol include/xvec_hip.h declares (tests check the library exports exactly these)
@@ -310,14 +311,14 @@ class Context:
         offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
         c = Calibration()
         _check(lib().xv_ctx_calibrate(self._h, feats.ctypes.data, offs.ctypes.data, len(offs) - 1, tol, ctypes.byref(c)))
-        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
+        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "checked_mx": c.checked_mx, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
 
     def calibrate_table(self, feature_rspecifier, chunk_size=-1, min_chunk_size=100, pad_input=True, max_utts=64, tol=7.5e-5):
         """The same on the first chunk of the first max_utts utterances of a feature table."""
         c = Calibration()
         _check(lib().xv_calibrate_table(self._h, feature_rspecifier.encode(), chunk_size, min_chunk_size, 1 if pad_input else 0,
                                         max_utts, tol, ctypes.byref(c)))
-        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
+        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "checked_mx": c.checked_mx, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
 
     @property
     def fast_mode(self):

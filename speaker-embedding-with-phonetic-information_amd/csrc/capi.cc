@@ -228,6 +228,7 @@ static void FillCalibration(const xv::Engine::Calibration& c, xv_calibration* ou
   out->checked = c.checked;
   out->err_mx = c.err_mx;
   out->err_mx2 = c.err_mx2;
+  out->checked_mx = c.checked_mx;
 }
 
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out) {

@@ -1120,6 +1120,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
       memset(&fa, 0, sizeof fa);
       fa.g = ga;
       fa.feats = feats_dev;
+      fa.feats_valid_idx = (long)plan.src_off[0] * info_.input_dim;
       fa.grp_src = (const int4*)plan.d_grp_src;
       fa.rows = plan.rows;
       fa.dim = info_.input_dim;
@@ -1272,15 +1273,20 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   Calibration c;
   c.chosen = fast_mode();
   if (!can_switch_fast_mode() || B <= 0) return c;
-  // chunks the lighter mode would run fast: pooled frames as FillPlan counts them
+  // Chunks each fast mode would run fast - pooled frames as FillPlan counts them.  fp16mx2 is validated on every chunk IT
+  // runs (from mx2_min_pooled_ frames, where its error is largest), fp16mx on those it runs (from mx_min_pooled_).
   const BlobLayerInfo& pl = info_.layers[info_.pooled_layer];
   const int pool_first = std::max(pl.left, -info_.pool_left);
   std::vector<int32_t> offs(1, row_offsets[0]);
   std::vector<int> pick;
+  std::vector<char> runs_mx;
   for (int b = 0; b < B; ++b) {
     const int T = row_offsets[b + 1] - row_offsets[b];
     const int cnt = std::min(T - 1 - pl.right, info_.pool_right) - pool_first + 1;
-    if (T >= info_.min_frames && cnt >= mx_min_pooled_) pick.push_back(b);
+    if (T >= info_.min_frames && cnt >= std::min(mx_min_pooled_, mx2_min_pooled_)) {
+      pick.push_back(b);
+      runs_mx.push_back(cnt >= mx_min_pooled_);
+    }
   }
   if (pick.empty()) return c;
   // packed copy of the picked chunks
@@ -1305,9 +1311,10 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     SetFastMode(before);
     throw;
   }
-  auto worst = [&](const std::vector<float>& got) {
+  auto worst = [&](const std::vector<float>& got, bool only_mx) {
     float w = 0.f;
     for (int i = 0; i < n; ++i) {
+      if (only_mx && !runs_mx[i]) continue;
       float d = 0.f, m = 0.f;
       for (int k = 0; k < E; ++k) {
         d = std::max(d, std::fabs(got[(size_t)i * E + k] - ref[(size_t)i * E + k]));
@@ -1318,10 +1325,17 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     }
     return w;
   };
+  int n_mx = 0;
+  for (int i = 0; i < n; ++i) n_mx += runs_mx[i] ? 1 : 0;
   c.checked = n;
-  c.err_mx = worst(mx);
-  c.err_mx2 = worst(mx2);
-  c.chosen = c.err_mx <= tol ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
+  c.checked_mx = n_mx;
+  c.err_mx = worst(mx, true);
+  c.err_mx2 = worst(mx2, false);
+  // The lighter mode governs a whole job: it is taken only on the evidence of at least kCalibMinChunks chunks it would run
+  // (the margin between the tolerance and the bar is argued for a sample of that order; one or two
+  // qualifying chunks are not a measurement).  Fewer: the packed mode stays.
+  const bool mx_ok = n_mx >= kCalibMinChunks && c.err_mx <= tol;
+  c.chosen = mx_ok ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
   SetFastMode(c.chosen);
   return c;
 }

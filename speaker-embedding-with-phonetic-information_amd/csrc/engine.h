@@ -127,14 +127,17 @@ class Engine {
   //   kPrecFp16x3   every chunk in the three-pass arithmetic
   // Calibrate() measures, on the caller's own chunks, the embeddings of the two fast modes against the three-pass ones and
   // switches the context to kPrecFp16Mx when its worst relative error stays within `tol`, else keeps kPrecFp16Mx2 (or drops
-  // to kPrecFp16x3 when even that exceeds 1e-4).  Only chunks that pool >= 300 frames count (the others run three-pass in
-  // kPrecFp16Mx anyway).  Synchronous; results of later calls are bit-reproducible for a given choice.
+  // to kPrecFp16x3 when even that exceeds 1e-4).  Each mode is measured on the chunks it runs fast (kPrecFp16Mx: >= 300 pooled
+  // frames, kPrecFp16Mx2: >= 160); kPrecFp16Mx needs at least kCalibMinChunks such chunks to be chosen.  Synchronous; results of later calls are bit-reproducible for a given choice.
   struct Calibration {
     int chosen = 0;           // kPrecFp16Mx / kPrecFp16Mx2 / kPrecFp16x3 (or the context's precision when it cannot switch)
     int checked = 0;          // chunks that entered the comparison
     float err_mx = 0.f;       // worst max|d| / max|ref| of kPrecFp16Mx over them
     float err_mx2 = 0.f;      // the same for kPrecFp16Mx2
+    int checked_mx = 0;       // chunks among `checked` that kPrecFp16Mx runs fast: err_mx is over these, and fewer than
+                              // kCalibMinChunks of them never select kPrecFp16Mx
   };
+  static constexpr int kCalibMinChunks = 16;
   bool can_switch_fast_mode() const { return info_.precision == kPrecFp16Mx2 && !frame_mode_; }
   int fast_mode() const { return can_switch_fast_mode() ? fast_mode_ : info_.precision; }
   void SetFastMode(int mode);   // throws unless can_switch_fast_mode() and mode is one of the three

@@ -276,12 +276,16 @@ inline bool FirstLayerApplicable(int dim, int noff, const int* off) {
     lo = off[j] < lo ? off[j] : lo;
     hi = off[j] > hi ? off[j] : hi;
   }
-  return dp <= 32 && noff * dp <= kFirstK && hi - lo <= 30 && (kFirstRows + hi - lo) * dp <= 512 * kFirstMaxSlots;   // dp: LDS
+  // dp <= 24: the kernel's LDS (tables + the 128 KiB weight plane + four feature buffers of 96 rows x dp halves) must fit 160 KiB
+  return dp <= 24 && noff * dp <= kFirstK && hi - lo <= 30 && (kFirstRows + hi - lo) * dp <= 512 * kFirstMaxSlots;
 }
 struct FirstArgs {
   GemmArgs g;               // the epilogue's side: n_tiles, relu, bn, bias / scale / offset, out_hi / out_lo / out_lo4 / out_lo4s,
                             // ldo, gmax_out, out_range - all indexed by ABSOLUTE device row (no region shift)
   const float* feats;       // as PrepArgs
+  long feats_valid_idx;     // element index of a float that exists (first row of the batch: row_offsets[0] * dim): what the
+                            // unconditional loads of slots without a source frame read.  (feats itself is the caller's base
+                            // shifted DOWN by row_offsets[0] rows, so element 0 may lie outside the allocation.)
   // where the frames of every 16-row group come from (built with the plan): {source row of the group's frame 0 before
   // the edge clamp, frames the chunk holds from there on (replicated edge frames included; 0: the group lies outside every
   // chunk), source row of the chunk's first frame, of its last frame}

@@ -2553,7 +2553,7 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
     const int fr = slot / dp;
     slot_fd[i] = slot < n_slots ? (fr << 8) | (slot - fr * dp) : -1;
   }
-  // the loads are unconditional (a slot without a source frame reads element 0 and is zeroed at commit): a conditional load
+  // the loads are unconditional (a slot without a source frame reads the batch's first element and is zeroed at commit): a conditional load
   // is merged with its default right where it is issued, i.e. waited for in front of the MFMAs instead of after them
   float pv[kFirstMaxSlots] = {0.f, 0.f, 0.f, 0.f};
   unsigned pv_ok = 0u;
@@ -2562,7 +2562,7 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
     pv_ok = 0u;
 #pragma unroll
     for (int i = 0; i < kFirstMaxSlots; ++i) {
-      long idx = 0;
+      long idx = fa.feats_valid_idx;
       if (slot_fd[i] >= 0) {
         const int d = slot_fd[i] & 255;
         const int r = r_first + (slot_fd[i] >> 8);

@@ -71,8 +71,8 @@ const char* kUsage =
     "  --precision=default|fp16mx2|fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
     "                                   arithmetic of the MFMA GEMMs.  default: fp16mx2 where every layer can run it, else\n"
     "                                   fp16x3 (nnet3-compute: always fp16x3) - and, unless --calibrate=false, the lighter\n"
-    "                                   fp16mx where the job's own first utterances show it within --calibrate-tol of the\n"
-    "                                   three-pass arithmetic (one log line says what was measured and chosen).\n"
+    "                                   fp16mx where a sample of the job's own utterances shows it within --calibrate-tol of\n"
+    "                                   the three-pass arithmetic (log lines say what was sampled, measured and chosen).\n"
     "                                   fp16x3: split fp16, three MFMAs per\n"
     "                                   product, fp32-grade (3e-7..4e-6 from the fp32 oracle).  fp16mx2: fp16 product +\n"
     "                                   two block-scaled 4-bit products that correct the fp16 rounding of the weights\n"
@@ -82,10 +82,12 @@ const char* kUsage =
     "                                   fp16x3), the others fp16x3; its error is the activation rounding averaged by the\n"
     "                                   pooling - 5-8e-5 on models with Kaldi-initialisation-like weights, 1-2e-4 on\n"
     "                                   heavy-tailed ones (DESIGN.md section 3.0): check it on your model first.\n"
-    "  --calibrate=true|false --calibrate-tol=<float>\n"
-    "                                   with --precision=default (default true, 7.5e-5): before the first batch, the first chunk of\n"
-    "                                   the first 64 utterances is computed in fp16x3, fp16mx and fp16mx2; fp16mx is used\n"
-    "                                   for the job when its worst embedding error against fp16x3 is within the tolerance\n"
+    "  --calibrate=true|false --calibrate-tol=<float> --calibrate-utts=<int>\n"
+    "                                   with --precision=default (default true, 7.5e-5, 64): before the first batch, the first\n"
+    "                                   chunk of 64 utterances - spread evenly over the whole list for a table that can be\n"
+    "                                   addressed (archive file, scp), the first 64 of a stream - is computed in fp16x3,\n"
+    "                                   fp16mx and fp16mx2; fp16mx is used for the job when at least 16 chunks long enough for\n"
+    "                                   it were compared and its worst embedding error against fp16x3 is within the tolerance\n"
     "  --fast-min-pooled=<int>          auto / fp16mx2: chunks that pool at least this many frames take the fast\n"
     "                                   kernels (default 300 / 160, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
@@ -111,6 +113,7 @@ struct Options {
   int fast_min_pooled = -1;
   bool calibrate = true;
   float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
+  int calibrate_utts = 64;         // utterances sampled (spread over the list of an addressable table, the head of a stream)
   int device = -1;
   bool print_args = true;
   int cmn_window = 0;
@@ -194,6 +197,7 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
       return false;
     }
   }
+  else if (name == "calibrate-utts") return need_int(&o->calibrate_utts);
   else if (name == "device") return need_int(&o->device);
   else if (name == "cmn-window") return need_int(&o->cmn_window);
   else if (name == "vad-rspecifier") o->vad_rspecifier = value;
@@ -427,6 +431,7 @@ int main(int argc, char** argv) {
     eo.vad_rspecifier = opt.vad_rspecifier;
     eo.calibrate = policy_default && opt.calibrate && !g_frame_job;   // no-op unless the context can switch (fp16mx2)
     eo.calibrate_tol = opt.calibrate_tol;
+    if (opt.calibrate_utts > 0) eo.calibrate_utts = opt.calibrate_utts;
     if (!opt.backend_mean.empty()) xv::ReadVectorObject(opt.backend_mean, &eo.backend_mean);
     if (!opt.backend_transform.empty()) {
       xv::Matrix t;

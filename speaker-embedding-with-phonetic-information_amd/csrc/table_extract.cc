@@ -77,30 +77,78 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
   std::ostringstream m;
   m.precision(3);
   if (c.checked == 0) {
-    m << "calibration: none of the first " << utts.size() << " utterances has a chunk long enough for the fp16mx arithmetic; keeping "
+    m << "calibration: none of the " << utts.size() << " sampled utterances has a chunk long enough for the fast arithmetic; keeping "
       << PrecisionName(c.chosen);
   } else {
-    m << "calibration on " << c.checked << " chunks against the three-pass arithmetic: fp16mx " << c.err_mx << ", fp16mx2 " << c.err_mx2
-      << " (tolerance " << opt.calibrate_tol << ") -> " << PrecisionName(c.chosen);
+    m << "calibration on " << c.checked << " chunks against the three-pass arithmetic: fp16mx " << c.err_mx << " (on the " << c.checked_mx
+      << " chunks it runs fast; it takes " << Engine::kCalibMinChunks << " to choose it), fp16mx2 " << c.err_mx2 << " (tolerance "
+      << opt.calibrate_tol << ") -> " << PrecisionName(c.chosen);
   }
   log("LOG", m.str());
   return c;
 }
 
+// Calibration sample of a table.  Tables whose objects can be addressed (an archive in a regular file, a script file) are
+// indexed once - headers only - and calibrate_utts utterances are drawn EVENLY over the whole list: the reference's lists are
+// sorted by speaker (utils/data/split_data.sh:18-21 splits them per speaker), so the head of a list is one or two speakers,
+// and the choice governs every utterance of the job.  Streams (the feature pipe of extract_xvectors_new.sh:79) can only be
+// read front to back: their sample is the head, and the log says so.  *strided tells which one it was.
+static void SampleTable(const ExtractOptions& opt, const std::string& feat_rspec, std::vector<std::string>* keys,
+                        std::vector<Matrix>* mats, bool* strided, long* n_list) {
+  *strided = false;
+  *n_list = -1;
+  const int want = std::max(1, opt.calibrate_utts);
+  {
+    MatrixTableIndexer ix(feat_rspec);
+    if (ix.usable()) {
+      std::vector<MatrixTableIndexer::Entry> all;
+      MatrixTableIndexer::Entry e;
+      while (ix.Next(&e))
+        if (e.error.empty()) all.push_back(std::move(e));
+      *strided = true;
+      *n_list = (long)all.size();
+      const long n = (long)all.size();
+      Input in;
+      std::string in_path;
+      long prev = -1;
+      for (int i = 0; i < want && n > 0; ++i) {
+        // centres of `want` equal slices of the list (all of it when it is shorter)
+        const long k = n <= want ? i : (long)(((2 * (long long)i + 1) * n) / (2LL * want));
+        if (k >= n || k == prev) continue;
+        prev = k;
+        Matrix m;
+        try {
+          ReadIndexedMatrix(all[k], &in, &in_path, &m);
+        } catch (const std::exception&) {
+          continue;   // the extraction itself will report it
+        }
+        keys->push_back(all[k].key);
+        mats->push_back(std::move(m));
+      }
+      return;
+    }
+  }
+  SequentialMatrixReader rd(feat_rspec);
+  std::string key, e;
+  Matrix m;
+  while ((int)keys->size() < want && rd.Next(&key, &m, &e)) {
+    if (!e.empty()) continue;
+    keys->push_back(key);
+    mats->push_back(std::move(m));
+  }
+  // (the reader is closed here; for a pipe that ends the producer early, which is what a "head" of the list wants)
+}
+
 Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec, const LogFn& log) {
   std::vector<std::string> keys;
   std::vector<Matrix> mats;
-  {
-    SequentialMatrixReader rd(feat_rspec);
-    std::string key, e;
-    Matrix m;
-    while ((int)keys.size() < opt.calibrate_utts && rd.Next(&key, &m, &e)) {
-      if (!e.empty()) continue;
-      keys.push_back(key);
-      mats.push_back(std::move(m));
-    }
-    // (the reader is closed here; for a pipe that ends the producer early, which is what a "head" of the list wants)
-  }
+  bool strided = false;
+  long n_list = -1;
+  SampleTable(opt, feat_rspec, &keys, &mats, &strided, &n_list);
+  std::ostringstream m;
+  if (strided) m << "calibration sample: " << keys.size() << " utterances spread evenly over the " << n_list << " of the table";
+  else m << "calibration sample: the first " << keys.size() << " utterances of the stream (a stream cannot be sampled any other way)";
+  log("LOG", m.str());
   std::vector<CalibUtt> utts;
   for (size_t i = 0; i < keys.size(); ++i) utts.push_back(CalibUtt{&keys[i], mats[i].data.data(), mats[i].rows, mats[i].cols});
   return CalibrateOnUtterances(engine, opt, utts, log);
@@ -299,6 +347,12 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       }
     }
   };
+  bool calibrated = !(opt.calibrate && engine->can_switch_fast_mode());   // nothing to choose: no batch is held back
+  if (!calibrated && indexer) {
+    // addressable table: the sample is spread over the whole list (SampleTable), drawn before the readers start
+    CalibrateOnTable(engine, opt, feat_rspec, log);
+    calibrated = true;
+  }
   if (indexer) {
     threads.emplace_back(index_pass);
     for (int i = 0; i < n_readers; ++i) threads.emplace_back(parallel_reader);
@@ -345,7 +399,6 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   Work work[Engine::kNumHostSlots];
   int cur = 0;
   long seq = 0;
-  bool calibrated = !(opt.calibrate && engine->can_switch_fast_mode());   // nothing to choose: no batch is held back
   constexpr int NS = Engine::kNumHostSlots;
   // stage timing of the consumer thread (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
   const bool timing = getenv("XVEC_TIMING") != nullptr;
@@ -512,9 +565,10 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
       }
     }
   };
-  // With calibration the arithmetic of the whole job is chosen on the first calibrate_utts utterances of the TABLE, before
-  // anything is submitted: batches are held back until that many utterances have arrived (whatever the batch size, so
-  // that the choice - and with it every embedding - does not depend on --batch-frames).
+  // With calibration the arithmetic of the whole job is chosen before anything is submitted.  Addressable tables were sampled
+  // over their whole list above; a stream is calibrated on its first calibrate_utts utterances: batches are held back until
+  // that many have arrived (whatever the batch size, so that the choice - and with it every embedding - does not depend on
+  // --batch-frames), and the log line says that the sample is the head of the stream.
   std::deque<Batch> held;
   size_t held_utts = 0;
   for (;;) {
@@ -540,7 +594,11 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
             std::vector<CalibUtt> cu;
             for (const Batch& hb : held)
               for (const Utt& u : hb.utts) cu.push_back(CalibUtt{&u.key, u.feats.data.data(), u.feats.rows, u.feats.cols});
-            if (!cu.empty()) CalibrateOnUtterances(engine, opt, cu, log);
+            if (!cu.empty()) {
+              log("LOG", "calibration sample: the first " + std::to_string(std::min(cu.size(), (size_t)opt.calibrate_utts)) +
+                             " utterances of the stream (a stream cannot be sampled any other way)");
+              CalibrateOnUtterances(engine, opt, cu, log);
+            }
           } catch (const std::exception& ex) {
             fatal = ex.what();
           }

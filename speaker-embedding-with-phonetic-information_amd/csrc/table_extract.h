@@ -35,8 +35,10 @@ struct CalibUtt {
 };
 Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& opt, const std::vector<CalibUtt>& utts,
                                           const LogFn& log);
-// The same on the first opt.calibrate_utts utterances of a feature table (multi-GPU jobs: one rank calibrates on the head of
-// the WHOLE list and the choice is applied on every rank, so that an N-way sharded job computes what the 1-way job does).
+// The same on opt.calibrate_utts utterances of a feature table: spread evenly over the WHOLE list where the table's objects
+// can be addressed (archive file, script file: the reference's lists are speaker-sorted, utils/data/split_data.sh:18-21, so a
+// head of the list is one or two speakers), the head of the stream otherwise.  Multi-GPU jobs: one rank calibrates on the
+// whole list and the choice is applied on every rank, so that an N-way sharded job computes what the 1-way job does.
 Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
                                      const LogFn& log);
 

@@ -149,9 +149,14 @@ def main(argv=None):
             else:
                 ctx = P.Context(blob=wt.numpy().tobytes(), device=local_rank)
             if rank == 0 and args.precision == "default" and args.calibrate.lower() in ("true", "t", "1") and lines:
-                head = os.path.join(args.out_dir, "feats_%s.head.scp" % args.name)
+                # the calibration sample: 64 utterances spread evenly over the WHOLE list, i.e. over every rank's slice (the
+                # lists of the reference are sorted by speaker, utils/data/split_data.sh:18-21: the head of the list is one or
+                # two speakers and lies in rank 0's slice only) - the rule of xv_calibrate_table (table_extract.cc SampleTable)
+                head = os.path.join(args.out_dir, "feats_%s.calib.scp" % args.name)
+                n_all, want = len(lines), 64
+                picks = range(n_all) if n_all <= want else sorted({((2 * i + 1) * n_all) // (2 * want) for i in range(want)})
                 with open(head, "w") as f:
-                    f.writelines(lines[:64])
+                    f.writelines(lines[k] for k in picks)
                 hspec = ("ark:" + args.feat_pipe.replace("SCP", head)) if args.feat_pipe else ("scp:" + head)
                 cal = ctx.calibrate_table(hspec, args.chunk_size, args.min_chunk_size, args.pad_input.lower() in ("true", "t", "1"),
                                           64, args.calibrate_tol)
