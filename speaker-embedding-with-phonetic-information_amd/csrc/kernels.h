@@ -153,6 +153,24 @@ inline int PlanWalkSteps(int ng, const WalkGroup* g, int* step_wcol, int cap, bo
   return n;
 }
 
+// The same for tdnn_gemm_kernel_p8, which walks K in tiles of 64 columns: group -> 64-column chunk -> offset -> the chunk's two
+// 32-column halves.  A block of the 4-bit residual plane (four consecutive steps) is then a pair of consecutive K tiles.
+inline int PlanWalkSteps64(int ng, const WalkGroup* g, int* step_wcol, int cap, bool* ok64) {
+  int n = 0;
+  bool ok = true;
+  for (int i = 0; i < ng; ++i) {
+    if (g[i].ksteps % 4) ok = false;
+    for (int c = 0; c < g[i].ksteps / 2; ++c)
+      for (int ij = 0; ij < g[i].nshift; ++ij)
+        for (int k = 0; k < 2; ++k) {
+          if (n < cap) step_wcol[n] = g[i].wcol0 + ij * g[i].wstride + (2 * c + k) * kBK;
+          ++n;
+        }
+  }
+  if (ok64) *ok64 = ok;
+  return n;
+}
+
 // kPrecFp16Mx2: first weight column of every 128-column step of the second walk (same groups and order: chunk -> offset);
 // returns the number of steps.  Needs every group to have a multiple of four 32-column steps.
 inline int PlanWalkLoSteps(int ng, const WalkGroup* g, int* lo_wcol, int cap) {
@@ -235,6 +253,11 @@ struct GemmArgs {
   unsigned* sk_flags;
   unsigned sk_epoch;
   unsigned* sk_error;    // host-mapped word: of the launch stream: receives sk_epoch when a flag wait timed out (see sk_take_error)
+  // tdnn_gemm_kernel_p8 (256 x 256 tiles, K tiles of 64 columns, walk order group -> 64-column chunk -> offset: PlanWalkSteps64).
+  // p8 != 0: launch that kernel - the caller's statement that this layer runs it for every launch of the mode (its sums are
+  // formed in another order than the 32-column kernels') and, for kPrecFp16Mx, that w4 / w4_scale are packed in its walk order.
+  int p8;
+  int p8_ktiles;         // K tiles of an output tile (set by the launcher)
 };
 
 // Arms a (start, stop) event pair for the kernels of the NEXT launch_* call of this thread (profiling; see kernels.hip).
@@ -250,6 +273,8 @@ const char* last_gemm_kernel();
 // with a group-max table, even tile count); otherwise the caller launches kPrecFp16x2 on the same operands.
 bool gemm_mx_applicable(const GemmArgs& a);
 bool gemm_mx2_applicable(const GemmArgs& a);   // kPrecFp16Mx2: also the 4-bit planes, sources of whole 128-column steps
+// tdnn_gemm_kernel_p8 can run this launch in kPrecFp16 / kPrecFp16Mx (see GemmArgs::p8)
+bool gemm_p8_applicable(const GemmArgs& a, int precision);
 // Stream-K workspace (partial-tile exchange) of a stream: allocated on first use, released by the owner of the
 // stream before it destroys it (Engine::~Engine).  sk_take_error: non-zero when a stream-K launch on stream s (of the
 // current device) timed out waiting for another workgroup's partial tile since the last call; the word is per stream and

@@ -2131,6 +2131,487 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v5 ("p8"): 256 x 256 output tiles, K tiles of 64 columns, phase-interleaved (shapes of
+// egs/sre/v2/local/nnet3/xvector/run_xvector_new.sh:96-99).  Standalone study of the schedule: tools/probe_p8.hip.
+//
+//  * 8 waves as 4 (frames) x 2 (columns): a wave owns 64 frames x 128 columns = two 64 x 64 blocks side by side, the
+//    accumulator layout of the wide stream-K kernel, so the epilogues are shared.  Wave group = column half (waves 0-3 / 4-7,
+//    one of each per SIMD).
+//  * LDS: two K-tile buffers of 64 KiB, each an activation tile (256 frames x 128 B) and a weight tile (256 rows x 128 B,
+//    rows ordered [64-column block h][column half][64 rows]): rows of 128 bytes = whole cache lines per row piece for the
+//    LDS-DMA (the 64-byte row pieces of the 32-column K steps are half lines: twice the requests per byte).  16-byte chunks
+//    XOR-swizzled with three row bits (chunk ^ ((row >> 1) & 7)): every ds_read_b128 lane group touches 16 distinct slots
+//    (SQ_LDS_BANK_CONFLICT = 0, profiles/r04_probe_p8_pmc.txt); applied to the per-lane SOURCE address of the DMA.
+//  * A K tile is four phases of 16 MFMAs; a phase = LOAD part (the phase's fragment reads, ONE staging unit of 16 KiB = two
+//    LDS-DMA instructions per wave, a counted wait where data is about to be needed), barrier, MFMA part, barrier; wave
+//    group 1 runs one barrier interval behind group 0, so that on every SIMD one wave multiplies while the other loads.
+//      phase 0: reads weight fragments h = 0 (8) + frame fragments 0, 1 (4)   MFMAs h = 0 x frames 0, 1
+//      phase 1: reads frame fragments 2, 3 (4)                               MFMAs h = 0 x frames 2, 3
+//      phase 2: reads weight fragments h = 1 (8)                             MFMAs h = 1 x frames 2, 3
+//      phase 3: -                                                            MFMAs h = 1 x frames 0, 1
+//    Staging units and their issue (tile t, phase p): (t,0) frames 128..255 of tile t+1; (t,1) weights h = 1 of t+1;
+//    (t,2) weights h = 0 of t+2; (t,3) frames 0..127 of t+2 - each at least two phases after the last read of the bytes it
+//    overwrites and four to six phases before its first read.  Waits: end of LOAD(t,1) for the weights h = 1 of tile t (four
+//    units stay in flight), end of LOAD(t,3) for tile t+1's phase-0 data (three units in flight): never vmcnt(0) inside a part.
+//  * The time offsets of a spliced layer are part of the K-tile ADDRESS (rows m0 + offset): the fragment reads never move.
+//    K walk: group -> 64-column chunk -> offset (PlanWalkSteps64); accumulation order therefore differs from the 32-column
+//    kernels: a layer runs either family for ALL its launches of a mode (GemmArgs::p8), never by launch size.
+//  * kPrecFp16Mx: a block = two K tiles.  The conversions of the frame fragments to e2m1 ride the MFMA parts of phases 0 / 1;
+//    the block's 4-bit weight tile (16 KiB, rows of 64 B, swizzled like the 32-column tiles) and its scales (1 KiB) are
+//    DMA'd in phase 1 of the block's first tile into a buffer of their own, read at the end of the block's last MFMA part into
+//    the registers of the fp16 weight fragments, and followed by the 32 block-scaled MFMAs.
+//  * Persistent grid, K tiles dealt out evenly in pairs, partial tiles exchanged through the stream-K workspace: the
+//    partition, the exchange and its ordering guarantees are those of tdnn_gemm_kernel_sk (bit-identical whatever the cut).
+constexpr int kP8Buf = 65536, kP8XW = 32768, kP8Unit = 16384;
+constexpr int kP8W4 = 2 * kP8Buf;       // 4-bit residual tile of the current block: 256 rows x 64 B
+constexpr int kP8SC = kP8W4 + 16384;    // its scales: two 128-column tiles x 512 B
+constexpr int kP8PB = kP8SC + 1024;     // epilogue parameters: [part & 1][column half][bias | scale | offset][128 floats]
+constexpr int kP8Lds = kP8PB + 2 * 3072;
+
+template <int PREC, int EPI>
+__global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
+  static_assert(PREC == kPrecFp16 || PREC == kPrecFp16Mx, "single-pass fp16 and the 1.25-pass arithmetic");
+  constexpr bool MX = PrecMx(PREC);
+  constexpr bool SWAP = (EPI != kEpiStats);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;   // frames wm * 64.., columns wn * 128..; wave group = wn
+  const int fr_i = lane & 15, fr_g = lane >> 4;
+  const int bid = blockIdx.x;
+  const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
+
+  // ---- this workgroup's share of the K tiles (the partition of tdnn_gemm_kernel_sk, in units of K-tile pairs) ----------
+  const int S = a.p8_ktiles;                   // K tiles of an output tile (even)
+  const int SQ = S >> 1;
+  const int G8 = gridDim.x >> 3;
+  const int xcd = bid & 7, jb = bid >> 3;
+  const int L = a.sk_lanes, NT = a.n_tiles >> 1, cpl = NT / L, Ng = G8 / L;
+  const int col_lane = jb % L, grp_j = jb / L;
+  const int tb0 = (int)((long)a.sk_mtiles * xcd / 8), tb1 = (int)((long)a.sk_mtiles * (xcd + 1) / 8);
+  const long steps_b = (long)(tb1 - tb0) * cpl * SQ;
+  const long s0 = steps_b * grp_j / Ng * 2, s1 = steps_b * (grp_j + 1) / Ng * 2;
+  const int k_head = (int)(s0 % S), k_tail = (int)(s1 % S);
+  const int t_first = (int)((s0 + S - 1) / S), t_end = (int)(s1 / S);
+  // (the launcher sizes the grid so that every share is at least one whole tile: a head and a tail never meet in one tile)
+  const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
+  if (s1 <= s0) return;   // an XCD block without row tiles (launches of fewer than eight of them)
+
+  // ---- staging geometry: a wave stages rows wave * 16 + piece * 8 + (lane >> 3) of every 128-row unit --------------------
+  int st_ru[2], st_c[2];
+  unsigned woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    st_ru[j] = wave * 16 + j * 8 + (lane >> 3);
+    st_c[j] = (lane & 7) ^ ((j * 4 + (lane >> 4)) & 7);   // logical 16-byte chunk this lane fetches
+    const int rho = st_ru[j] & 63;
+    const int wrow = (st_ru[j] >> 6) * 128 + (SWAP ? swap_fields(rho) : rho);
+    woff[j] = (unsigned)(wrow * a.ldw + st_c[j] * 8) * 2u;
+  }
+  unsigned woff4[2] = {0u, 0u};   // 4-bit tile: rows wave * 32 + u * 16 + (lane >> 2), 64 B each, chunks swizzled with two row bits
+  if constexpr (MX) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r4 = wave * 32 + u * 16 + (lane >> 2);
+      const int rho = r4 & 63;
+      const int wrow = ((r4 >> 6) & 1) * 128 + (r4 >> 7) * 64 + (SWAP ? swap_fields(rho) : rho);
+      woff4[u] = (unsigned)(wrow * a.ldw4 + ((lane & 3) ^ ((lane >> 3) & 3)) * 16);
+    }
+  }
+  const unsigned st_lane = lds_base + wave * 2048;
+
+  // ---- per-part state ----------------------------------------------------------------------------------------------------
+  int m0 = 0, n0 = 0, nt = 0;
+  int kind = 0, n_tiles_part = 0, kb_part = 0;
+  // issue side: position in the walk (group, chunk, offset) and the addresses of its K tile
+  int ig = 0, ic = 0, ij = 0;
+  Grp gi = a.grp[0];
+  const char* xb = nullptr;
+  const char* wb = nullptr;
+  const char* wtile = nullptr;          // weight row n0
+  const uint8_t* wtile_4 = nullptr;
+  const uint8_t* wtile_s = nullptr;
+  unsigned xoff[2] = {0u, 0u};
+  long x_next = 0, x_wrap = 0, w_next = 0, w_wrap = 0, x128 = 0;
+  const long w64 = (long)a.ldw * 128;
+  auto bind_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xoff[j] = (unsigned)(st_ru[j] * gi.ld + st_c[j] * 8) * 2u;
+    xb = (const char*)gi.hi + ((long)(m0 + gi.shift0 + ij * gi.dstep) * gi.ld + ic * 64) * 2;
+    wb = wtile + (long)(gi.wcol0 + ij * gi.wstride + ic * 64) * 2;
+    x_next = (long)gi.dstep * gi.ld * 2;
+    x_wrap = 128 - (long)(gi.nshift - 1) * gi.dstep * gi.ld * 2;
+    w_next = (long)gi.wstride * 2;
+    w_wrap = 128 - (long)(gi.nshift - 1) * gi.wstride * 2;
+    x128 = (long)gi.ld * 256;
+  };
+  auto adv = [&]() __attribute__((always_inline)) {
+    if (++ij == gi.nshift) {
+      ij = 0;
+      xb += x_wrap;
+      wb += w_wrap;
+      if (++ic == (gi.ksteps >> 1)) {
+        ic = 0;
+        if (++ig < a.ngrp) {
+          gi = a.grp[ig];
+          bind_group();
+        }
+      }
+    } else {
+      xb += x_next;
+      wb += w_next;
+    }
+  };
+  // staging units: 0 = weights h = 0, 1 = frames 0..127, 2 = frames 128..255, 3 = weights h = 1
+  auto issue = [&](const int unit, const int buf) __attribute__((always_inline)) {
+    if (unit == 0 || unit == 3) {
+      const char* src = wb + (unit == 3 ? w64 : 0);
+      const unsigned dst = st_lane + buf * kP8Buf + kP8XW + (unit == 3 ? kP8Unit : 0);
+      glds16_sbase(src, woff[0], dst);
+      glds16_sbase(src, woff[1], dst + 1024);
+    } else {
+      const char* src = xb + (unit == 2 ? x128 : 0);
+      const unsigned dst = st_lane + buf * kP8Buf + (unit == 2 ? kP8Unit : 0);
+      glds16_sbase(src, xoff[0], dst);
+      glds16_sbase(src, xoff[1], dst + 1024);
+    }
+  };
+  // the 4-bit tile of block `blk` of the tile's walk and its scales: three DMA instructions in EVERY wave (waves 4-7 repeat
+  // the scale pieces of waves 0-3: the counted waits are the same in all waves)
+  auto issue_w4 = [&](const int blk) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      const unsigned d4 = lds_base + kP8W4 + wave * 2048;
+      glds16_sbase(wtile_4 + blk * 64, woff4[0], d4);
+      glds16_sbase(wtile_4 + blk * 64, woff4[1], d4 + 1024);
+      const int pc = wave & 3;   // piece: 128-column tile pc >> 1, half pc & 1
+      glds4_sbase(wtile_s + ((long)(pc >> 1) * SQ + blk) * 512 + (pc & 1) * 256, (unsigned)lane * 4u,
+                  lds_base + kP8SC + pc * 256);
+    }
+  };
+
+  // ---- fragment read geometry ------------------------------------------------------------------------------------------------
+  const int sw = (fr_g ^ ((fr_i >> 1) & 7)) * 16;
+  const int xrd0 = (wm * 64 + fr_i) * 128 + sw, xrd1 = xrd0 ^ 64;
+  const int wrd0 = kP8XW + (wn * 64 + fr_i) * 128 + sw, wrd1 = wrd0 ^ 64;
+  const int w4rd = kP8W4 + (wn * 64 + fr_i) * 64 + (fr_g ^ ((fr_i >> 1) & 3)) * 16;   // + h * 8192 + p * 1024
+
+  // kPrecFp16Mx: scales of the 4-bit copies of the frame fragments (one power of two per 16-row group of the output rows,
+  // from the group maxima of the source plane: see tdnn_gemm_kernel_sk)
+  int xs_b = 0;
+  float xs_f[MX ? 4 : 1];
+  typedef __attribute__((ext_vector_type(4))) unsigned xs_uvec;
+  auto xs_request = [&](const unsigned* gmax, xs_uvec& g) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      const unsigned* p = gmax + ((m0 + wm * 64) >> 4);
+      asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(g) : "s"(p) : "memory");
+    }
+  };
+  auto xs_finish = [&](xs_uvec& g) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g) : : "memory");
+      xs_b = 0;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        unsigned e = (g[f] >> 23) & 255u;
+        e = e < 16u ? 16u : (e > 200u ? 200u : e);
+        xs_b |= (int)((e - 2u) << (8 * f));
+        xs_f[f] = __builtin_bit_cast(float, (e - 2u) << 23);
+      }
+    }
+  };
+  int rg = 0, r_left = 0;   // read side: group of the current K tile, tiles left in it
+
+  f32x4 acc[2][4][4];
+  s16x8 xf[4][2], wf[4][2];
+  i32x4 x4[MX ? 4 : 1];
+
+  auto barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma = [&](auto HH, auto PP, auto QQ, const int k) __attribute__((always_inline)) {
+    constexpr int H = decltype(HH)::value, pw = decltype(PP)::value, qx = decltype(QQ)::value;   // weight fragment pw, frame fragment qx
+    // accumulators tied in place (inline asm): left to itself hipcc rotates the 128 accumulator registers through copies
+    // across the phases of the loop and spills (see tdnn_gemm_kernel_sk); the waits these instructions need are explicit
+    if constexpr (SWAP) mfma16_f16_inplace(wf[pw][k], xf[qx][k], acc[H][pw][qx]);
+    else mfma16_f16_inplace(xf[qx][k], wf[pw][k], acc[H][qx][pw]);
+  };
+  // One phase.  P = phase, B = buffer of the tile, ODD = second tile of its pair (the 4-bit conversions go to dwords 2, 3; the
+  // block-scaled MFMAs follow its last phase), WK = vmcnt of the wait at the end of the LOAD part (-1: none); unit / ibuf =
+  // what the LOAD part stages (unit < 0: nothing), w4_blk >= 0: also the 4-bit tile of that block.
+  auto phase = [&](auto PP, auto BB, auto OO, auto WW, auto WL, const int unit, const int ibuf, const int w4_blk, const bool more) __attribute__((always_inline)) {
+    constexpr int P = decltype(PP)::value, B = decltype(BB)::value, ODD = decltype(OO)::value;
+    constexpr int WK = decltype(WW)::value, WKL = decltype(WL)::value;   // vmcnt of the wait: steady state / last pair of a part
+    const char* xs0 = smem + B * kP8Buf + xrd0;
+    const char* xs1 = smem + B * kP8Buf + xrd1;
+    const char* ws0 = smem + B * kP8Buf + wrd0;
+    const char* ws1 = smem + B * kP8Buf + wrd1;
+    if constexpr (P == 0) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        wf[p][0] = *(const s16x8*)(ws0 + p * 2048);
+        wf[p][1] = *(const s16x8*)(ws1 + p * 2048);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        xf[q][0] = *(const s16x8*)(xs0 + q * 2048);
+        xf[q][1] = *(const s16x8*)(xs1 + q * 2048);
+      }
+    } else if constexpr (P == 1) {
+#pragma unroll
+      for (int q = 2; q < 4; ++q) {
+        xf[q][0] = *(const s16x8*)(xs0 + q * 2048);
+        xf[q][1] = *(const s16x8*)(xs1 + q * 2048);
+      }
+    } else if constexpr (P == 2) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        wf[p][0] = *(const s16x8*)(ws0 + kP8Unit + p * 2048);
+        wf[p][1] = *(const s16x8*)(ws1 + kP8Unit + p * 2048);
+      }
+    }
+    if (unit >= 0) issue(unit, ibuf);
+    if (w4_blk >= 0) issue_w4(w4_blk);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WK >= 0) {
+      if constexpr (WKL >= 0 && WKL != WK) {
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WKL < 0 ? 0 : WKL) : "memory");
+      } else if constexpr (WKL < 0) {
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WK) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WK) : "memory");
+      }
+    }
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the fragments are in (the MFMAs are inline asm: their waits are ours)
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int H = P >> 1;
+    constexpr int Q0 = (P == 0 || P == 3) ? 0 : 2;
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 2>([&](auto K) {
+      static_for<0, 4>([&](auto PW) {
+        static_for<Q0, Q0 + 2>([&](auto QX) { mfma(std::integral_constant<int, H>{}, PW, QX, decltype(K)::value); });
+      });
+    });
+    if constexpr (MX && P < 2) {
+      // the fragments just read, as e2m1: dword 2 * ODD + k of the block's 4-bit fragments
+#pragma unroll
+      for (int q = Q0; q < Q0 + 2; ++q) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          x4[q][2 * ODD + k] = cvt8_fp4(xf[q][k], xs_f[q], x4[q][2 * ODD + k]);
+          asm volatile("" : "+v"(x4[q]));
+        }
+      }
+    }
+    if constexpr (MX && ODD && P == 3) {
+      // the block's 4-bit weight fragments into the registers of the fp16 ones (dead), its scales, 32 block-scaled MFMAs:
+      // h = 0 first (the accumulators of h = 1 were written by the MFMAs just issued)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) wf[w & 3][w >> 2] = *(const s16x8*)(smem + w4rd + (w >> 2) * 8192 + (w & 3) * 1024);
+      int ws_v[2];
+      const char* sc = smem + kP8SC + wn * 512 + (fr_i * 4 + fr_g) * 4;
+      ws_v[0] = *(const int*)(sc);
+      ws_v[1] = *(const int*)(sc + 256);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 4" ::: "memory");   // v_cvt results -> MFMA operands
+      static_for<0, 2>([&](auto HH) {
+        static_for<0, 4>([&](auto PW) {
+          static_for<0, 4>([&](auto QX) {
+            constexpr int h = decltype(HH)::value, pw = decltype(PW)::value, qx = decltype(QX)::value;
+            if constexpr (SWAP) mfma_mx4_inplace<pw, qx>(wf[pw][h], x4[qx], acc[h][pw][qx], ws_v[h], xs_b);
+            else mfma_mx4_inplace<qx, pw>(x4[qx], wf[pw][h], acc[h][qx][pw], xs_b, ws_v[h]);
+          });
+        });
+      });
+    }
+    __builtin_amdgcn_s_setprio(0);
+    barrier();
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 3> I3;
+  typedef std::integral_constant<int, -1> IN;
+  constexpr int E = MX ? 3 : 0;   // DMA instructions of issue_w4 per wave
+
+  // position of K tile k in the walk
+  auto seek = [&](int k, int& g, int& c, int& j) __attribute__((always_inline)) {
+    g = 0;
+    for (;;) {
+      const int n = (a.grp[g].ksteps >> 1) * a.grp[g].nshift;
+      if (k < n || g + 1 >= a.ngrp) break;
+      k -= n;
+      ++g;
+    }
+    const int ns = a.grp[g].nshift;
+    c = k / ns;
+    j = k - c * ns;
+  };
+  constexpr long kPartialFloats = 256L * 256;
+  constexpr int kAuxCoherent = 1 | 16;
+  auto open_part = [&](int part) __attribute__((always_inline)) {
+    int tile, kb, ke;
+    if (k_tail && part == 0) {
+      tile = t_end; kb = 0; ke = k_tail; kind = 1;
+    } else {
+      const int w = part - (k_tail ? 1 : 0);
+      if (w < t_end - t_first) {
+        tile = t_first + w; kb = 0; ke = S; kind = 0;
+      } else {
+        tile = t_first - 1; kb = k_head; ke = S; kind = 2;
+      }
+    }
+    const int mt = tb0 + tile / cpl;
+    nt = col_lane * cpl + tile % cpl;
+    m0 = mt * 256;
+    n0 = nt * 256;
+    wtile = (const char*)a.w_hi + (long)n0 * a.ldw * 2;
+    seek(kb, ig, ic, ij);
+    gi = a.grp[ig];
+    bind_group();
+    rg = ig;
+    r_left = (gi.ksteps >> 1) * gi.nshift - (ic * gi.nshift + ij);
+    kb_part = kb;
+    n_tiles_part = ke - kb;
+    if (EPI != kEpiSplitK && kind != 1 && wave < 6) {
+      // bias / scale / offset of the tile's 256 columns -> LDS, [column half][bias | scale | offset][128]
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const unsigned dst = lds_base + kP8PB + (part & 1) * 3072 + hh * 1536 + wave * 256;
+        if (wave < 2 || a.bn) {
+          const float* src = (wave < 2 ? a.bias : wave < 4 ? a.scale : a.offset) + n0 + hh * 128 + (wave & 1) * 64;
+          glds4_sbase(src, (unsigned)lane * 4u, dst);
+        } else {
+          *(float*)(smem + kP8PB + (part & 1) * 3072 + hh * 1536 + wave * 256 + lane * 4) = wave < 4 ? 1.f : 0.f;
+        }
+      }
+    }
+    xs_uvec xg;
+    if constexpr (MX) {
+      wtile_4 = a.w4 + (long)n0 * a.ldw4;
+      wtile_s = a.w4_scale + (long)nt * 2 * SQ * 512;
+      xs_request(gi.gmax, xg);
+    }
+    issue(0, 0);
+    issue(1, 0);
+    issue(2, 0);
+    issue(3, 0);
+    adv();
+    issue(0, 1);
+    issue(1, 1);
+    xs_finish(xg);
+  };
+
+  open_part(0);
+#pragma nounroll
+  for (int part = 0; part < n_parts; ++part) {
+    if (kind == 2) {
+      const int prev = bid - 8 * L;   // same lane, previous group: its first action was the store waited for here
+      if (tid == 0) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__hip_atomic_load(a.sk_flags + prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
+          __builtin_amdgcn_s_sleep(8);
+          if (__builtin_readcyclecounter() - t0 > 4000000000ull) {
+            __hip_atomic_store(a.sk_error, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.sk_ws + (long)prev * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[h][p][q] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent));
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[h][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // everything open_part issued has landed (and the previous epilogue's stores are out: the counter does not tell them apart)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wn == 1) barrier();
+    const int pairs = n_tiles_part >> 1;
+#pragma nounroll
+    for (int pr = 0; pr < pairs; ++pr) {
+      if constexpr (MX) {
+        if (r_left == 0) {   // the walk enters another source: its group maxima (a pair never straddles two groups)
+          ++rg;
+          r_left = (a.grp[rg].ksteps >> 1) * a.grp[rg].nshift;
+          xs_uvec xg;
+          xs_request(a.grp[rg].gmax, xg);
+          xs_finish(xg);
+        }
+        r_left -= 2;
+      }
+      const int blk = (kb_part >> 1) + pr;
+      // tile t (buffer 0), tile t + 1 (buffer 1).  In the last pair of a part only the second tile's remaining units are
+      // staged; fewer instructions are then in flight behind the ones a wait is for, so its counts are smaller.  Waits: see
+      // the header (with the 4-bit tile: E more instructions in flight)
+      const bool more = pr + 1 < pairs;
+      phase(I0{}, I0{}, I0{}, IN{}, IN{}, 2, 1, -1, more);
+      phase(I1{}, I0{}, I0{}, std::integral_constant<int, 8 + E>{}, std::integral_constant<int, 8 + E>{}, 3, 1, MX ? blk : -1, more);
+      if (more) adv();
+      phase(I2{}, I0{}, I0{}, IN{}, IN{}, more ? 0 : -1, 0, -1, more);
+      phase(I3{}, I0{}, I0{}, std::integral_constant<int, 6 + E>{}, std::integral_constant<int, 2 + E>{}, more ? 1 : -1, 0, -1, more);
+      phase(I0{}, I1{}, I1{}, IN{}, IN{}, more ? 2 : -1, 0, -1, more);
+      phase(I1{}, I1{}, I1{}, std::integral_constant<int, 8>{}, I0{}, more ? 3 : -1, 0, -1, more);
+      if (more) adv();
+      phase(I2{}, I1{}, I1{}, IN{}, IN{}, more ? 0 : -1, 1, -1, more);
+      phase(I3{}, I1{}, I1{}, std::integral_constant<int, 6>{}, IN{}, more ? 1 : -1, 1, -1, more);
+    }
+    if (wn == 0) barrier();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
+    // every wave is past its last LDS read: the buffers may be refilled for the next part while this one's results go out
+    const int e_kind = kind, e_m0 = m0, e_n0 = n0;
+    const float* e_par = (const float*)(smem + kP8PB + (part & 1) * 3072 + wn * 1536);
+    if (part + 1 < n_parts) open_part(part + 1);
+    if (e_kind == 1) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.sk_ws + (long)bid * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[h][p][q]), rs, tid * 16,
+                                                   ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.sk_flags + bid, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      float gm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        constexpr bool LAZY = (EPI == kEpiAct || EPI == kEpiF32);   // parameters read from LDS where they are used: 48 registers less
+        EpiRegs er;
+        epilogue_prefetch_lds<EPI, LAZY>(a, e_par, e_m0 + wm * 64, h * 64, lane, er);
+        gemm_epilogue<PREC, EPI, LAZY>(a, acc[h], e_m0 + wm * 64, e_n0 + wn * 128 + h * 64, lane, er, gm, h == 0 ? 1 : 2, e_par, h * 64);
+      }
+    }
+  }
+}
+
 // Workspace of the stream-K variant (one slot of raw accumulators + one flag per workgroup), per stream: launches on
 // different streams may overlap.  The epoch makes flags of earlier launches stale without clearing them.  Entries
 // belong to whoever owns the stream and are released through release_stream_workspace before the stream is destroyed.
@@ -2277,6 +2758,61 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
   }
 }
 
+
+// tdnn_gemm_kernel_p8 can run this launch: whole 256 x 256 tiles, every K group a whole number of 64-column tiles (of
+// 128-column blocks for kPrecFp16Mx), an even number of K tiles, and for kPrecFp16Mx the residual plane in ITS walk order
+// (GemmArgs::p8 is the caller's statement that w4 / w4_scale are in that order)
+bool gemm_p8_applicable(const GemmArgs& a, int precision) {
+  if (precision != kPrecFp16 && precision != kPrecFp16Mx) return false;
+  if ((a.m_tiles & 1) || (a.n_tiles & 1) || a.ksplit > 1) return false;
+  GemmArgs b = a;
+  build_groups(&b);
+  int t = 0;
+  for (int i = 0; i < b.ngrp; ++i) {
+    if (b.grp[i].ksteps % (precision == kPrecFp16Mx ? 4 : 2) || b.grp[i].ld % 64) return false;
+    if (precision == kPrecFp16Mx && !b.grp[i].gmax) return false;
+    t += (b.grp[i].ksteps >> 1) * b.grp[i].nshift;
+  }
+  if (t < 2 || (t & 1)) return false;
+  if (precision == kPrecFp16Mx && (!a.w4 || !a.w4_scale || a.ldw4 <= 0)) return false;
+  return true;
+}
+
+template <int PREC, int EPI>
+static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
+  if (!gemm_p8_applicable(a, PREC)) return hipErrorInvalidValue;
+  static std::atomic<unsigned long long> attr_done{0};
+  int attr_dev = 0;
+  if (lds_attr_needed(&attr_done, &attr_dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel_p8<PREC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
+    if (e != hipSuccess) return e;
+    attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
+  }
+  GemmArgs b = a;
+  build_groups(&b);
+  b.p8_ktiles = 0;
+  for (int i = 0; i < b.ngrp; ++i) b.p8_ktiles += (b.grp[i].ksteps >> 1) * b.grp[i].nshift;
+  b.sk_mtiles = a.m_tiles >> 1;
+  const int nt = a.n_tiles >> 1;
+  int grid = device_cu_count() / 8 * 8;
+  if (grid < 8) return hipErrorInvalidValue;
+  // column lanes: the largest of 4, 2, 1 that divides the column tiles and the workgroups of an XCD block; groups: as many
+  // as the CUs allow, but every group's share must hold at least one whole tile
+  int l = 4;
+  while (l > 1 && (nt % l || (grid / 8) % l)) l >>= 1;
+  b.sk_lanes = l;
+  const int tiles_min = std::max(1, (b.sk_mtiles / 8) * (nt / l));
+  grid = 8 * l * std::min(grid / 8 / l, tiles_min);
+  SkWorkspace w;
+  hipError_t e = sk_workspace(s, grid, (size_t)grid * 256 * 256 * sizeof(float), &w, &b.sk_epoch, &b.sk_error);
+  if (e != hipSuccess) return e;
+  b.sk_ws = w.ws;
+  b.sk_flags = w.flags;
+  note_kernel("_p8", PREC, EPI, 0);
+  XV_LAUNCH((tdnn_gemm_kernel_p8<PREC, EPI>), dim3(grid), dim3(512), kP8Lds, s, b);
+  return hipGetLastError();
+}
+
 template <int PREC, int EPI>
 static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (PrecXPlanes(PREC) * (256 + 16) * kBK * 2 + PrecWPlanes(PREC) * kTileBytes) + (PrecMx(PREC) ? 1536 : 0) + (PrecMx2(PREC) ? 3 * (256 + 16) * 4 : 0);
@@ -2313,6 +2849,10 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+  if (a.p8) {   // the caller packed / chose this layer for the 64-column K walk: no other kernel accumulates in that order
+    if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx) && (EPI == kEpiAct || EPI == kEpiStats)) return launch_one_p8<PREC, EPI>(a, s);
+    else return hipErrorInvalidValue;
+  }
   const int variant = gemm_variant();
   // default policy (same box, 256 x 400 workload): two-pass mode - stream-K for every layer; three-pass and single-pass
   // modes - stream-K only for the long-K layers (tdnn2 / tdnn3, 48 K steps: -5 % / -9 %), the short-K ones are faster

@@ -98,6 +98,25 @@ def test_repeatability_and_single_utterance_batch(v2):
         ctx.forward_batch(x[:0], [0])               # empty batch is an argument error, not a crash
 
 
+def test_batch_that_starts_at_a_large_row_offset(v2):
+    """xv_forward_batch with row_offsets[0] > 0 (a window of a larger feature buffer).  The engine stages only the rows of
+    the batch and hands the kernels a base shifted DOWN by row_offsets[0] rows, so element 0 of that base lies far below the
+    staging buffer: the first-layer kernel's unconditional loads for slots without a source frame must not go there
+    (a fault is fatal with XNACK off).  Same bits as the batch at offset 0, in every arithmetic."""
+    P, net, line, model, ctx, ev = v2
+    utts = [H.features(500 + i, T) for i, T in enumerate((400, 57, 333, 15))]
+    feats, offs = H.pack(utts)
+    shift = 3_000_000                                   # 276 MB of rows in front: far outside anything mapped nearby
+    for c in (ctx, P.Context(model, precision=P.PREC_FP16X3)):
+        want = c.forward_batch(feats, offs)
+        # rows below row_offsets[0] are never read: pass a base the batch's own rows start 3M rows above
+        base = feats.ctypes.data - shift * feats.shape[1] * 4
+        out = np.empty_like(want)
+        o2 = (np.asarray(offs) + shift).astype(np.int32)
+        P._check(P.lib().xv_forward_batch(c._h, base, o2.ctypes.data, len(o2) - 1, out.ctypes.data))
+        assert np.array_equal(out, want)
+
+
 def test_compressed_feature_archive_through_the_cli(tmp_path, v2):
     # steps/make_mfcc.sh writes compress=true archives (make_mfcc.sh:12); the extractor must read CM/CM2 directly
     P, net, line, model, ctx, ev = v2

@@ -166,3 +166,53 @@ def test_ctx_create_broadcast_over_two_devices():
     assert [c.device for c in ctxs] == [0, 1]
     for c in ctxs:
         assert np.array_equal(c.forward_batch(feats, offs), want)
+
+
+def _two_gpus():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+def test_bench_two_gpus_over_rccl():
+    """bench.py --gpus 2 as the driver launches it: fresh child processes under torch.distributed.run, one rank per GPU, the
+    `nccl` (= RCCL) backend, the weight image broadcast over xGMI, max-over-ranks timing, one JSON line whose value is the
+    whole job's.  Needs two visible GPUs (the one-GPU test boxes skip it; the driver's 8-GPU node runs it)."""
+    import json
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--no-extra-modes", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["parity_rel_err_vs_oracle_fp32"] < 1e-4
+    # two GPUs process two batches per step: well above what one of them delivers alone on this workload
+    assert d["value"] > 1.5 * 256 / (d["ms_per_step"] * 1e-3) / 2 * 0.99
+
+
+def test_dist_extract_two_gpus_over_rccl_equal_one_rank(tmp_path):
+    """dist_extract.py --backend nccl with two ranks on two devices against a one-rank run of the same job: same keys in the
+    same order, every vector byte-identical, the concatenated per-rank arks are the one-rank ark (utils/split_scp.pl:208-217,
+    extract_xvectors_new.sh:99) - with the weights carried by a real two-rank RCCL broadcast."""
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    net, _ = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    lens = [400, 137, 25, 333, 1000, 64, 400, 400, 211, 15, 399, 640, 87] + [400] * 20
+    utts = [("utt%02d" % i, H.features(900 + i, T)) for i, T in enumerate(lens)]
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"))
+    one, log1 = _run_dist_extract(tmp_path, 1, "one", ["--backend", "nccl"])
+    two, log2 = _run_dist_extract(tmp_path, 2, "two", ["--backend", "nccl"])
+    assert "Done 33 utterances, failed for 0 (over 2 ranks)" in log2, log2[-2000:]
+    k1 = [l.split()[0] for l in open(one / "xvector_t.scp")]
+    assert k1 == [l.split()[0] for l in open(two / "xvector_t.scp")] == [k for k, _ in utts]
+    v1 = dict(kio.read_scp(str(one / "xvector_t.scp"), "vector"))
+    v2 = dict(kio.read_scp(str(two / "xvector_t.scp"), "vector"))
+    for k in k1:
+        assert v1[k].tobytes() == v2[k].tobytes(), k
+    cat = (two / "xvector_t.1.ark").read_bytes() + (two / "xvector_t.2.ark").read_bytes()
+    assert cat == (one / "xvector_t.1.ark").read_bytes()
