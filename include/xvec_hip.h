@@ -257,6 +257,11 @@ typedef struct {
    * out_lo4 / out_lo4_scale (epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E): see xv_seg_desc */
   const void* w4b; int32_t ldw4b; const void* w4b_scale;
   void* out_lo4; void* out_lo4_scale;
+  /* != 0: run tdnn_gemm_kernel_p8 (256 x 256 tiles, K tiles of 64 columns; XV_PREC_FP16 and XV_PREC_FP16MX, epilogues 0 and 2;
+   * rows and n_pad multiples of 256).  Its K walk is group -> 64-column chunk -> offset: for XV_PREC_FP16MX w4 / w4_scale must
+   * come from xv_pack_mx_residual64.  A layer runs this kernel for every launch of a mode or for none (its sums are formed in
+   * another order than the 32-column kernels'). */
+  int32_t p8;
 } xv_gemm_desc;
 /* Host helper for the test above: packs the e2m1 residual plane of one weight matrix exactly like xv_model_pack does
  * (w, w_hi_f16: [n_pad][k_len] row-major, k_len = sum of the segments' k_len; seg_src[j] equal = same source plane).
@@ -265,6 +270,9 @@ typedef struct {
 xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg,
                               const int32_t* seg_src, const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4,
                               uint8_t* w4_scale);
+/* the same in the K-walk order of tdnn_gemm_kernel_p8 (xv_gemm_desc.p8) */
+xv_status xv_pack_mx_residual64(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg, const int32_t* seg_src,
+                                const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4, uint8_t* w4_scale);
 /* XV_PREC_FP16MX2: the 4-bit image of the weights for the second K walk (w: [n_pad][k_len], the values of the fp16 planes'
  * domain; every k_len a multiple of 128): w4b receives n_pad * (k_len / 128 * 64) bytes, w4b_scale n_pad * (k_len / 32)
  * bytes in natural order (tile them with xv_tile_mx_scales). */

@@ -59,7 +59,8 @@ class GemmDesc(ctypes.Structure):
                 ("w4", ctypes.c_void_p), ("ldw4", ctypes.c_int32), ("w4_scale", ctypes.c_void_p),
                 ("gmax_out", ctypes.c_void_p),
                 ("w4b", ctypes.c_void_p), ("ldw4b", ctypes.c_int32), ("w4b_scale", ctypes.c_void_p),
-                ("out_lo4", ctypes.c_void_p), ("out_lo4_scale", ctypes.c_void_p)]
+                ("out_lo4", ctypes.c_void_p), ("out_lo4_scale", ctypes.c_void_p),
+                ("p8", ctypes.c_int32)]
 
 
 class Calibration(ctypes.Structure):
@@ -77,7 +78,7 @@ ABI_SYMBOLS = [
     "xv_ctx_profile_report", "xv_extract_utterances", "xv_ctx_calibrate", "xv_ctx_set_fast_mode", "xv_ctx_fast_mode",
     "xv_calibrate_table", "xv_ctx_set_calibration",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
-    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_tile_mx_scales", "xv_pack_mx_weights",
+    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_pack_mx_residual64", "xv_tile_mx_scales", "xv_pack_mx_weights",
 ]
 
 _lib = None
@@ -132,6 +133,7 @@ def lib():
                                                  ctypes.POINTER(ctypes.c_void_p)]
     L.xv_pack_mx_residual.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.xv_pack_mx_residual64.argtypes = L.xv_pack_mx_residual.argtypes
     L.xv_pack_mx_weights.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.xv_tile_mx_scales.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
@@ -430,7 +432,7 @@ def kernel_tdnn_gemm(desc):
     _check(lib().xv_kernel_tdnn_gemm(ctypes.byref(desc)))
 
 
-def pack_mx_residual(w, w_hi_f16, segs):
+def pack_mx_residual(w, w_hi_f16, segs, walk64=False):
     """e2m1 residual plane + E8M0 scales [n_pad, K / 32] (one per block of four K steps and lane group) of XV_PREC_FP16MX
     for one weight matrix (host; no GPU).
     w: float32 [n_pad, K]; w_hi_f16: uint16 [n_pad, K] (fp16 bit patterns); segs: [(source id, row shift, k_len)]."""
@@ -444,8 +446,9 @@ def pack_mx_residual(w, w_hi_f16, segs):
     assert int(klen.sum()) == K and K % 128 == 0
     w4 = np.zeros((n_pad, K // 128 * 64), dtype=np.uint8)
     sc = np.zeros((n_pad, K // 32), dtype=np.uint8)
-    _check(lib().xv_pack_mx_residual(w.ctypes.data, hi.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data,
-                                     klen.ctypes.data, w4.ctypes.data, sc.ctypes.data))
+    fn = lib().xv_pack_mx_residual64 if walk64 else lib().xv_pack_mx_residual   # walk64: the K order of tdnn_gemm_kernel_p8
+    _check(fn(w.ctypes.data, hi.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data,
+              klen.ctypes.data, w4.ctypes.data, sc.ctypes.data))
     return w4, sc
 
 

@@ -541,10 +541,16 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
     a.w4b_scale = (const uint8_t*)d->w4b_scale;
     a.out_lo4 = (uint8_t*)d->out_lo4;
     a.out_lo4s = (uint8_t*)d->out_lo4_scale;
+    a.p8 = d->p8;
+    if (a.p8) {
+      if (!xv::gemm_p8_applicable(a, d->precision) || (d->epilogue != xv::kEpiAct && d->epilogue != xv::kEpiStats))
+        return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: p8 needs XV_PREC_FP16 or XV_PREC_FP16MX, epilogue 0 or 2, rows and n_pad "
+                                "multiples of 256, K groups of whole 64-column tiles (128-column blocks for XV_PREC_FP16MX)");
+    } else
     if (d->precision == xv::kPrecFp16Mx2 && !xv::gemm_mx2_applicable(a))
       return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX2 needs what XV_PREC_FP16MX needs and the 4-bit planes of the "
                               "weights and of every source (whole 128-column steps)");
-    if (d->precision == xv::kPrecFp16Mx && !xv::gemm_mx_applicable(a))
+    if (!a.p8 && d->precision == xv::kPrecFp16Mx && !xv::gemm_mx_applicable(a))
       return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX needs the residual plane, a group-max table per source, "
                               "K groups of whole 128-column blocks and an even number of 128-row tiles");
     hipError_t e = xv::launch_tdnn_gemm(a, d->precision, d->epilogue, (hipStream_t)d->hip_stream);
@@ -553,8 +559,9 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
   });
 }
 
-xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg, const int32_t* seg_src,
-                              const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4, uint8_t* w4_scale) {
+static xv_status PackMxResidualImpl(bool walk64, const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg,
+                                    const int32_t* seg_src, const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4,
+                                    uint8_t* w4_scale) {
   if (!w || !w_hi_f16 || !seg_src || !seg_shift || !seg_klen || !w4 || !w4_scale || nseg < 1 || nseg > xv::kMaxSeg || n_pad < 1)
     return Fail(XV_ERR_ARG, "xv_pack_mx_residual: bad argument");
   return Guard([&] {
@@ -571,7 +578,8 @@ xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t 
     const int ng = xv::PlanWalkGroups(nseg, key, shift, ksteps, wg);
     std::vector<int> step_wcol(k_pad / xv::kBK);
     bool ok = false;
-    xv::PlanWalkSteps(ng, wg, step_wcol.data(), (int)step_wcol.size(), &ok);
+    if (walk64) xv::PlanWalkSteps64(ng, wg, step_wcol.data(), (int)step_wcol.size(), &ok);
+    else xv::PlanWalkSteps(ng, wg, step_wcol.data(), (int)step_wcol.size(), &ok);
     if (!ok) return Fail(XV_ERR_ARG, "xv_pack_mx_residual: a K group is not a multiple of four steps");
     const int ldw4 = k_pad / xv::kBK / 4 * 64;
     std::vector<float> res(k_pad);
@@ -581,6 +589,16 @@ xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t 
     }
     return XV_OK;
   });
+}
+
+xv_status xv_pack_mx_residual(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg, const int32_t* seg_src,
+                              const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4, uint8_t* w4_scale) {
+  return PackMxResidualImpl(false, w, w_hi_f16, n_pad, nseg, seg_src, seg_shift, seg_klen, w4, w4_scale);
+}
+
+xv_status xv_pack_mx_residual64(const float* w, const uint16_t* w_hi_f16, int32_t n_pad, int32_t nseg, const int32_t* seg_src,
+                                const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4, uint8_t* w4_scale) {
+  return PackMxResidualImpl(true, w, w_hi_f16, n_pad, nseg, seg_src, seg_shift, seg_klen, w4, w4_scale);
 }
 
 xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,

@@ -16,8 +16,9 @@ namespace {
 
 constexpr int kDefaultFastMinPooledMx2 = 160;   // the deeper c-vector network measured 7.9e-5 at 117 pooled frames (heavy-tailed model)
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 4;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
-                                       // plane; 4: + the 4-bit weight image of kPrecFp16Mx2
+constexpr uint32_t kBlobVersion = 5;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
+                                       // plane; 4: + the 4-bit weight image of kPrecFp16Mx2; 5: + the residual plane in the
+                                       // K-walk order of tdnn_gemm_kernel_p8
 constexpr uint64_t kNone = ~0ull;
 
 struct BlobHeader {
@@ -41,6 +42,8 @@ struct BlobLayer {
   uint64_t w4, w4_scale;                     // kPrecFp16Mx residual plane + its E8M0 scales in both tile orders, or kNone
   int32_t ldw4, ldw4b;
   uint64_t w4b, w4b_scale;                   // kPrecFp16Mx2: 4-bit image of the weights + scales (both tile orders), or kNone
+  uint64_t w4p, w4p_scale;                   // the residual plane of w4 in the walk order of tdnn_gemm_kernel_p8 (PlanWalkSteps64:
+                                             // 64-column chunk -> offset) + scales, for the layers that kernel can run, or kNone
 };
 
 // Round-to-nearest-even onto the e2m1 grid {0, .5, 1, 1.5, 2, 3, 4, 6} (saturating), like v_cvt_scalef32_pk_fp4_*.
@@ -182,7 +185,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     b.offset = cur;
     cur = Align256(cur + (uint64_t)b.n_pad * 4);
     // kPrecFp16Mx residual plane (frame-level layers whose K walk consists of whole blocks of four steps)
-    b.w4 = b.w4_scale = b.w4b = b.w4b_scale = kNone;
+    b.w4 = b.w4_scale = b.w4b = b.w4b_scale = b.w4p = b.w4p_scale = kNone;
     b.ldw4 = b.ldw4b = 0;
     if ((precision == kPrecAuto || precision == kPrecFp16Mx || precision == kPrecFp16Mx2) && !L.segment_level) {
       long key[kMaxSeg];
@@ -202,6 +205,15 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4);
         b.w4_scale = cur;
         cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);   // both tile orders (TileMxScales)
+        bool ok64 = false;
+        if (b.n_pad % 256 == 0 && PlanWalkSteps64(ng, wg, nullptr, 0, &ok64) == nsteps && ok64) {
+          // whole 256-column tiles and K groups of whole 128-column blocks: tdnn_gemm_kernel_p8 can run the layer's 1.25-pass
+          // launches; its blocks are pairs of 64-column K tiles, so the residual plane is packed a second time in its order
+          b.w4p = cur;
+          cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4);
+          b.w4p_scale = cur;
+          cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
+        }
       }
       if (precision == kPrecFp16Mx2) {
         // second K walk: every source another layer's output padded to whole 128-column steps (kernels.hip,
@@ -328,6 +340,24 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
       }
       TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4_scale);
       TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4_scale + (size_t)b.n_pad * nsc);
+      if (b.w4p != kNone) {   // the same residuals in the walk order of tdnn_gemm_kernel_p8
+        std::vector<int> step64(b.k_pad / kBK);
+        PlanWalkSteps64(ng, wg, step64.data(), (int)step64.size(), nullptr);
+        std::fill(nat.begin(), nat.end(), 127);
+        for (int n = 0; n < L.out_dim; ++n) {
+          for (int k = 0; k < b.k_pad; ++k) {
+            float r = 0.f;
+            if (src_col[k] >= 0) {
+              const float w = L.w[(size_t)n * L.in_dim + src_col[k]] * wscale;
+              r = w - host_f16_to_f32(whi[(size_t)n * b.k_pad + k]);
+            }
+            res[k] = r;
+          }
+          PackMxRow(res.data(), b.k_pad, step64.data(), data + b.w4p + (size_t)n * b.ldw4, nat.data() + (size_t)n * nsc);
+        }
+        TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4p_scale);
+        TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4p_scale + (size_t)b.n_pad * nsc);
+      }
       if (b.w4b != kNone) {   // kPrecFp16Mx2: 4-bit image of the (scaled) weights in the order of the second walk
         std::vector<int> lo_wcol(b.k_pad / 128);
         const int n_lo = PlanWalkLoSteps(ng, wg, lo_wcol.data(), (int)lo_wcol.size());
@@ -478,6 +508,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
     li.right = b.right;
     li.has_w4 = b.w4 != kNone;
     li.has_w4b = b.w4b != kNone;
+    li.has_w4p = b.w4p != kNone;
     for (int j = 0; j < b.nsrc; ++j) {
       LayerSource s;
       s.layer = b.src_layer[j];
@@ -607,6 +638,12 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     layers_[i].w4b = b.w4b == kNone ? nullptr : base + b.w4b;
     layers_[i].w4b_scale = b.w4b_scale == kNone ? nullptr : base + b.w4b_scale;
     layers_[i].ldw4b = b.ldw4b;
+    layers_[i].w4p = b.w4p == kNone ? nullptr : base + b.w4p;
+    layers_[i].w4p_scale = b.w4p_scale == kNone ? nullptr : base + b.w4p_scale;
+  }
+  {
+    const char* e = getenv("XVEC_P8");   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
+    use_p8_ = !(e && *e && atoi(e) == 0);
   }
   in_ld_ = RoundUp(info_.input_dim, kBK);
   stats_ld_ = RoundUp(2 * info_.pool_dim, kBK);
@@ -1146,6 +1183,12 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         if (first_prof) prof_labels_.back() += std::string(" ") + last_gemm_kernel();
       }
     } else if (li.segment_level || plan.rows_fast == 0) {
+      if (prec == kPrecFp16 && use_p8_ && !li.segment_level && (epi == kEpiAct || epi == kEpiStats)) {
+        // single-pass fp16: the layers tdnn_gemm_kernel_p8 can run, run it - for every launch (see the fast region below)
+        GemmArgs g8 = ga;
+        g8.p8 = 1;
+        if (gemm_p8_applicable(g8, kPrecFp16)) ga = g8;
+      }
       Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
       if (first_prof) prof_labels_.back() += std::string(" ") + last_gemm_kernel();
     } else {
@@ -1187,6 +1230,15 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
             if (rprec == kPrecFp16x3E && epi != kEpiAct) throw EngineError("fp16mx2: layer " + li.name + " cannot run the mode");
           } else {
             rprec = (mx_pass && gemm_mx_applicable(gr)) ? (int)kPrecFp16Mx : (int)kPrecFp16x2;
+            if (rprec == kPrecFp16Mx && use_p8_ && dl.w4p && (epi == kEpiAct || epi == kEpiStats)) {
+              // the layer's 1.25-pass launches run the 256 x 256 x 64 kernel - all of them, whatever their size: its sums are
+              // formed in another order than the 32-column kernels', and a chunk's embedding must not depend on its batch
+              GemmArgs g8 = gr;
+              g8.p8 = 1;
+              g8.w4 = dl.w4p;
+              g8.w4_scale = dl.w4p_scale + (epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0);
+              if (gemm_p8_applicable(g8, kPrecFp16Mx)) gr = g8;
+            }
           }
         }
         Check(launch_tdnn_gemm(gr, rprec, epi, s), "tdnn_gemm launch");

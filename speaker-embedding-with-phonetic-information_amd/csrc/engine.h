@@ -53,6 +53,7 @@ struct BlobLayerInfo {
   int in_dim, out_dim, k_pad, n_pad, relu, bn, log_softmax, segment_level, left, right;
   bool has_w4 = false;   // carries the 4-bit residual plane of kPrecFp16Mx
   bool has_w4b = false;  // and the 4-bit weight image of kPrecFp16Mx2
+  bool has_w4p = false;  // and the residual plane in the walk order of tdnn_gemm_kernel_p8
   std::vector<LayerSource> src;
 };
 
@@ -170,6 +171,8 @@ class Engine {
     const uint8_t* w4b;         // kPrecFp16Mx2
     const uint8_t* w4b_scale;
     int ldw4b;
+    const uint8_t* w4p = nullptr;        // residual plane + scales in the K-walk order of tdnn_gemm_kernel_p8 (row pitch ldw4)
+    const uint8_t* w4p_scale = nullptr;
     // layers that read only the network input and run tdnn_first_kernel: compact weight planes [n_pad][kFirstK], built on
     // the device from the packed image at construction (owned: first_buf)
     bool first = false;
@@ -235,6 +238,7 @@ class Engine {
   int slow_prec_ = 0;
   bool has_fast_ = false;
   bool fast_mx_ = false;
+  bool use_p8_ = true;      // tdnn_gemm_kernel_p8 for the layers and modes it can run (XVEC_P8=0: never)
   bool fast_mx2_ = false;   // kPrecFp16Mx2: every frame-level layer of a fast chunk runs it (or kPrecFp16x3E on the input)
   // Frame-level log-posteriors in the single-pass fp16 mode: the head's logits stay a 16-bit plane like every other layer's
   // output of that mode (2 instead of 4 bytes per logit written by the head GEMM and read by the LogSoftmax pass: the two

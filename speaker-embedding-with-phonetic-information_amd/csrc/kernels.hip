@@ -2392,42 +2392,64 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     constexpr int H = P >> 1;
     constexpr int Q0 = (P == 0 || P == 3) ? 0 : 2;
     __builtin_amdgcn_s_setprio(1);
-    static_for<0, 2>([&](auto K) {
-      static_for<0, 4>([&](auto PW) {
-        static_for<Q0, Q0 + 2>([&](auto QX) { mfma(std::integral_constant<int, H>{}, PW, QX, decltype(K)::value); });
-      });
-    });
     if constexpr (MX && P < 2) {
-      // the fragments just read, as e2m1: dword 2 * ODD + k of the block's 4-bit fragments
-#pragma unroll
-      for (int q = Q0; q < Q0 + 2; ++q) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          x4[q][2 * ODD + k] = cvt8_fp4(xf[q][k], xs_f[q], x4[q][2 * ODD + k]);
-          asm volatile("" : "+v"(x4[q]));
-        }
-      }
-    }
-    if constexpr (MX && ODD && P == 3) {
-      // the block's 4-bit weight fragments into the registers of the fp16 ones (dead), its scales, 32 block-scaled MFMAs:
-      // h = 0 first (the accumulators of h = 1 were written by the MFMAs just issued)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int w = 0; w < 8; ++w) wf[w & 3][w >> 2] = *(const s16x8*)(smem + w4rd + (w >> 2) * 8192 + (w & 3) * 1024);
+      // 16 MFMAs and, one behind each, the 16 conversions of the fragments just read (e2m1 dword 2 * ODD + k of the block's
+      // 4-bit fragments): left to hipcc twelve of them trail the MFMAs as one chain of dependent quarter-rate instructions
+      // (every fragment's four conversions write bytes of one register), ~200 cycles of an MFMA part in which the matrix pipe
+      // idles.  Here the four chains (frame fragment x 32-column half) take turns, so dependent ones are eight issues apart.
+      static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int mk = i >> 3, mp = (i >> 1) & 3, mq = Q0 + (i & 1);          // MFMA i: k-half, weight fragment, frame fragment
+        mfma(std::integral_constant<int, H>{}, std::integral_constant<int, mp>{}, std::integral_constant<int, mq>{}, mk);
+        constexpr int cq = Q0 + (i & 1), ck = (i >> 1) & 1, cj = i >> 2;          // conversion i: chain (cq, ck), its dword cj
+        const u32x4 u = __builtin_bit_cast(u32x4, xf[cq][ck]);
+        int d = x4[cq][2 * ODD + ck];
+        asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,%3,%4]"
+                     : "+v"(d)
+                     : "v"(u[cj]), "v"(xs_f[cq]), "n"(cj & 1), "n"(cj >> 1));
+        x4[cq][2 * ODD + ck] = d;
+      });
+    } else if constexpr (MX && ODD && P == 3) {
+      // last phase of a block: its fp16 MFMAs by 32-column half, the 4-bit weight fragments of h = 0 / h = 1 read into the
+      // registers of the half just finished (their latency behind the other half's MFMAs / the first 16 block-scaled ones)
       int ws_v[2];
       const char* sc = smem + kP8SC + wn * 512 + (fr_i * 4 + fr_g) * 4;
       ws_v[0] = *(const int*)(sc);
       ws_v[1] = *(const int*)(sc + 256);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
+      static_for<0, 4>([&](auto PW) {
+        static_for<Q0, Q0 + 2>([&](auto QX) { mfma(std::integral_constant<int, H>{}, PW, QX, 0); });
+      });
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 4" ::: "memory");   // v_cvt results -> MFMA operands
+#pragma unroll
+      for (int w = 0; w < 4; ++w) wf[w][0] = *(const s16x8*)(smem + w4rd + w * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 4>([&](auto PW) {
+        static_for<Q0, Q0 + 2>([&](auto QX) { mfma(std::integral_constant<int, H>{}, PW, QX, 1); });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) wf[w][1] = *(const s16x8*)(smem + w4rd + 8192 + w * 1024);
+      asm volatile("s_waitcnt lgkmcnt(4)\n\ts_nop 4" ::: "memory");   // the fragments of h = 0 are in; v_cvt results -> MFMA operands
+      __builtin_amdgcn_sched_barrier(0);
       static_for<0, 2>([&](auto HH) {
+        constexpr int h = decltype(HH)::value;
+        if constexpr (h == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         static_for<0, 4>([&](auto PW) {
           static_for<0, 4>([&](auto QX) {
-            constexpr int h = decltype(HH)::value, pw = decltype(PW)::value, qx = decltype(QX)::value;
+            constexpr int pw = decltype(PW)::value, qx = decltype(QX)::value;
             if constexpr (SWAP) mfma_mx4_inplace<pw, qx>(wf[pw][h], x4[qx], acc[h][pw][qx], ws_v[h], xs_b);
             else mfma_mx4_inplace<qx, pw>(x4[qx], wf[pw][h], acc[h][qx][pw], xs_b, ws_v[h]);
           });
+        });
+      });
+    } else {
+      static_for<0, 2>([&](auto K) {
+        static_for<0, 4>([&](auto PW) {
+          static_for<Q0, Q0 + 2>([&](auto QX) { mfma(std::integral_constant<int, H>{}, PW, QX, decltype(K)::value); });
         });
       });
     }

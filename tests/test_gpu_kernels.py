@@ -46,7 +46,7 @@ def _planes_value(hi, lo):
     return hi.float() + (lo.float() if lo is not None else 0)
 
 
-def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None):
+def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None, p8=0):
     """segs: list of (source index, ld, row_shift, k_len).  Returns (kernel output, reference output)."""
     torch = _torch()
     P = _pkg()
@@ -81,6 +81,7 @@ def _run_case(prec, epi, rows, n_pad, segs, relu, bn, seed=0, m_valid=None):
     d.bias, d.scale, d.offset = bias.data_ptr(), scale.data_ptr(), offset.data_ptr()
     d.relu, d.bn = int(relu), int(bn)
     d.hip_stream = None
+    d.p8 = p8
 
     # reference on the values the kernel actually sees (quantised planes), accumulated in fp32/fp64
     Xq = [_planes_value(*p).double() for p in Xp]
@@ -279,7 +280,7 @@ def _gmax_bits(plane_abs_max, torch):
     return plane_abs_max.float().view(torch.int32)
 
 
-def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6):
+def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6, p8=0):
     torch = _torch()
     P = _pkg()
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -304,7 +305,7 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6):
     Wh = W.to(torch.float16)
     # residual plane + row scales from the library's own packer (the same code xv_model_pack runs)
     w4, w4s = P.pack_mx_residual(W.cpu().numpy(), Wh.cpu().view(torch.int16).numpy().view(np.uint16),
-                                 [(s[0], s[2], s[3]) for s in segs])
+                                 [(s[0], s[2], s[3]) for s in segs], walk64=bool(p8))
     w4_d, w4s_d = torch.from_numpy(w4).to(dev), torch.from_numpy(w4s).to(dev)
     w4t_d = torch.from_numpy(P.tile_mx_scales(w4s, epi)).to(dev)    # the same scales in the kernels' staging order
     # group maxima of the source planes (rows relative to logical row 0)
@@ -331,10 +332,12 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6):
         d.w4b, d.ldw4b, d.w4b_scale = w4b_d.data_ptr(), K // 2, w4bs_d.data_ptr()
     d.w_hi, d.w_lo, d.ldw = Wh.data_ptr(), None, K
     d.w4, d.ldw4, d.w4_scale = w4_d.data_ptr(), K // 128 * 64, w4t_d.data_ptr()
-    d.rows, d.n_pad = rows, n_pad
+    run_rows = variant_rows or rows     # variant_rows: launch only the first rows of the same data (another tile partition)
+    d.rows, d.n_pad = run_rows, n_pad
     d.bias, d.scale, d.offset = bias.data_ptr(), scale.data_ptr(), offset.data_ptr()
     d.relu, d.bn = 1, 1
     d.hip_stream = None
+    d.p8 = p8
 
     # ---- reference: fp16 x . fp16 w_hi + q4(x / sx) sx . q4((w - w_hi) / sw) sw, in fp64
     Whd = Wh.double()
@@ -351,7 +354,10 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6):
         klen = segs[j][3]
         for jj in range(ns):
             c = np.arange(klen)
-            step_of_col[k0 + jj * klen + c] = base + (c // 32) * ns + jj
+            if p8:   # tdnn_gemm_kernel_p8: 64-column chunk -> offset -> the chunk's two halves
+                step_of_col[k0 + jj * klen + c] = base + ((c // 64) * ns + jj) * 2 + (c % 64) // 32
+            else:
+                step_of_col[k0 + jj * klen + c] = base + (c // 32) * ns + jj
         base += ns * klen // 32
         k0 += ns * klen
         j += ns
@@ -387,8 +393,8 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6):
         P.kernel_tdnn_gemm(d)
         torch.cuda.synchronize()
         # the recorded group maxima are those of the fp32 results before the fp16 rounding of the plane
-        want = z.float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))
-        got = gm_out.view(torch.float32)
+        want = z.float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))[:run_rows // 16]
+        got = gm_out.view(torch.float32)[:run_rows // 16]
         assert torch.allclose(got, want, rtol=1e-4, atol=0), (got[:4], want[:4])
         if prec == 7:   # the output plane with its own 4-bit residual: two to three bits better than fp16 alone
             return oh.double().cpu().numpy() + _decode_lo4(o4, o4s, n_pad), z.cpu().numpy()
@@ -471,3 +477,71 @@ def test_gemm_mx2_per_tile_kernel(epi, segs):
         assert (np.abs(out - ref) / scale).max() < 3e-5
     else:
         assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tdnn_gemm_kernel_p8: 256 x 256 tiles, K tiles of 64 columns (xv_gemm_desc.p8).  Same references as above - the kernel
+# forms its sums in another order (64-column chunk -> offset), which a tolerance on fp32 accumulation order does not see.
+P8_TDNN2 = [(0, 512, -2, 512), (0, 512, 0, 512), (0, 512, 2, 512)]
+P8_TDNN3 = [(0, 512, -3, 512), (0, 512, 0, 512), (0, 512, 3, 512)]
+P8_PLAIN = [(0, 512, 0, 512)]
+P8_TWO = [(0, 512, 0, 512), (1, 128, 0, 128)]
+
+
+def _p8_check(out, ref, epi, tol):
+    if epi == 2:
+        scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+        assert (np.abs(out - ref) / scale).max() < 3e-5
+    else:
+        assert np.abs(out - ref).max() / np.abs(ref).max() < tol
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", [P8_TDNN2, P8_PLAIN, P8_TWO], ids=["tdnn2", "tdnn4", "cvec5"])
+def test_gemm_p8_fp16_small_launch(epi, segs):
+    # 3 row tiles x 2 column tiles on a grid of a few workgroups: whole tiles only, XCD blocks without tiles return at once
+    out, ref = _run_case(2, epi, 3 * 256, 512, segs, relu=True, bn=True, seed=21, p8=1)
+    _p8_check(out, ref, epi, TOL[2] + OUT_Q[2])
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+def test_gemm_p8_fp16_stream_k(epi):
+    # 100 row tiles x 2 column tiles = 200 tiles of 24 K tiles on 256 workgroups: 12.5 row tiles per XCD block, 16 groups of 2
+    # column lanes, every workgroup a head part, whole tiles and a tail part cut at an even K tile inside an offset group
+    out, ref = _run_case(2, epi, 100 * 256, 512, P8_TDNN3, relu=True, bn=True, seed=22, p8=1)
+    _p8_check(out, ref, epi, TOL[2] + OUT_Q[2])
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", [P8_TDNN2, P8_TDNN3, P8_PLAIN, P8_TWO], ids=["tdnn2", "tdnn3", "tdnn4", "cvec5"])
+def test_gemm_p8_mx_small_launch(epi, segs):
+    out, ref = _run_mx_case(epi, 3 * 256, 512, segs, seed=23, p8=1)
+    _p8_check(out, ref, epi, 2e-5 + 2.0 ** -10)
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", [P8_TDNN3, P8_TWO], ids=["tdnn3", "cvec5"])
+def test_gemm_p8_mx_stream_k(epi, segs):
+    out, ref = _run_mx_case(epi, 100 * 256, 768 if segs is P8_TWO else 512, segs, seed=24, p8=1)
+    _p8_check(out, ref, epi, 2e-5 + 2.0 ** -10)
+
+
+def test_gemm_p8_is_independent_of_the_cut():
+    """The same rows as part of a large launch (stream-K cuts inside tiles) and as a launch of their own (whole tiles): same
+    bits - a chunk's activations do not depend on what it is batched with."""
+    torch = _torch()
+    big, _ = _run_mx_case(0, 100 * 256, 512, P8_TDNN2, seed=25, p8=1)
+    small, _ = _run_mx_case(0, 100 * 256, 512, P8_TDNN2, seed=25, p8=1, variant_rows=2 * 256)
+    assert np.array_equal(big[:2 * 256], small[:2 * 256])
+
+
+def test_gemm_p8_refuses_unsuitable_launch():
+    P = _pkg()
+    with pytest.raises(P.XvError):
+        _run_case(2, 0, 3 * 128, 512, P8_PLAIN, relu=True, bn=True, seed=1, p8=1)          # rows not a multiple of 256
+    with pytest.raises(P.XvError):
+        _run_case(2, 0, 2 * 256, 384, P8_PLAIN, relu=True, bn=True, seed=1, p8=1)          # n_pad not a multiple of 256
+    with pytest.raises(P.XvError):
+        _run_case(3, 0, 2 * 256, 512, P8_PLAIN, relu=True, bn=True, seed=1, p8=1)          # three-pass arithmetic
+    with pytest.raises(P.XvError):
+        _run_case(2, 0, 2 * 256, 512, [(0, 96, 0, 96)], relu=True, bn=True, seed=1, p8=1)  # K not in whole 64-column tiles

@@ -44,7 +44,8 @@ def test_single_pass_per_tile_kernels_keep_two_workgroups_per_cu(resources):
 
 def test_persistent_kernels_fit_one_workgroup_per_cu(resources):
     # the stream-K and first-layer kernels run 512 threads per CU: two waves per SIMD, 256 registers
-    names = [k for k in resources if k.startswith("tdnn_gemm_kernel_sk<") or k.startswith("tdnn_first_kernel<")]
-    assert names
+    names = [k for k in resources if k.startswith("tdnn_gemm_kernel_sk<") or k.startswith("tdnn_first_kernel<") or
+             k.startswith("tdnn_gemm_kernel_p8<")]
+    assert names and sum(k.startswith("tdnn_gemm_kernel_p8<") for k in names) == 4, names
     for k in names:
         assert resources[k]["vgpr"] + resources[k]["agpr"] <= 256 and resources[k]["occ"] >= 2, (k, resources[k])
