@@ -279,6 +279,8 @@ def main():
                     help="default = what the command-line tools ship (XV_PREC_DEFAULT): the context is packed as fp16mx2 and, like "
                          "nnet3-xvector-compute does on its own table, calibrated on 64 chunks spread over the workload "
                          "(xv_ctx_calibrate, outside the timed region): fp16mx if its error against fp16x3 is within 7.5e-5 on the worst chunk, else fp16mx2")
+    ap.add_argument("--no-parity-sweep", action="store_true",
+                    help="skip the every-chunk comparison against fp16x3 (profiling runs: the last forward pass of the process is then the timed workload's)")
     ap.add_argument("--no-calibrate", action="store_true", help="with --precision default: keep fp16mx2 whatever the model")
     ap.add_argument("--topology", default="v2_xvector")
     ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
@@ -502,7 +504,7 @@ def main():
             "parity_chunks_vs_oracle": nchk,
             "kernels_ms_per_step": {l: ms / max(1, c) for (l, c, ms) in prof},
         }
-        if not frame_level and PRECISION_NOTES[args.precision] != 1:
+        if not frame_level and PRECISION_NOTES[args.precision] != 1 and not args.no_parity_sweep:
             # every chunk of the step against the three-pass arithmetic on the same inputs: worst chunk of max|d| / max|ref|
             cx = P.Context(model, device=local_rank, precision=P.PRECISIONS["fp16x3"])
             ox = torch.empty_like(out)
@@ -574,7 +576,10 @@ def main():
             oc = {}
             for key, kw in (("v5_cvector", dict(topology="v5_cvector", precision=args.precision, output_node=None, ragged=None)),
                             ("v3_senone_fp16_ragged", dict(topology="v3_multitask", precision="fp16",
-                                                           output_node="output_am.log-softmax", ragged=(200, 600)))):
+                                                           output_node="output_am.log-softmax", ragged=(200, 600))),
+                            # the same job in the parity-grade arithmetic nnet3-compute defaults to (config 5 names fp16)
+                            ("v3_senone_fp16x3_ragged", dict(topology="v3_multitask", precision="fp16x3",
+                                                             output_node="output_am.log-softmax", ragged=(200, 600)))):
                 try:
                     oc[key] = extra_config(torch, P, H, np, dev, local_rank, batch=B, steps=max(5, args.steps // 3), **kw)
                 except Exception as e:   # noqa: BLE001

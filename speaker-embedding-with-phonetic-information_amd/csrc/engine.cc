@@ -163,6 +163,9 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     b.out_dim = L.out_dim;
     b.k_pad = kp;
     b.n_pad = RoundUp(L.out_dim, kBN);
+    // wide frame-level layers in whole 256-column tiles (the senone head of prepare_nnet3_xconfig.sh:53-59: 3856 -> 4096 instead
+    // of 3968): tdnn_gemm_kernel_p8 can then run them, which is worth more than the 3 % of padding
+    if (!L.segment_level && b.n_pad > 1024 && (b.n_pad / kBN) % 2) b.n_pad += kBN;
     b.relu = L.relu;
     b.bn = L.bn || (f16 && split);   // scaled split-fp16 weights: the epilogue's scale step undoes the scaling
     b.log_softmax = L.log_softmax;

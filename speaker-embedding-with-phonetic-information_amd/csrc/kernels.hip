@@ -2332,6 +2332,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  const bool prio_mfma = !(a.p8 & 2), prio_load = (a.p8 & 4) != 0;   // issue priority of the two halves of a phase (XVEC_P8_FLAGS)
   auto mfma = [&](auto HH, auto PP, auto QQ, const int k) __attribute__((always_inline)) {
     constexpr int H = decltype(HH)::value, pw = decltype(PP)::value, qx = decltype(QQ)::value;   // weight fragment pw, frame fragment qx
     // accumulators tied in place (inline asm): left to itself hipcc rotates the 128 accumulator registers through copies
@@ -2349,6 +2350,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     const char* xs1 = smem + B * kP8Buf + xrd1;
     const char* ws0 = smem + B * kP8Buf + wrd0;
     const char* ws1 = smem + B * kP8Buf + wrd1;
+    if (prio_load) __builtin_amdgcn_s_setprio(1);
     if constexpr (P == 0) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -2391,7 +2393,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     constexpr int H = P >> 1;
     constexpr int Q0 = (P == 0 || P == 3) ? 0 : 2;
-    __builtin_amdgcn_s_setprio(1);
+    if (prio_load) __builtin_amdgcn_s_setprio(0);
+    if (prio_mfma) __builtin_amdgcn_s_setprio(1);
     if constexpr (MX && P < 2) {
       // 16 MFMAs and, one behind each, the 16 conversions of the fragments just read (e2m1 dword 2 * ODD + k of the block's
       // 4-bit fragments): left to hipcc twelve of them trail the MFMAs as one chain of dependent quarter-rate instructions
@@ -2453,7 +2456,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
         });
       });
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (prio_mfma) __builtin_amdgcn_s_setprio(0);
     barrier();
   };
   typedef std::integral_constant<int, 0> I0;
@@ -2814,6 +2817,14 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
   build_groups(&b);
   b.p8_ktiles = 0;
   for (int i = 0; i < b.ngrp; ++i) b.p8_ktiles += (b.grp[i].ksteps >> 1) * b.grp[i].nshift;
+  {
+    static int flags = -1;
+    if (flags < 0) {
+      const char* e = getenv("XVEC_P8_FLAGS");   // experiments: 1 = no priority for the MFMA part, 2 = priority for the LOAD part
+      flags = (e && *e) ? atoi(e) & 3 : 0;
+    }
+    b.p8 = 1 | (flags << 1);
+  }
   b.sk_mtiles = a.m_tiles >> 1;
   const int nt = a.n_tiles >> 1;
   int grid = device_cu_count() / 8 * 8;

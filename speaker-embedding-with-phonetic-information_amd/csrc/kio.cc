@@ -1,6 +1,8 @@
 // kio - Kaldi table / object I/O without Kaldi.  See kio.h for what it replaces and why.
 #include "kio.h"
 
+#include <fcntl.h>
+
 #include <sys/stat.h>
 
 #include <ctype.h>
@@ -43,6 +45,13 @@ void Input::Open(const std::string& rx_in) {
     f_ = popen(cmd.c_str(), "r");
     if (!f_) throw KioError("failed to start input pipe: " + cmd);
     is_pipe_ = true;
+    // a feature pipe (extract_xvectors_new.sh:79) carries gigabytes: the largest pipe buffer an unprivileged process may ask
+    // for (1 MiB by default) instead of 64 KiB - fewer hand-overs between the producer and this reader
+#ifdef F_SETPIPE_SZ
+    (void)fcntl(fileno(f_), F_SETPIPE_SZ, 1 << 20);
+#endif
+    // (stdio buffer left small: an fread of a whole matrix then goes from the pipe straight into its destination - one copy per
+    // byte - instead of through the FILE buffer)
     return;
   }
   // "file:offset"
@@ -339,6 +348,11 @@ static void ReadTextNumbers(Input& in, std::vector<float>* vals, std::vector<int
 template <typename T>
 static void ReadGrow(Input& in, std::vector<T>* v, size_t n) {
   constexpr size_t kBlock = (size_t)1 << 22;   // elements
+  if (v->size() >= n) {   // a recycled buffer that is large enough: nothing to allocate, nothing to zero-fill
+    v->resize(n);
+    in.Read(v->data(), n * sizeof(T));
+    return;
+  }
   v->clear();
   size_t done = 0;
   while (done < n) {

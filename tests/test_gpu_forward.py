@@ -150,7 +150,7 @@ def test_trained_like_model_needs_the_three_pass_mode(seed):
     assert errs["auto"] > 2e-5                                      # the fast kernels really ran
 
 
-@pytest.mark.parametrize("which", ["init_123", "trained_11", "trained_12", "v5_trained_11"])
+@pytest.mark.parametrize("which", ["init_123", "trained_11", "trained_12", "v5_trained_11", "v5_trained_12", "v5_trained_13"])
 def test_fp16mx2_is_model_independent(which):
     """XV_PREC_FP16MX2 corrects the fp16 rounding of the activations with a 4-bit residual plane (1.5 MFMA passes per
     product): on the heavy-tailed, BatchNorm-calibrated models where the one-plane modes land at 1.2 - 1.7e-4 it stays

@@ -28,7 +28,8 @@ def main():
     else:
         lens = np.full(64, int(targ))
     T = float(lens.mean())
-    extra = [a for a in sys.argv[3:] if a.startswith("--")]
+    extra = [a for a in sys.argv[3:] if a.startswith("--") and a != "--pipe"]
+    pipe = "--pipe" in sys.argv[3:]   # the recipes' form: the features arrive through a pipe (extract_xvectors_new.sh:79)
     wspec = ([a for a in sys.argv[3:] if not a.startswith("--")] or [None])[0]
     d = tempfile.mkdtemp(prefix="xvcli", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     net, line = H.synth_model("v2_xvector")
@@ -40,14 +41,14 @@ def main():
             kio.write_matrix(f, pool[i % 64])
     binp = os.path.join(ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
     cmd = [binp, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine"] + extra + [
-        os.path.join(d, "final.raw"), "ark:%s/feats.ark" % d, wspec or "ark,scp:%s/x.ark,%s/x.scp" % (d, d)]
+        os.path.join(d, "final.raw"), ("ark:cat %s/feats.ark |" if pipe else "ark:%s/feats.ark") % d, wspec or "ark,scp:%s/x.ark,%s/x.scp" % (d, d)]
     t0 = time.perf_counter()
     r = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE)
     wall = time.perf_counter() - t0
     err = r.stderr.decode()
     m = re.search(r"Time taken ([0-9.e+-]+)s", err)
     loop = float(m.group(1)) if m else None
-    print(json.dumps({"utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
+    print(json.dumps({"input": "pipe" if pipe else "file", "utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
                       "loop_s": loop, "loop_utt_per_s": n / loop if loop else None,
                       "feature_GB": n * T * 23 * 4 / 1e9, "frames_per_s": n * T / loop if loop else None, "tail": [l for l in err.strip().splitlines() if "stages" in l or "Done" in l or "WaitHost" in l]}))
     for fn in os.listdir(d):

@@ -45,6 +45,14 @@ __device__ __forceinline__ int swap_fields(int rho) {
   const int p = (rho >> 4) & 3, g = (rho >> 2) & 3, r = rho & 3;
   return ((p >> 1) << 5) | (g << 3) | ((p & 1) << 2) | r;
 }
+// accumulator forced into the AGPR half of the register file ("a" constraint)
+__device__ __forceinline__ void mfma16_acc(const s16x8& a, const s16x8& b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// accumulator tied in place in the VGPR half
+__device__ __forceinline__ void mfma16_vin(const s16x8& a, const s16x8& b, f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(512) void p8_kernel(const PArgs a) {
         const unsigned dst = st_lane + buf * kBuf + kXW + (kind == 3 ? kUnit : 0);
         glds16_sbase(src, woff[0], dst);
         glds16_sbase(src, woff[1], dst + 1024);
-      } else {
+      } else if (!(V & 32) || ij == 0) {   // bit 5: frames staged for the first offset of a chunk only (garbage results)
         const char* src = xb + (kind == 2 ? x128 : 0);
         const unsigned dst = st_lane + buf * kBuf + (kind == 2 ? kUnit : 0);
         glds16_sbase(src, xoff[0], dst);
@@ -208,7 +216,11 @@ __global__ __launch_bounds__(512) void p8_kernel(const PArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-          for (int q = Q0; q < Q0 + 2; ++q) acc[H][p][q] = mfma16(wf[p][k], xf[q][k], acc[H][p][q]);
+          for (int q = Q0; q < Q0 + 2; ++q) {
+            if constexpr (V & 64) mfma16_acc(wf[p][k], xf[q][k], acc[H][p][q]);
+            else if constexpr (V & 128) mfma16_vin(wf[p][k], xf[q][k], acc[H][p][q]);
+            else acc[H][p][q] = mfma16(wf[p][k], xf[q][k], acc[H][p][q]);
+          }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     barrier();
@@ -890,6 +902,9 @@ int main(int argc, char** argv) {
     check("E ", rune<0>(a, iters, s));   // one barrier per K tile
     if (argc > 3) {
       // ablations of the same launch (garbage results)
+      printf("   P (prio): accumulators in AGPRs %.4f (no reads %.4f, no dma %.4f), in VGPRs through asm %.4f (no reads %.4f)\n", run<64>(a, iters, s),
+             run<65>(a, iters, s), run<66>(a, iters, s), run<128>(a, iters, s), run<129>(a, iters, s));
+      printf("   P: frames once per chunk (garbage) %.4f, with prio %.4f\n", run<48>(a, iters, s), run<32>(a, iters, s));
       printf("   P: again %.4f  prio %.4f  no reads %.4f  no dma %.4f  no mfma %.4f  no stagger %.4f  mfma only %.4f  dma only %.4f  reads only %.4f  barriers only %.4f\n",
              run<16>(a, iters, s), run<0>(a, iters, s), run<17>(a, iters, s), run<18>(a, iters, s), run<20>(a, iters, s), run<24>(a, iters, s),
              run<19>(a, iters, s), run<21>(a, iters, s), run<22>(a, iters, s), run<23>(a, iters, s));
