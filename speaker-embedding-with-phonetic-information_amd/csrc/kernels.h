@@ -171,6 +171,20 @@ inline int PlanWalkSteps64(int ng, const WalkGroup* g, int* step_wcol, int cap, 
   return n;
 }
 
+// kPrecFp16Mx2 on tdnn_gemm_kernel_p8: first weight column of every 128-column step of ITS second walk - tiles of 256 columns
+// (two steps), group -> 256-column chunk -> offset.  Needs every group to have a multiple of eight 32-column steps.
+inline int PlanWalkLoSteps64(int ng, const WalkGroup* g, int* lo_wcol, int cap) {
+  int n = 0;
+  for (int i = 0; i < ng; ++i)
+    for (int c = 0; c < g[i].ksteps / 8; ++c)
+      for (int ij = 0; ij < g[i].nshift; ++ij)
+        for (int k = 0; k < 2; ++k) {
+          if (n < cap) lo_wcol[n] = g[i].wcol0 + ij * g[i].wstride + (2 * c + k) * 4 * kBK;
+          ++n;
+        }
+  return n;
+}
+
 // kPrecFp16Mx2: first weight column of every 128-column step of the second walk (same groups and order: chunk -> offset);
 // returns the number of steps.  Needs every group to have a multiple of four 32-column steps.
 inline int PlanWalkLoSteps(int ng, const WalkGroup* g, int* lo_wcol, int cap) {
@@ -258,6 +272,8 @@ struct GemmArgs {
   // formed in another order than the 32-column kernels') and, for kPrecFp16Mx, that w4 / w4_scale are packed in its walk order.
   int p8;
   int p8_ktiles;         // K tiles of an output tile (set by the launcher)
+  int p8_ktiles_lo;      // kPrecFp16Mx2: tiles of the second walk (256 4-bit columns each); w4b / w4b_scale are then in ITS order
+                         // (PlanWalkLoSteps64)
 };
 
 // Arms a (start, stop) event pair for the kernels of the NEXT launch_* call of this thread (profiling; see kernels.hip).

@@ -2138,8 +2138,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
 //  * 8 waves as 4 (frames) x 2 (columns): a wave owns 64 frames x 128 columns = two 64 x 64 blocks side by side, the
 //    accumulator layout of the wide stream-K kernel, so the epilogues are shared.  Wave group = column half (waves 0-3 / 4-7,
 //    one of each per SIMD).
-//  * LDS: two K-tile buffers of 64 KiB, each an activation tile (256 frames x 128 B) and a weight tile (256 rows x 128 B,
-//    rows ordered [64-column block h][column half][64 rows]): rows of 128 bytes = whole cache lines per row piece for the
+//  * LDS: two K-tile buffers, each an activation tile (256 frames x 128 B) and a weight tile (256 rows x 128 B, rows
+//    ordered [64-column block h][column half][64 rows]), laid out [frames 0 | frames 1 | weights 0 | weights 1]: rows of 128 bytes = whole cache lines per row piece for the
 //    LDS-DMA (the 64-byte row pieces of the 32-column K steps are half lines: twice the requests per byte).  16-byte chunks
 //    XOR-swizzled with three row bits (chunk ^ ((row >> 1) & 7)): every ds_read_b128 lane group touches 16 distinct slots
 //    (SQ_LDS_BANK_CONFLICT = 0, profiles/r04_probe_p8_pmc.txt); applied to the per-lane SOURCE address of the DMA.
@@ -2167,12 +2167,39 @@ constexpr int kP8Buf = 65536, kP8XW = 32768, kP8Unit = 16384;
 constexpr int kP8W4 = 2 * kP8Buf;       // 4-bit residual tile of the current block: 256 rows x 64 B
 constexpr int kP8SC = kP8W4 + 16384;    // its scales: two 128-column tiles x 512 B
 constexpr int kP8PB = kP8SC + 1024;     // epilogue parameters: [part & 1][column half][bias | scale | offset][128 floats]
-constexpr int kP8Lds = kP8PB + 2 * 3072;
+constexpr int kP8WSL = kP8PB + 2 * 3072;   // kPrecFp16Mx2, second walk: weight scales [tile & 1][128-column half of the K tile][128-column tile][512]
+constexpr int kP8XSL = kP8WSL + 2 * 2048;  // and the scales of the activation residuals, [tile & 1][frame][4]: one byte per 64 columns
+constexpr int kP8Lds = kP8XSL + 2 * 1024;
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the counted waits of tdnn_gemm_kernel_p8: what is in flight behind the data a wait is
+// for depends on the walk - 4-bit tiles, scale pieces, the tail of a part - and is counted as it is issued)
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+  }
+}
 
 template <int PREC, int EPI>
 __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
-  static_assert(PREC == kPrecFp16 || PREC == kPrecFp16Mx, "single-pass fp16 and the 1.25-pass arithmetic");
+  static_assert(PREC == kPrecFp16 || PREC == kPrecFp16Mx || PREC == kPrecFp16Mx2, "single-pass fp16, the 1.25- and the 1.5-pass arithmetic");
   constexpr bool MX = PrecMx(PREC);
+  constexpr bool MX2 = PrecMx2(PREC);
   constexpr bool SWAP = (EPI != kEpiStats);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -2183,25 +2210,40 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   const int bid = blockIdx.x;
   const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
 
-  // ---- this workgroup's share of the K tiles (the partition of tdnn_gemm_kernel_sk, in units of K-tile pairs) ----------
-  const int S = a.p8_ktiles;                   // K tiles of an output tile (even)
-  const int SQ = S >> 1;
+  // ---- this workgroup's share of the K tiles (the partition of tdnn_gemm_kernel_sk) ----------------------------------------
+  // kPrecFp16Mx2: behind the S tiles of 64 fp16 columns an output tile's walk goes on with S_lo tiles of 256 4-bit columns
+  // (128 B per row: the same LDS image, DMA and fragment reads) over the activations' residual planes and the 4-bit image of the
+  // weights.  Cuts: at even tiles inside the first walk (a block of the residual product is a tile pair), anywhere in the second.
+  const int S = a.p8_ktiles;                   // K tiles of the first walk (even)
+  const int S_lo = MX2 ? a.p8_ktiles_lo : 0;
+  const int ST = S + S_lo;
+  const int NG = a.ngrp + (MX2 ? a.ngrp_lo : 0);
   const int G8 = gridDim.x >> 3;
   const int xcd = bid & 7, jb = bid >> 3;
   const int L = a.sk_lanes, NT = a.n_tiles >> 1, cpl = NT / L, Ng = G8 / L;
   const int col_lane = jb % L, grp_j = jb / L;
   const int tb0 = (int)((long)a.sk_mtiles * xcd / 8), tb1 = (int)((long)a.sk_mtiles * (xcd + 1) / 8);
-  const long steps_b = (long)(tb1 - tb0) * cpl * SQ;
-  const long s0 = steps_b * grp_j / Ng * 2, s1 = steps_b * (grp_j + 1) / Ng * 2;
-  const int k_head = (int)(s0 % S), k_tail = (int)(s1 % S);
-  const int t_first = (int)((s0 + S - 1) / S), t_end = (int)(s1 / S);
+  long s0, s1;
+  {
+    const long all = (long)(tb1 - tb0) * cpl * ST;
+    auto cut = [&](long g) __attribute__((always_inline)) {
+      const long s = all * g / Ng;
+      int k = (int)(s % ST);
+      if (k < S) k &= ~1;
+      return s - s % ST + k;
+    };
+    s0 = cut(grp_j);
+    s1 = cut(grp_j + 1);
+  }
+  const int k_head = (int)(s0 % ST), k_tail = (int)(s1 % ST);
+  const int t_first = (int)((s0 + ST - 1) / ST), t_end = (int)(s1 / ST);
   // (the launcher sizes the grid so that every share is at least one whole tile: a head and a tail never meet in one tile)
   const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
   if (s1 <= s0) return;   // an XCD block without row tiles (launches of fewer than eight of them)
 
   // ---- staging geometry: a wave stages rows wave * 16 + piece * 8 + (lane >> 3) of every 128-row unit --------------------
   int st_ru[2], st_c[2];
-  unsigned woff[2];
+  unsigned woff[2];   // (the second walk's 4-bit weight image is stored with the row pitch of the fp16 plane: the same offsets)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     st_ru[j] = wave * 16 + j * 8 + (lane >> 3);
@@ -2225,36 +2267,38 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   // ---- per-part state ----------------------------------------------------------------------------------------------------
   int m0 = 0, n0 = 0, nt = 0;
   int kind = 0, n_tiles_part = 0, kb_part = 0;
-  // issue side: position in the walk (group, chunk, offset) and the addresses of its K tile
-  int ig = 0, ic = 0, ij = 0;
+  // issue side: position in the walk (tile index, group, chunk, offset) and the addresses of its K tile
+  int it = 0, ig = 0, ic = 0, ij = 0;
   Grp gi = a.grp[0];
   const char* xb = nullptr;
   const char* wb = nullptr;
   const char* wtile = nullptr;          // weight row n0
-  const uint8_t* wtile_4 = nullptr;
-  const uint8_t* wtile_s = nullptr;
   unsigned xoff[2] = {0u, 0u};
-  long x_next = 0, x_wrap = 0, w_next = 0, w_wrap = 0, x128 = 0;
-  const long w64 = (long)a.ldw * 128;
+  int x_next = 0, x_wrap = 0, w_next = 0, w_wrap = 0;   // byte steps of the walk (they fit 32 bits; fewer scalar registers)
   auto bind_group = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) xoff[j] = (unsigned)(st_ru[j] * gi.ld + st_c[j] * 8) * 2u;
     xb = (const char*)gi.hi + ((long)(m0 + gi.shift0 + ij * gi.dstep) * gi.ld + ic * 64) * 2;
-    wb = wtile + (long)(gi.wcol0 + ij * gi.wstride + ic * 64) * 2;
-    x_next = (long)gi.dstep * gi.ld * 2;
-    x_wrap = 128 - (long)(gi.nshift - 1) * gi.dstep * gi.ld * 2;
-    w_next = (long)gi.wstride * 2;
-    w_wrap = 128 - (long)(gi.nshift - 1) * gi.wstride * 2;
-    x128 = (long)gi.ld * 256;
+    x_next = gi.dstep * gi.ld * 2;
+    x_wrap = 128 - (gi.nshift - 1) * gi.dstep * gi.ld * 2;
+    if (MX2 && it >= S) {   // second walk: the weight tiles follow each other in walk order
+      wb = (const char*)a.w4b + (long)n0 * a.ldw * 2 + (long)(it - S) * 128;   // (row pitch of the fp16 plane: GemmArgs::ldw4b)
+      w_next = w_wrap = 128;
+    } else {
+      wb = wtile + (long)(gi.wcol0 + ij * gi.wstride + ic * 64) * 2;
+      w_next = gi.wstride * 2;
+      w_wrap = 128 - (gi.nshift - 1) * gi.wstride * 2;
+    }
   };
   auto adv = [&]() __attribute__((always_inline)) {
+    ++it;
     if (++ij == gi.nshift) {
       ij = 0;
       xb += x_wrap;
       wb += w_wrap;
       if (++ic == (gi.ksteps >> 1)) {
         ic = 0;
-        if (++ig < a.ngrp) {
+        if (++ig < NG) {
           gi = a.grp[ig];
           bind_group();
         }
@@ -2267,13 +2311,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   // staging units: 0 = weights h = 0, 1 = frames 0..127, 2 = frames 128..255, 3 = weights h = 1
   auto issue = [&](const int unit, const int buf) __attribute__((always_inline)) {
     if (unit == 0 || unit == 3) {
-      const char* src = wb + (unit == 3 ? w64 : 0);
-      const unsigned dst = st_lane + buf * kP8Buf + kP8XW + (unit == 3 ? kP8Unit : 0);
+      const unsigned dst = st_lane + 2 * kP8XW + buf * kP8XW + (unit == 3 ? kP8Unit : 0);
+      const char* src = wb + (unit == 3 ? (long)a.ldw * 128 : 0);
       glds16_sbase(src, woff[0], dst);
       glds16_sbase(src, woff[1], dst + 1024);
     } else {
-      const char* src = xb + (unit == 2 ? x128 : 0);
-      const unsigned dst = st_lane + buf * kP8Buf + (unit == 2 ? kP8Unit : 0);
+      const char* src = xb + (unit == 2 ? (long)gi.ld * 256 : 0);
+      const unsigned dst = st_lane + buf * kP8XW + (unit == 2 ? kP8Unit : 0);
       glds16_sbase(src, xoff[0], dst);
       glds16_sbase(src, xoff[1], dst + 1024);
     }
@@ -2283,24 +2327,38 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   auto issue_w4 = [&](const int blk) __attribute__((always_inline)) {
     if constexpr (MX) {
       const unsigned d4 = lds_base + kP8W4 + wave * 2048;
-      glds16_sbase(wtile_4 + blk * 64, woff4[0], d4);
-      glds16_sbase(wtile_4 + blk * 64, woff4[1], d4 + 1024);
+      const uint8_t* w4t = a.w4 + (long)n0 * a.ldw4 + blk * 64;
+      glds16_sbase(w4t, woff4[0], d4);
+      glds16_sbase(w4t, woff4[1], d4 + 1024);
       const int pc = wave & 3;   // piece: 128-column tile pc >> 1, half pc & 1
-      glds4_sbase(wtile_s + ((long)(pc >> 1) * SQ + blk) * 512 + (pc & 1) * 256, (unsigned)lane * 4u,
+      glds4_sbase(a.w4_scale + ((long)(nt * 2 + (pc >> 1)) * (S >> 1) + blk) * 512 + (pc & 1) * 256, (unsigned)lane * 4u,
                   lds_base + kP8SC + pc * 256);
+    }
+  };
+  // kPrecFp16Mx2: the scales of the second-walk tile the issue side stands on, into scale buffer sb: the weights' (2 KiB: two
+  // 128-column steps x two 128-column tiles x 512 B, one 256-byte piece per wave) and the activation residuals' (one dword per
+  // frame = its four 64-column blocks of the tile; waves 4-7 repeat the pieces of waves 0-3).  Two DMA instructions per wave.
+  auto issue_scales = [&](const int sb) __attribute__((always_inline)) {
+    if constexpr (MX2) {
+      const int t_lo = it - S;
+      const int t128 = (wave >> 1) & 1, ks = wave >> 2, half = wave & 1;
+      glds4_sbase(a.w4b_scale + ((long)(nt * 2 + t128) * (2 * S_lo) + 2 * t_lo + ks) * 512 + half * 256, (unsigned)lane * 4u,
+                  lds_base + kP8WSL + sb * 2048 + ks * 1024 + t128 * 512 + half * 256);
+      const uint8_t* xs = gi.lo4s + (long)(m0 + gi.shift0 + ij * gi.dstep + (wave & 3) * 64) * gi.ld4s + ic * 4;
+      glds4_sbase(xs, (unsigned)(lane * gi.ld4s), lds_base + kP8XSL + sb * 1024 + (wave & 3) * 256);
     }
   };
 
   // ---- fragment read geometry ------------------------------------------------------------------------------------------------
   const int sw = (fr_g ^ ((fr_i >> 1) & 7)) * 16;
   const int xrd0 = (wm * 64 + fr_i) * 128 + sw, xrd1 = xrd0 ^ 64;
-  const int wrd0 = kP8XW + (wn * 64 + fr_i) * 128 + sw, wrd1 = wrd0 ^ 64;
+  const int wrd0 = 2 * kP8XW + (wn * 64 + fr_i) * 128 + sw, wrd1 = wrd0 ^ 64;
   const int w4rd = kP8W4 + (wn * 64 + fr_i) * 64 + (fr_g ^ ((fr_i >> 1) & 3)) * 16;   // + h * 8192 + p * 1024
 
   // kPrecFp16Mx: scales of the 4-bit copies of the frame fragments (one power of two per 16-row group of the output rows,
   // from the group maxima of the source plane: see tdnn_gemm_kernel_sk)
-  int xs_b = 0;
-  float xs_f[MX ? 4 : 1];
+  int xs_b = 0;             // 2^(e - 2) as E8M0 bytes, fragment f in byte f: the scale operand of the block-scaled MFMAs
+  float xs_f[MX ? 4 : 1];   // the same as floats: the divisor of the conversions
   typedef __attribute__((ext_vector_type(4))) unsigned xs_uvec;
   auto xs_request = [&](const unsigned* gmax, xs_uvec& g) __attribute__((always_inline)) {
     if constexpr (MX) {
@@ -2326,13 +2384,14 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   f32x4 acc[2][4][4];
   s16x8 xf[4][2], wf[4][2];
   i32x4 x4[MX ? 4 : 1];
+  int ws_lo[MX2 ? 2 : 1], xs_lo[MX2 ? 2 : 1];   // second walk: scale words, [128-column half]: the weights' of the phase's 64-row block, the frames' of the tile
 
   auto barrier = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  const bool prio_mfma = !(a.p8 & 2), prio_load = (a.p8 & 4) != 0;   // issue priority of the two halves of a phase (XVEC_P8_FLAGS)
+  constexpr bool prio_mfma = true, prio_load = false;   // issue priority of the two halves of a phase (either way: +-1 %, measured)
   auto mfma = [&](auto HH, auto PP, auto QQ, const int k) __attribute__((always_inline)) {
     constexpr int H = decltype(HH)::value, pw = decltype(PP)::value, qx = decltype(QQ)::value;   // weight fragment pw, frame fragment qx
     // accumulators tied in place (inline asm): left to itself hipcc rotates the 128 accumulator registers through copies
@@ -2340,16 +2399,24 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     if constexpr (SWAP) mfma16_f16_inplace(wf[pw][k], xf[qx][k], acc[H][pw][qx]);
     else mfma16_f16_inplace(xf[qx][k], wf[pw][k], acc[H][qx][pw]);
   };
+  // DMA instructions issued in this phase (c0) and in the three before it: what may still be in flight when a wait is for the
+  // data of an older phase.  WAIT = 1 (end of LOAD(t,1)): everything issued up to phase (t-1,1) has landed - the weights h = 1 of
+  // tile t, the 4-bit tile of a block that began in t-1; WAIT = 3 (end of LOAD(t,3)): everything up to phase (t,0) - tile t+1's
+  // phase-0 data (and the second walk's scales, issued a tile earlier).  Never vmcnt(0) inside a part in the steady state.
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   // One phase.  P = phase, B = buffer of the tile, ODD = second tile of its pair (the 4-bit conversions go to dwords 2, 3; the
-  // block-scaled MFMAs follow its last phase), WK = vmcnt of the wait at the end of the LOAD part (-1: none); unit / ibuf =
-  // what the LOAD part stages (unit < 0: nothing), w4_blk >= 0: also the 4-bit tile of that block.
-  auto phase = [&](auto PP, auto BB, auto OO, auto WW, auto WL, const int unit, const int ibuf, const int w4_blk, const bool more) __attribute__((always_inline)) {
+  // block-scaled MFMAs follow its last phase), LO = a tile of the second walk; unit / ibuf = what the LOAD part stages (unit < 0:
+  // nothing), w4_blk >= 0: also the 4-bit tile of that block, sc_buf >= 0: also the second-walk scales of the issue side's tile.
+  auto phase = [&](auto PP, auto BB, auto OO, auto LL, const int unit, const int ibuf, const int w4_blk, const int sc_buf,
+                   const bool steady) __attribute__((always_inline)) {
     constexpr int P = decltype(PP)::value, B = decltype(BB)::value, ODD = decltype(OO)::value;
-    constexpr int WK = decltype(WW)::value, WKL = decltype(WL)::value;   // vmcnt of the wait: steady state / last pair of a part
-    const char* xs0 = smem + B * kP8Buf + xrd0;
-    const char* xs1 = smem + B * kP8Buf + xrd1;
-    const char* ws0 = smem + B * kP8Buf + wrd0;
-    const char* ws1 = smem + B * kP8Buf + wrd1;
+    constexpr bool LO = decltype(LL)::value != 0;
+    // LDS: [frames, buffer 0 | frames, buffer 1 | weights, buffer 0 | weights, buffer 1], 32 KiB each: every fragment read is one of
+    // four per-lane bases + a 16-bit immediate
+    const char* xs0 = smem + xrd0 + B * kP8XW;
+    const char* xs1 = smem + xrd1 + B * kP8XW;
+    const char* ws0 = smem + wrd0 + B * kP8XW;
+    const char* ws1 = smem + wrd1 + B * kP8XW;
     if (prio_load) __builtin_amdgcn_s_setprio(1);
     if constexpr (P == 0) {
 #pragma unroll
@@ -2361,6 +2428,18 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       for (int q = 0; q < 2; ++q) {
         xf[q][0] = *(const s16x8*)(xs0 + q * 2048);
         xf[q][1] = *(const s16x8*)(xs1 + q * 2048);
+      }
+      if constexpr (MX2 && LO) {
+        // the tile's scales into registers for its four phases: weights - one dword per 64-row block = the bytes of its four
+        // fragments for this lane's (row, lane group); activations - byte 2 k + (lane group >> 1) of a frame's dword
+        const uint8_t* xsl = (const uint8_t*)smem + kP8XSL + B * 1024 + (wm * 64 + fr_i) * 4 + (fr_g >> 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          int x = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x |= (int)xsl[q * 64 + 2 * k] << (8 * q);
+          xs_lo[k] = x;
+        }
       }
     } else if constexpr (P == 1) {
 #pragma unroll
@@ -2375,18 +2454,39 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
         wf[p][1] = *(const s16x8*)(ws1 + kP8Unit + p * 2048);
       }
     }
-    if (unit >= 0) issue(unit, ibuf);
-    if (w4_blk >= 0) issue_w4(w4_blk);
+    if constexpr (MX2 && LO && (P == 0 || P == 2)) {
+      // the weights' scale words of the 64-row block h the next two phases multiply: one dword = the bytes of its four fragments
+      const char* wsl = smem + kP8WSL + B * 2048 + wn * 512 + (P >> 1) * 256 + (fr_i * 4 + fr_g) * 4;
+      ws_lo[0] = *(const int*)(wsl);
+      ws_lo[1] = *(const int*)(wsl + 1024);
+    }
+    c3 = c2;
+    c2 = c1;
+    c1 = c0;
+    c0 = 0;
+    if (unit >= 0) {
+      issue(unit, ibuf);
+      c0 += 2;
+    }
+    if (w4_blk >= 0) {
+      issue_w4(w4_blk);
+      c0 += 3;
+    }
+    if (sc_buf >= 0) {
+      issue_scales(sc_buf);
+      c0 += 2;
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (WK >= 0) {
-      if constexpr (WKL >= 0 && WKL != WK) {
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WK) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WKL < 0 ? 0 : WKL) : "memory");
-      } else if constexpr (WKL < 0) {
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WK) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WK) : "memory");
-      }
+    // steady state (every phase of this pair and of the one before it staged its unit): the counts are constants - 2 per phase,
+    // + 3 in phase 1 of a block's first tile (4-bit tile and scales); the tail of a part and the second walk count as they go
+    constexpr int E1 = (MX && !LO && !ODD) ? 3 : 0;
+    if constexpr (P == 1) {
+      if (!MX2 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + E1) : "memory");
+      else wait_vmcnt_n(c0 + c1 + c2 + c3);
+    }
+    if constexpr (P == 3) {
+      if (!MX2 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + E1) : "memory");
+      else wait_vmcnt_n(c0 + c1 + c2);
     }
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the fragments are in (the MFMAs are inline asm: their waits are ours)
@@ -2395,7 +2495,19 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     constexpr int Q0 = (P == 0 || P == 3) ? 0 : 2;
     if (prio_load) __builtin_amdgcn_s_setprio(0);
     if (prio_mfma) __builtin_amdgcn_s_setprio(1);
-    if constexpr (MX && P < 2) {
+    if constexpr (MX2 && LO) {
+      // 16 block-scaled MFMAs: the fragments just read ARE the 4-bit operands (16 bytes per lane = 32 columns of a 128-column half)
+      asm volatile("s_nop 4" ::: "memory");   // the scale words are assembled by VALU instructions
+      static_for<0, 2>([&](auto K) {
+        static_for<0, 4>([&](auto PW) {
+          static_for<Q0, Q0 + 2>([&](auto QX) {
+            constexpr int k = decltype(K)::value, pw = decltype(PW)::value, qx = decltype(QX)::value;
+            if constexpr (SWAP) mfma_mx4_inplace<pw, qx>(wf[pw][k], xf[qx][k], acc[H][pw][qx], ws_lo[k], xs_lo[k]);
+            else mfma_mx4_inplace<qx, pw>(xf[qx][k], wf[pw][k], acc[H][qx][pw], xs_lo[k], ws_lo[k]);
+          });
+        });
+      });
+    } else if constexpr (MX && P < 2) {
       // 16 MFMAs and, one behind each, the 16 conversions of the fragments just read (e2m1 dword 2 * ODD + k of the block's
       // 4-bit fragments): left to hipcc twelve of them trail the MFMAs as one chain of dependent quarter-rate instructions
       // (every fragment's four conversions write bytes of one register), ~200 cycles of an MFMA part in which the matrix pipe
@@ -2406,10 +2518,18 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
         mfma(std::integral_constant<int, H>{}, std::integral_constant<int, mp>{}, std::integral_constant<int, mq>{}, mk);
         constexpr int cq = Q0 + (i & 1), ck = (i >> 1) & 1, cj = i >> 2;          // conversion i: chain (cq, ck), its dword cj
         const u32x4 u = __builtin_bit_cast(u32x4, xf[cq][ck]);
-        int d = x4[cq][2 * ODD + ck];
-        asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,%3,%4]"
-                     : "+v"(d)
-                     : "v"(u[cj]), "v"(xs_f[cq]), "n"(cj & 1), "n"(cj >> 1));
+        const float xsc = xs_f[cq];
+        int d;
+        if constexpr (cj == 0) {
+          // the first of a dword's four conversions DEFINES the register (the other three bytes follow): the 4-bit fragments are
+          // then dead between blocks and through the second walk instead of 16 registers carried around the loop
+          asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2" : "=v"(d) : "v"(u[0]), "v"(xsc));
+        } else {
+          d = x4[cq][2 * ODD + ck];
+          asm volatile("v_cvt_scalef32_pk_fp4_f16 %0, %1, %2 op_sel:[0,0,%3,%4]"
+                       : "+v"(d)
+                       : "v"(u[cj]), "v"(xsc), "n"(cj & 1), "n"(cj >> 1));
+        }
         x4[cq][2 * ODD + ck] = d;
       });
     } else if constexpr (MX && ODD && P == 3) {
@@ -2463,15 +2583,32 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   typedef std::integral_constant<int, 1> I1;
   typedef std::integral_constant<int, 2> I2;
   typedef std::integral_constant<int, 3> I3;
-  typedef std::integral_constant<int, -1> IN;
-  constexpr int E = MX ? 3 : 0;   // DMA instructions of issue_w4 per wave
+  // The eight phases of a tile pair (tile t in buffer 0, t + 1 in buffer 1) of the first (LL = 0) or the second walk.  n_left =
+  // tiles of the part from t on: what a phase stages exists only while the part goes on - (t,0) (t,1): tile t+1's second half,
+  // (t,2) (t,3): tile t+2's first half (+ its scales, second walk), and so on; a part's last pair may hold one tile only.
+  auto pair = [&](auto LL, const int n_left, const int blk) __attribute__((always_inline)) {
+    constexpr int LOW = decltype(LL)::value;
+    const bool t1 = n_left > 1, t2 = n_left > 2, t3 = n_left > 3;
+    phase(I0{}, I0{}, I0{}, LL, t1 ? 2 : -1, 1, -1, -1, t3);
+    phase(I1{}, I0{}, I0{}, LL, t1 ? 3 : -1, 1, (MX && !LOW) ? blk : -1, -1, t3);
+    if (t2) adv();
+    phase(I2{}, I0{}, I0{}, LL, t2 ? 0 : -1, 0, -1, (MX2 && t2 && it >= S) ? 0 : -1, t3);
+    phase(I3{}, I0{}, I0{}, LL, t2 ? 1 : -1, 0, -1, -1, t3);
+    if (t1) {
+      phase(I0{}, I1{}, I1{}, LL, t2 ? 2 : -1, 0, -1, -1, t3);
+      phase(I1{}, I1{}, I1{}, LL, t2 ? 3 : -1, 0, -1, -1, t3);
+      if (t3) adv();
+      phase(I2{}, I1{}, I1{}, LL, t3 ? 0 : -1, 1, -1, (MX2 && t3 && it >= S) ? 1 : -1, t3);
+      phase(I3{}, I1{}, I1{}, LL, t3 ? 1 : -1, 1, -1, -1, t3);
+    }
+  };
 
-  // position of K tile k in the walk
+  // position of K tile k in the walk (first-walk groups, then the second walk's)
   auto seek = [&](int k, int& g, int& c, int& j) __attribute__((always_inline)) {
     g = 0;
     for (;;) {
       const int n = (a.grp[g].ksteps >> 1) * a.grp[g].nshift;
-      if (k < n || g + 1 >= a.ngrp) break;
+      if (k < n || g + 1 >= NG) break;
       k -= n;
       ++g;
     }
@@ -2488,9 +2625,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     } else {
       const int w = part - (k_tail ? 1 : 0);
       if (w < t_end - t_first) {
-        tile = t_first + w; kb = 0; ke = S; kind = 0;
+        tile = t_first + w; kb = 0; ke = ST; kind = 0;
       } else {
-        tile = t_first - 1; kb = k_head; ke = S; kind = 2;
+        tile = t_first - 1; kb = k_head; ke = ST; kind = 2;
       }
     }
     const int mt = tb0 + tile / cpl;
@@ -2498,6 +2635,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     m0 = mt * 256;
     n0 = nt * 256;
     wtile = (const char*)a.w_hi + (long)n0 * a.ldw * 2;
+    it = kb;
     seek(kb, ig, ic, ij);
     gi = a.grp[ig];
     bind_group();
@@ -2519,19 +2657,22 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       }
     }
     xs_uvec xg;
+    const bool first_walk = kb < S;
     if constexpr (MX) {
-      wtile_4 = a.w4 + (long)n0 * a.ldw4;
-      wtile_s = a.w4_scale + (long)nt * 2 * SQ * 512;
-      xs_request(gi.gmax, xg);
+      if (first_walk) xs_request(gi.gmax, xg);
     }
     issue(0, 0);
     issue(1, 0);
     issue(2, 0);
     issue(3, 0);
-    adv();
-    issue(0, 1);
-    issue(1, 1);
-    xs_finish(xg);
+    if (MX2 && it >= S) issue_scales(0);
+    if (n_tiles_part > 1) {
+      adv();
+      issue(0, 1);
+      issue(1, 1);
+      if (MX2 && it >= S) issue_scales(1);
+    }
+    if (MX && first_walk) xs_finish(xg);
   };
 
   open_part(0);
@@ -2573,35 +2714,27 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    c0 = c1 = c2 = c3 = 0;
     if (wn == 1) barrier();
-    const int pairs = n_tiles_part >> 1;
+    const int ntp = n_tiles_part;
 #pragma nounroll
-    for (int pr = 0; pr < pairs; ++pr) {
-      if constexpr (MX) {
-        if (r_left == 0) {   // the walk enters another source: its group maxima (a pair never straddles two groups)
-          ++rg;
-          r_left = (a.grp[rg].ksteps >> 1) * a.grp[rg].nshift;
-          xs_uvec xg;
-          xs_request(a.grp[rg].gmax, xg);
-          xs_finish(xg);
+    for (int t = 0; t < ntp; t += 2) {
+      const bool lo = MX2 && kb_part + t >= S;
+      if (!lo) {
+        if constexpr (MX) {
+          if (r_left == 0) {   // the walk enters another source: its group maxima (a pair never straddles two groups)
+            ++rg;
+            r_left = (a.grp[rg].ksteps >> 1) * a.grp[rg].nshift;
+            xs_uvec xg;
+            xs_request(a.grp[rg].gmax, xg);
+            xs_finish(xg);
+          }
+          r_left -= 2;
         }
-        r_left -= 2;
+        pair(I0{}, ntp - t, (kb_part + t) >> 1);
+      } else {
+        if constexpr (MX2) pair(I1{}, ntp - t, 0);
       }
-      const int blk = (kb_part >> 1) + pr;
-      // tile t (buffer 0), tile t + 1 (buffer 1).  In the last pair of a part only the second tile's remaining units are
-      // staged; fewer instructions are then in flight behind the ones a wait is for, so its counts are smaller.  Waits: see
-      // the header (with the 4-bit tile: E more instructions in flight)
-      const bool more = pr + 1 < pairs;
-      phase(I0{}, I0{}, I0{}, IN{}, IN{}, 2, 1, -1, more);
-      phase(I1{}, I0{}, I0{}, std::integral_constant<int, 8 + E>{}, std::integral_constant<int, 8 + E>{}, 3, 1, MX ? blk : -1, more);
-      if (more) adv();
-      phase(I2{}, I0{}, I0{}, IN{}, IN{}, more ? 0 : -1, 0, -1, more);
-      phase(I3{}, I0{}, I0{}, std::integral_constant<int, 6 + E>{}, std::integral_constant<int, 2 + E>{}, more ? 1 : -1, 0, -1, more);
-      phase(I0{}, I1{}, I1{}, IN{}, IN{}, more ? 2 : -1, 0, -1, more);
-      phase(I1{}, I1{}, I1{}, std::integral_constant<int, 8>{}, I0{}, more ? 3 : -1, 0, -1, more);
-      if (more) adv();
-      phase(I2{}, I1{}, I1{}, IN{}, IN{}, more ? 0 : -1, 1, -1, more);
-      phase(I3{}, I1{}, I1{}, std::integral_constant<int, 6>{}, IN{}, more ? 1 : -1, 1, -1, more);
     }
     if (wn == 0) barrier();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
@@ -2788,18 +2921,25 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 // 128-column blocks for kPrecFp16Mx), an even number of K tiles, and for kPrecFp16Mx the residual plane in ITS walk order
 // (GemmArgs::p8 is the caller's statement that w4 / w4_scale are in that order)
 bool gemm_p8_applicable(const GemmArgs& a, int precision) {
-  if (precision != kPrecFp16 && precision != kPrecFp16Mx) return false;
+  if (precision != kPrecFp16 && precision != kPrecFp16Mx) return false;   // (kPrecFp16Mx2: see launch_one)
   if ((a.m_tiles & 1) || (a.n_tiles & 1) || a.ksplit > 1) return false;
+  const bool mx = precision != kPrecFp16, mx2 = precision == kPrecFp16Mx2;
   GemmArgs b = a;
   build_groups(&b);
   int t = 0;
   for (int i = 0; i < b.ngrp; ++i) {
-    if (b.grp[i].ksteps % (precision == kPrecFp16Mx ? 4 : 2) || b.grp[i].ld % 64) return false;
-    if (precision == kPrecFp16Mx && !b.grp[i].gmax) return false;
+    // whole K tiles: 64 columns; whole blocks of the residual product: 128; whole tiles of the second walk: 256
+    if (b.grp[i].ksteps % (mx2 ? 8 : mx ? 4 : 2) || b.grp[i].ld % (mx2 ? 256 : 64)) return false;
+    if (mx && !b.grp[i].gmax) return false;
     t += (b.grp[i].ksteps >> 1) * b.grp[i].nshift;
   }
   if (t < 2 || (t & 1)) return false;
-  if (precision == kPrecFp16Mx && (!a.w4 || !a.w4_scale || a.ldw4 <= 0)) return false;
+  if (mx && (!a.w4 || !a.w4_scale || a.ldw4 <= 0)) return false;
+  if (mx2) {
+    if (!a.w4b || !a.w4b_scale || a.ldw4b <= 0) return false;
+    for (int j = 0; j < a.nseg; ++j)
+      if (!a.seg[j].lo4 || !a.seg[j].lo4s) return false;
+  }
   return true;
 }
 
@@ -2817,6 +2957,11 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
   build_groups(&b);
   b.p8_ktiles = 0;
   for (int i = 0; i < b.ngrp; ++i) b.p8_ktiles += (b.grp[i].ksteps >> 1) * b.grp[i].nshift;
+  b.p8_ktiles_lo = 0;
+  if constexpr (PrecMx2(PREC)) {
+    build_lo_groups(&b);   // second walk: the 4-bit planes, steps of 128 columns (a tile = two of them)
+    for (int i = 0; i < b.ngrp_lo; ++i) b.p8_ktiles_lo += (b.grp[b.ngrp + i].ksteps >> 1) * b.grp[b.ngrp + i].nshift;
+  }
   {
     static int flags = -1;
     if (flags < 0) {
@@ -2883,6 +3028,10 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (a.p8) {   // the caller packed / chose this layer for the 64-column K walk: no other kernel accumulates in that order
+    // (kPrecFp16Mx2: the kernel's second-walk path is written - tiles of 256 4-bit columns through the same phases - but hipcc
+    // (ROCm 7.2) keeps 28 of its 32 accumulator fragments in scratch for that instantiation, 520-660 bytes per lane whatever
+    // is taken out of it; until that is understood the 1.5-pass launches stay on tdnn_gemm_kernel_sk, and this instantiation is
+    // not built)
     if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx) && (EPI == kEpiAct || EPI == kEpiStats)) return launch_one_p8<PREC, EPI>(a, s);
     else return hipErrorInvalidValue;
   }
