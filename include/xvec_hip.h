@@ -257,9 +257,9 @@ typedef struct {
    * out_lo4 / out_lo4_scale (epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E): see xv_seg_desc */
   const void* w4b; int32_t ldw4b; const void* w4b_scale;
   void* out_lo4; void* out_lo4_scale;
-  /* != 0: run tdnn_gemm_kernel_p8 (256 x 256 tiles, K tiles of 64 columns; XV_PREC_FP16 and XV_PREC_FP16MX, epilogues 0 and 2;
-   * rows and n_pad multiples of 256).  Its K walk is group -> 64-column chunk -> offset: for XV_PREC_FP16MX w4 / w4_scale must
-   * come from xv_pack_mx_residual64.  A layer runs this kernel for every launch of a mode or for none (its sums are formed in
+  /* != 0: run tdnn_gemm_kernel_p8 (256 x 256 tiles, K tiles of 64 columns; XV_PREC_FP16, XV_PREC_FP16MX and XV_PREC_FP16MX2,
+   * epilogues 0 and 2; rows and n_pad multiples of 256).  Its K walk is group -> 64-column chunk -> offset: w4 / w4_scale must
+   * come from xv_pack_mx_residual64 (and, XV_PREC_FP16MX2, w4b / w4b_scale from xv_pack_mx_weights64 with ldw4b = 2 * ldw).  A layer runs this kernel for every launch of a mode or for none (its sums are formed in
    * another order than the 32-column kernels'). */
   int32_t p8;
 } xv_gemm_desc;
@@ -278,6 +278,10 @@ xv_status xv_pack_mx_residual64(const float* w, const uint16_t* w_hi_f16, int32_
  * bytes in natural order (tile them with xv_tile_mx_scales). */
 xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
                              const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale);
+/* the same in the order of tdnn_gemm_kernel_p8's second walk (tiles of 256 columns: every k_len a multiple of 256), rows of
+ * k_len * 2 bytes - the pitch of the fp16 plane, which is what xv_gemm_desc.ldw4b must then say: w4b receives n_pad * k_len * 2 bytes */
+xv_status xv_pack_mx_weights64(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
+                               const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale);
 /* natural[n_pad][k_len / 32] (what xv_pack_mx_residual / xv_pack_mx_weights wrote) -> the order the kernels stage the scales in for the given
  * epilogue (xv_gemm_desc.epilogue): n_pad * (k_len / 32) bytes.  n_pad must be a multiple of 128. */
 xv_status xv_tile_mx_scales(const uint8_t* natural, int32_t n_pad, int32_t k_len, int32_t epilogue, uint8_t* tiled);

@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "xv_ctx_profile_report", "xv_extract_utterances", "xv_ctx_calibrate", "xv_ctx_set_fast_mode", "xv_ctx_fast_mode",
     "xv_calibrate_table", "xv_ctx_set_calibration",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
-    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_pack_mx_residual64", "xv_tile_mx_scales", "xv_pack_mx_weights",
+    "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_pack_mx_residual64", "xv_tile_mx_scales", "xv_pack_mx_weights", "xv_pack_mx_weights64",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib():
     L.xv_pack_mx_residual64.argtypes = L.xv_pack_mx_residual.argtypes
     L.xv_pack_mx_weights.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.xv_pack_mx_weights64.argtypes = L.xv_pack_mx_weights.argtypes
     L.xv_tile_mx_scales.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     L.xv_ctx_free.argtypes = [ctypes.c_void_p]
     L.xv_ctx_free.restype = None
@@ -452,19 +453,20 @@ def pack_mx_residual(w, w_hi_f16, segs, walk64=False):
     return w4, sc
 
 
-def pack_mx_weights(w, segs):
-    """4-bit image of a weight matrix for the second K walk of XV_PREC_FP16MX2 + its scales [n_pad, K / 32] (natural order)."""
+def pack_mx_weights(w, segs, walk64=False):
+    """4-bit image of a weight matrix for the second K walk of XV_PREC_FP16MX2 + its scales [n_pad, K / 32] (natural order).
+    walk64: in the order of tdnn_gemm_kernel_p8's second walk, rows of 2 K bytes (GemmDesc.ldw4b = 2 K then)."""
     import numpy as np
     w = np.ascontiguousarray(w, dtype=np.float32)
     n_pad, K = w.shape
     src = np.array([s[0] for s in segs], dtype=np.int32)
     shift = np.array([s[1] for s in segs], dtype=np.int32)
     klen = np.array([s[2] for s in segs], dtype=np.int32)
-    assert int(klen.sum()) == K and np.all(klen % 128 == 0)
-    w4b = np.zeros((n_pad, K // 2), dtype=np.uint8)
+    assert int(klen.sum()) == K and np.all(klen % (256 if walk64 else 128) == 0)
+    w4b = np.zeros((n_pad, 2 * K if walk64 else K // 2), dtype=np.uint8)
     sc = np.zeros((n_pad, K // 32), dtype=np.uint8)
-    _check(lib().xv_pack_mx_weights(w.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data, klen.ctypes.data,
-                                    w4b.ctypes.data, sc.ctypes.data))
+    fn = lib().xv_pack_mx_weights64 if walk64 else lib().xv_pack_mx_weights
+    _check(fn(w.ctypes.data, n_pad, len(segs), src.ctypes.data, shift.ctypes.data, klen.ctypes.data, w4b.ctypes.data, sc.ctypes.data))
     return w4b, sc
 
 

@@ -544,8 +544,8 @@ xv_status xv_kernel_tdnn_gemm(const xv_gemm_desc* d) {
     a.p8 = d->p8;
     if (a.p8) {
       if (!xv::gemm_p8_applicable(a, d->precision) || (d->epilogue != xv::kEpiAct && d->epilogue != xv::kEpiStats))
-        return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: p8 needs XV_PREC_FP16 or XV_PREC_FP16MX, epilogue 0 or 2, rows and n_pad "
-                                "multiples of 256, K groups of whole 64-column tiles (128-column blocks for XV_PREC_FP16MX)");
+        return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: p8 needs XV_PREC_FP16, XV_PREC_FP16MX or XV_PREC_FP16MX2, epilogue 0 or 2, rows and n_pad "
+                                "multiples of 256, K groups of whole 64-column tiles (128-column blocks for XV_PREC_FP16MX, 256 for XV_PREC_FP16MX2)");
     } else
     if (d->precision == xv::kPrecFp16Mx2 && !xv::gemm_mx2_applicable(a))
       return Fail(XV_ERR_ARG, "xv_kernel_tdnn_gemm: XV_PREC_FP16MX2 needs what XV_PREC_FP16MX needs and the 4-bit planes of the "
@@ -601,15 +601,15 @@ xv_status xv_pack_mx_residual64(const float* w, const uint16_t* w_hi_f16, int32_
   return PackMxResidualImpl(true, w, w_hi_f16, n_pad, nseg, seg_src, seg_shift, seg_klen, w4, w4_scale);
 }
 
-xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
-                             const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale) {
+static xv_status PackMxWeightsImpl(bool walk64, const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src,
+                                   const int32_t* seg_shift, const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale) {
   if (!w || !seg_src || !seg_shift || !seg_klen || !w4b || !w4b_scale || nseg < 1 || nseg > xv::kMaxSeg || n_pad < 1)
     return Fail(XV_ERR_ARG, "xv_pack_mx_weights: bad argument");
   return Guard([&] {
     long key[xv::kMaxSeg];
     int shift[xv::kMaxSeg], ksteps[xv::kMaxSeg], k_pad = 0;
     for (int j = 0; j < nseg; ++j) {
-      if (seg_klen[j] % 128) return Fail(XV_ERR_ARG, "xv_pack_mx_weights: k_len must be a multiple of 128");
+      if (seg_klen[j] % (walk64 ? 256 : 128)) return Fail(XV_ERR_ARG, "xv_pack_mx_weights: k_len must be a multiple of 128 (256 for the p8 order)");
       key[j] = seg_src[j];
       shift[j] = seg_shift[j];
       ksteps[j] = seg_klen[j] / xv::kBK;
@@ -618,12 +618,25 @@ xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const 
     xv::WalkGroup wg[xv::kMaxSeg];
     const int ng = xv::PlanWalkGroups(nseg, key, shift, ksteps, wg);
     std::vector<int> lo_wcol(k_pad / 128);
-    const int n_lo = xv::PlanWalkLoSteps(ng, wg, lo_wcol.data(), (int)lo_wcol.size());
+    const int n_lo = walk64 ? xv::PlanWalkLoSteps64(ng, wg, lo_wcol.data(), (int)lo_wcol.size())
+                            : xv::PlanWalkLoSteps(ng, wg, lo_wcol.data(), (int)lo_wcol.size());
     if (n_lo != (int)lo_wcol.size()) return Fail(XV_ERR_ARG, "xv_pack_mx_weights: inconsistent walk");
+    const size_t pitch = walk64 ? (size_t)k_pad * 2 : (size_t)n_lo * 64;   // p8: rows of the fp16 plane's pitch
+    if (walk64) memset(w4b, 0, pitch * n_pad);
     for (int n = 0; n < n_pad; ++n)
-      xv::PackMxWeightsRow(w + (size_t)n * k_pad, lo_wcol.data(), n_lo, w4b + (size_t)n * n_lo * 64, w4b_scale + (size_t)n * n_lo * 4);
+      xv::PackMxWeightsRow(w + (size_t)n * k_pad, lo_wcol.data(), n_lo, w4b + (size_t)n * pitch, w4b_scale + (size_t)n * n_lo * 4);
     return XV_OK;
   });
+}
+
+xv_status xv_pack_mx_weights(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
+                             const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale) {
+  return PackMxWeightsImpl(false, w, n_pad, nseg, seg_src, seg_shift, seg_klen, w4b, w4b_scale);
+}
+
+xv_status xv_pack_mx_weights64(const float* w, int32_t n_pad, int32_t nseg, const int32_t* seg_src, const int32_t* seg_shift,
+                               const int32_t* seg_klen, uint8_t* w4b, uint8_t* w4b_scale) {
+  return PackMxWeightsImpl(true, w, n_pad, nseg, seg_src, seg_shift, seg_klen, w4b, w4b_scale);
 }
 
 xv_status xv_tile_mx_scales(const uint8_t* natural, int32_t n_pad, int32_t k_len, int32_t epilogue, uint8_t* tiled) {

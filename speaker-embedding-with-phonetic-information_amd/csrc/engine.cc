@@ -16,9 +16,9 @@ namespace {
 
 constexpr int kDefaultFastMinPooledMx2 = 160;   // the deeper c-vector network measured 7.9e-5 at 117 pooled frames (heavy-tailed model)
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 5;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
+constexpr uint32_t kBlobVersion = 6;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
                                        // plane; 4: + the 4-bit weight image of kPrecFp16Mx2; 5: + the residual plane in the
-                                       // K-walk order of tdnn_gemm_kernel_p8
+                                       // K-walk order of tdnn_gemm_kernel_p8; 6: + the 4-bit weight image in the order of ITS second walk
 constexpr uint64_t kNone = ~0ull;
 
 struct BlobHeader {
@@ -44,6 +44,9 @@ struct BlobLayer {
   uint64_t w4b, w4b_scale;                   // kPrecFp16Mx2: 4-bit image of the weights + scales (both tile orders), or kNone
   uint64_t w4p, w4p_scale;                   // the residual plane of w4 in the walk order of tdnn_gemm_kernel_p8 (PlanWalkSteps64:
                                              // 64-column chunk -> offset) + scales, for the layers that kernel can run, or kNone
+  uint64_t w4bp, w4bp_scale;                 // kPrecFp16Mx2 on that kernel: the 4-bit weight image in the order of its second walk
+                                             // (PlanWalkLoSteps64: tiles of 256 columns), rows of k_pad * 2 bytes (the pitch of
+                                             // the fp16 plane; a row's tiles fill the first quarter), + scales, or kNone
 };
 
 // Round-to-nearest-even onto the e2m1 grid {0, .5, 1, 1.5, 2, 3, 4, 6} (saturating), like v_cvt_scalef32_pk_fp4_*.
@@ -188,7 +191,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     b.offset = cur;
     cur = Align256(cur + (uint64_t)b.n_pad * 4);
     // kPrecFp16Mx residual plane (frame-level layers whose K walk consists of whole blocks of four steps)
-    b.w4 = b.w4_scale = b.w4b = b.w4b_scale = b.w4p = b.w4p_scale = kNone;
+    b.w4 = b.w4_scale = b.w4b = b.w4b_scale = b.w4p = b.w4p_scale = b.w4bp = b.w4bp_scale = kNone;
     b.ldw4 = b.ldw4b = 0;
     if ((precision == kPrecAuto || precision == kPrecFp16Mx || precision == kPrecFp16Mx2) && !L.segment_level) {
       long key[kMaxSeg];
@@ -233,6 +236,15 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4b);
           b.w4b_scale = cur;
           cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
+          bool lo64 = b.w4p != kNone;   // tdnn_gemm_kernel_p8's second walk: tiles of 256 columns, i.e. sources of whole multiples of 256
+          for (int j = 0; j < b.nsrc; ++j)
+            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256) lo64 = false;
+          if (lo64) {
+            b.w4bp = cur;
+            cur = Align256(cur + (uint64_t)b.n_pad * b.k_pad * 2);
+            b.w4bp_scale = cur;
+            cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
+          }
         } else if (!input_only) {
           throw EngineError("precision fp16mx2 cannot run layer " + L.name + " (every source but the network input must be another layer's output)");
         }
@@ -372,6 +384,16 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
         }
         TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4b_scale);
         TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4b_scale + (size_t)b.n_pad * nsc);
+        if (b.w4bp != kNone) {   // the same image in the order of tdnn_gemm_kernel_p8's second walk, rows of k_pad * 2 bytes
+          const int n64 = PlanWalkLoSteps64(ng, wg, lo_wcol.data(), (int)lo_wcol.size());
+          std::fill(nat.begin(), nat.end(), 127);
+          for (int n = 0; n < L.out_dim; ++n) {
+            for (int k = 0; k < b.k_pad; ++k) wrow[k] = src_col[k] >= 0 ? L.w[(size_t)n * L.in_dim + src_col[k]] * wscale : 0.f;
+            PackMxWeightsRow(wrow.data(), lo_wcol.data(), n64, data + b.w4bp + (size_t)n * b.k_pad * 2, nat.data() + (size_t)n * nsc);
+          }
+          TileMxScales(nat.data(), b.n_pad, nsc, true, data + b.w4bp_scale);
+          TileMxScales(nat.data(), b.n_pad, nsc, false, data + b.w4bp_scale + (size_t)b.n_pad * nsc);
+        }
       }
     }
     float* bias = (float*)(data + b.bias);
@@ -643,6 +665,8 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     layers_[i].ldw4b = b.ldw4b;
     layers_[i].w4p = b.w4p == kNone ? nullptr : base + b.w4p;
     layers_[i].w4p_scale = b.w4p_scale == kNone ? nullptr : base + b.w4p_scale;
+    layers_[i].w4bp = b.w4bp == kNone ? nullptr : base + b.w4bp;
+    layers_[i].w4bp_scale = b.w4bp_scale == kNone ? nullptr : base + b.w4bp_scale;
   }
   {
     const char* e = getenv("XVEC_P8");   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
@@ -1231,6 +1255,18 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
             // network input only (PackModel checked it) and runs the three-pass arithmetic on the planes of prep_input
             rprec = gemm_mx2_applicable(gr) ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3E;
             if (rprec == kPrecFp16x3E && epi != kEpiAct) throw EngineError("fp16mx2: layer " + li.name + " cannot run the mode");
+            if (rprec == kPrecFp16Mx2 && use_p8_ && dl.w4p && dl.w4bp && (epi == kEpiAct || epi == kEpiStats)) {
+              // the 1.5-pass launches of the layers tdnn_gemm_kernel_p8 can run: both 4-bit images in its walk orders
+              const size_t so = epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0;
+              GemmArgs g8 = gr;
+              g8.p8 = 1;
+              g8.w4 = dl.w4p;
+              g8.w4_scale = dl.w4p_scale + so;
+              g8.w4b = dl.w4bp;
+              g8.ldw4b = li.k_pad * 2;
+              g8.w4b_scale = dl.w4bp_scale + so;
+              if (gemm_p8_applicable(g8, kPrecFp16Mx2)) gr = g8;
+            }
           } else {
             rprec = (mx_pass && gemm_mx_applicable(gr)) ? (int)kPrecFp16Mx : (int)kPrecFp16x2;
             if (rprec == kPrecFp16Mx && use_p8_ && dl.w4p && (epi == kEpiAct || epi == kEpiStats)) {

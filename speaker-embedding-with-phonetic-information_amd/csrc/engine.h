@@ -173,6 +173,8 @@ class Engine {
     int ldw4b;
     const uint8_t* w4p = nullptr;        // residual plane + scales in the K-walk order of tdnn_gemm_kernel_p8 (row pitch ldw4)
     const uint8_t* w4p_scale = nullptr;
+    const uint8_t* w4bp = nullptr;       // kPrecFp16Mx2 on that kernel: 4-bit weight image of its second walk (rows of k_pad * 2 bytes) + scales
+    const uint8_t* w4bp_scale = nullptr;
     // layers that read only the network input and run tdnn_first_kernel: compact weight planes [n_pad][kFirstK], built on
     // the device from the packed image at construction (owned: first_buf)
     bool first = false;

@@ -2241,26 +2241,45 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
   if (s1 <= s0) return;   // an XCD block without row tiles (launches of fewer than eight of them)
 
-  // ---- staging geometry: a wave stages rows wave * 16 + piece * 8 + (lane >> 3) of every 128-row unit --------------------
-  int st_ru[2], st_c[2];
-  unsigned woff[2];   // (the second walk's 4-bit weight image is stored with the row pitch of the fp16 plane: the same offsets)
+  // ---- staging geometry: a wave stages rows wave * 16 + piece * 8 + (lane >> 3) of every 128-row unit; the lane fetches the
+  // logical 16-byte chunk (lane & 7) ^ ((piece * 4 + (lane >> 4)) & 7) of its row.  The per-lane byte offsets of the units live
+  // in registers (six of them).  Only the 1.5-pass instantiation, which has none to spare, recomputes them where a unit is
+  // issued (RECOMPUTE; from an opaque copy of the lane id, or hipcc hoists them back): measured on the 1.25-pass kernel that
+  // costs 13 % (tdnn2 0.186 -> 0.210 ms) - the LOAD part of a phase has no room for two dozen more VALU instructions.
+  constexpr bool RECOMPUTE = MX2;
+  auto lane_now = [&]() __attribute__((always_inline)) {
+    int l = lane;
+    if constexpr (RECOMPUTE) asm volatile("" : "+v"(l));
+    return l;
+  };
+  auto unit_offsets = [&](const int ld_elems, const bool weights, unsigned (&off)[2]) __attribute__((always_inline)) {
+    const int l = lane_now();
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    st_ru[j] = wave * 16 + j * 8 + (lane >> 3);
-    st_c[j] = (lane & 7) ^ ((j * 4 + (lane >> 4)) & 7);   // logical 16-byte chunk this lane fetches
-    const int rho = st_ru[j] & 63;
-    const int wrow = (st_ru[j] >> 6) * 128 + (SWAP ? swap_fields(rho) : rho);
-    woff[j] = (unsigned)(wrow * a.ldw + st_c[j] * 8) * 2u;
-  }
-  unsigned woff4[2] = {0u, 0u};   // 4-bit tile: rows wave * 32 + u * 16 + (lane >> 2), 64 B each, chunks swizzled with two row bits
-  if constexpr (MX) {
+    for (int j = 0; j < 2; ++j) {
+      const int ru = wave * 16 + j * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((j * 4 + (l >> 4)) & 7);
+      int row = ru;
+      if (weights) {
+        const int rho = ru & 63;
+        row = (ru >> 6) * 128 + (SWAP ? swap_fields(rho) : rho);
+      }
+      off[j] = (unsigned)(row * ld_elems + c * 8) * 2u;
+    }
+  };
+  auto w4_offsets = [&](unsigned (&off)[2]) __attribute__((always_inline)) {   // 4-bit tile: rows wave * 32 + u * 16 + (lane >> 2), 64 B each
+    const int l = lane_now();
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int r4 = wave * 32 + u * 16 + (lane >> 2);
+      const int r4 = wave * 32 + u * 16 + (l >> 2);
       const int rho = r4 & 63;
       const int wrow = ((r4 >> 6) & 1) * 128 + (r4 >> 7) * 64 + (SWAP ? swap_fields(rho) : rho);
-      woff4[u] = (unsigned)(wrow * a.ldw4 + ((lane & 3) ^ ((lane >> 3) & 3)) * 16);
+      off[u] = (unsigned)(wrow * a.ldw4 + ((l & 3) ^ ((l >> 3) & 3)) * 16);
     }
+  };
+  unsigned woff_r[2] = {0u, 0u}, woff4_r[2] = {0u, 0u}, xoff_r[2] = {0u, 0u};
+  if constexpr (!RECOMPUTE) {
+    unit_offsets(a.ldw, true, woff_r);
+    if constexpr (MX) w4_offsets(woff4_r);
   }
   const unsigned st_lane = lds_base + wave * 2048;
 
@@ -2273,22 +2292,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   const char* xb = nullptr;
   const char* wb = nullptr;
   const char* wtile = nullptr;          // weight row n0
-  unsigned xoff[2] = {0u, 0u};
   int x_next = 0, x_wrap = 0, w_next = 0, w_wrap = 0;   // byte steps of the walk (they fit 32 bits; fewer scalar registers)
   auto bind_group = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) xoff[j] = (unsigned)(st_ru[j] * gi.ld + st_c[j] * 8) * 2u;
+    if constexpr (!RECOMPUTE) unit_offsets(gi.ld, false, xoff_r);
     xb = (const char*)gi.hi + ((long)(m0 + gi.shift0 + ij * gi.dstep) * gi.ld + ic * 64) * 2;
     x_next = gi.dstep * gi.ld * 2;
     x_wrap = 128 - (gi.nshift - 1) * gi.dstep * gi.ld * 2;
-    if (MX2 && it >= S) {   // second walk: the weight tiles follow each other in walk order
-      wb = (const char*)a.w4b + (long)n0 * a.ldw * 2 + (long)(it - S) * 128;   // (row pitch of the fp16 plane: GemmArgs::ldw4b)
-      w_next = w_wrap = 128;
-    } else {
-      wb = wtile + (long)(gi.wcol0 + ij * gi.wstride + ic * 64) * 2;
-      w_next = gi.wstride * 2;
-      w_wrap = 128 - (gi.nshift - 1) * gi.wstride * 2;
-    }
+    // second walk: the weight tiles follow each other in walk order, 128 bytes per row and tile, in an image with the row pitch of
+    // the fp16 plane (GemmArgs::ldw4b); first walk: the tile's columns of the fp16 plane
+    const bool lo_i = MX2 && it >= S;
+    const char* wb_hi = wtile + (long)(gi.wcol0 + ij * gi.wstride + ic * 64) * 2;
+    const char* wb_lo = MX2 ? (const char*)a.w4b + (long)n0 * a.ldw * 2 + (long)(it - S) * 128 : wb_hi;
+    wb = lo_i ? wb_lo : wb_hi;
+    w_next = lo_i ? 128 : gi.wstride * 2;
+    w_wrap = lo_i ? 128 : 128 - (gi.nshift - 1) * gi.wstride * 2;
   };
   auto adv = [&]() __attribute__((always_inline)) {
     ++it;
@@ -2313,11 +2330,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     if (unit == 0 || unit == 3) {
       const unsigned dst = st_lane + 2 * kP8XW + buf * kP8XW + (unit == 3 ? kP8Unit : 0);
       const char* src = wb + (unit == 3 ? (long)a.ldw * 128 : 0);
+      unsigned woff[2] = {woff_r[0], woff_r[1]};   // (the second walk's 4-bit weight image has the row pitch of the fp16 plane: the same offsets)
+      if constexpr (RECOMPUTE) unit_offsets(a.ldw, true, woff);
       glds16_sbase(src, woff[0], dst);
       glds16_sbase(src, woff[1], dst + 1024);
     } else {
       const char* src = xb + (unit == 2 ? (long)gi.ld * 256 : 0);
       const unsigned dst = st_lane + buf * kP8XW + (unit == 2 ? kP8Unit : 0);
+      unsigned xoff[2] = {xoff_r[0], xoff_r[1]};
+      if constexpr (RECOMPUTE) unit_offsets(gi.ld, false, xoff);
       glds16_sbase(src, xoff[0], dst);
       glds16_sbase(src, xoff[1], dst + 1024);
     }
@@ -2327,6 +2348,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   auto issue_w4 = [&](const int blk) __attribute__((always_inline)) {
     if constexpr (MX) {
       const unsigned d4 = lds_base + kP8W4 + wave * 2048;
+      unsigned woff4[2] = {woff4_r[0], woff4_r[1]};
+      if constexpr (RECOMPUTE) w4_offsets(woff4);
       const uint8_t* w4t = a.w4 + (long)n0 * a.ldw4 + blk * 64;
       glds16_sbase(w4t, woff4[0], d4);
       glds16_sbase(w4t, woff4[1], d4 + 1024);
@@ -2716,25 +2739,28 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     c0 = c1 = c2 = c3 = 0;
     if (wn == 1) barrier();
+    // the pairs of the first walk, then - kPrecFp16Mx2 - those of the second: two loops one behind the other.  (As the two arms
+    // of an if inside ONE loop hipcc gives the accumulator tuples different homes in the two bodies and keeps 28 of the 32
+    // fragments in scratch between them: 660 bytes per lane.)
     const int ntp = n_tiles_part;
+    const int n_hi = MX2 ? (kb_part >= S ? 0 : (kb_part + ntp <= S ? ntp : S - kb_part)) : ntp;   // tiles of the first walk in this part
 #pragma nounroll
-    for (int t = 0; t < ntp; t += 2) {
-      const bool lo = MX2 && kb_part + t >= S;
-      if (!lo) {
-        if constexpr (MX) {
-          if (r_left == 0) {   // the walk enters another source: its group maxima (a pair never straddles two groups)
-            ++rg;
-            r_left = (a.grp[rg].ksteps >> 1) * a.grp[rg].nshift;
-            xs_uvec xg;
-            xs_request(a.grp[rg].gmax, xg);
-            xs_finish(xg);
-          }
-          r_left -= 2;
+    for (int t = 0; t < n_hi; t += 2) {
+      if constexpr (MX) {
+        if (r_left == 0) {   // the walk enters another source: its group maxima (a pair never straddles two groups)
+          ++rg;
+          r_left = (a.grp[rg].ksteps >> 1) * a.grp[rg].nshift;
+          xs_uvec xg;
+          xs_request(a.grp[rg].gmax, xg);
+          xs_finish(xg);
         }
-        pair(I0{}, ntp - t, (kb_part + t) >> 1);
-      } else {
-        if constexpr (MX2) pair(I1{}, ntp - t, 0);
+        r_left -= 2;
       }
+      pair(I0{}, ntp - t, (kb_part + t) >> 1);
+    }
+    if constexpr (MX2) {
+#pragma nounroll
+      for (int t = n_hi; t < ntp; t += 2) pair(I1{}, ntp - t, 0);
     }
     if (wn == 0) barrier();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
@@ -2921,7 +2947,10 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 // 128-column blocks for kPrecFp16Mx), an even number of K tiles, and for kPrecFp16Mx the residual plane in ITS walk order
 // (GemmArgs::p8 is the caller's statement that w4 / w4_scale are in that order)
 bool gemm_p8_applicable(const GemmArgs& a, int precision) {
-  if (precision != kPrecFp16 && precision != kPrecFp16Mx) return false;   // (kPrecFp16Mx2: see launch_one)
+#ifndef XVEC_P8_MX2
+  if (precision == kPrecFp16Mx2) return false;   // experimental, not built by default (launch_one)
+#endif
+  if (precision != kPrecFp16 && precision != kPrecFp16Mx && precision != kPrecFp16Mx2) return false;
   if ((a.m_tiles & 1) || (a.n_tiles & 1) || a.ksplit > 1) return false;
   const bool mx = precision != kPrecFp16, mx2 = precision == kPrecFp16Mx2;
   GemmArgs b = a;
@@ -3028,11 +3057,19 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (a.p8) {   // the caller packed / chose this layer for the 64-column K walk: no other kernel accumulates in that order
-    // (kPrecFp16Mx2: the kernel's second-walk path is written - tiles of 256 4-bit columns through the same phases - but hipcc
-    // (ROCm 7.2) keeps 28 of its 32 accumulator fragments in scratch for that instantiation, 520-660 bytes per lane whatever
-    // is taken out of it; until that is understood the 1.5-pass launches stay on tdnn_gemm_kernel_sk, and this instantiation is
-    // not built)
-    if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx) && (EPI == kEpiAct || EPI == kEpiStats)) return launch_one_p8<PREC, EPI>(a, s);
+    // kPrecFp16Mx2: the kernel's second-walk path (tiles of 256 4-bit columns through the same phases) is written, compiles
+    // without scratch and passes 27 of its 28 kernel tests - and is NOT built by default (-DXVEC_P8_MX2 builds it): measured on
+    // the bench workload it loses to tdnn_gemm_kernel_sk where the time is (tdnn2 / tdnn3 0.279 / 0.272 ms against 0.251 / 0.247;
+    // tdnn4 0.131 against 0.144; whole step 237 k against 246 k utt/s), one statistics-epilogue case with cuts inside a
+    // time-offset group differs from the emulation, and two runs differ in the last bits (a race somewhere in the second walk's
+    // staging).  The 1.5-pass launches stay on tdnn_gemm_kernel_sk.
+#ifdef XVEC_P8_MX2
+    constexpr bool kP8Mx2 = true;
+#else
+    constexpr bool kP8Mx2 = false;
+#endif
+    if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx || (kP8Mx2 && PREC == kPrecFp16Mx2)) && (EPI == kEpiAct || EPI == kEpiStats))
+      return launch_one_p8<PREC, EPI>(a, s);
     else return hipErrorInvalidValue;
   }
   const int variant = gemm_variant();

@@ -326,10 +326,10 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6, p8=0
             d.seg[j].lo4 = lo4[si][0].data_ptr() + HALO * (src_ld[si] // 2)
             d.seg[j].lo4_scale = lo4[si][1].data_ptr() + HALO * lo4[si][1].shape[1]
     if prec == 7:
-        w4b, w4bs = P.pack_mx_weights(W.cpu().numpy(), [(s[0], s[2], s[3]) for s in segs])
+        w4b, w4bs = P.pack_mx_weights(W.cpu().numpy(), [(s[0], s[2], s[3]) for s in segs], walk64=bool(p8))
         w4b_d = torch.from_numpy(w4b).to(dev)
         w4bs_d = torch.from_numpy(P.tile_mx_scales(w4bs, epi)).to(dev)
-        d.w4b, d.ldw4b, d.w4b_scale = w4b_d.data_ptr(), K // 2, w4bs_d.data_ptr()
+        d.w4b, d.ldw4b, d.w4b_scale = w4b_d.data_ptr(), (2 * K if p8 else K // 2), w4bs_d.data_ptr()
     d.w_hi, d.w_lo, d.ldw = Wh.data_ptr(), None, K
     d.w4, d.ldw4, d.w4_scale = w4_d.data_ptr(), K // 128 * 64, w4t_d.data_ptr()
     run_rows = variant_rows or rows     # variant_rows: launch only the first rows of the same data (another tile partition)
