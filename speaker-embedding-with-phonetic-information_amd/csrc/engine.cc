@@ -236,7 +236,7 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4b);
           b.w4b_scale = cur;
           cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
-          bool lo64 = b.w4p != kNone;   // tdnn_gemm_kernel_p8's second walk: tiles of 256 columns, i.e. sources of whole multiples of 256
+          bool lo64 = kP8Mx2Built && b.w4p != kNone;   // tdnn_gemm_kernel_p8's second walk: tiles of 256 columns, i.e. sources of whole multiples of 256
           for (int j = 0; j < b.nsrc; ++j)
             if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256) lo64 = false;
           if (lo64) {

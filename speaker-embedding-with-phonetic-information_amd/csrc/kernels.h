@@ -289,6 +289,13 @@ const char* last_gemm_kernel();
 // with a group-max table, even tile count); otherwise the caller launches kPrecFp16x2 on the same operands.
 bool gemm_mx_applicable(const GemmArgs& a);
 bool gemm_mx2_applicable(const GemmArgs& a);   // kPrecFp16Mx2: also the 4-bit planes, sources of whole 128-column steps
+// The 1.5-pass path of tdnn_gemm_kernel_p8 is experimental and not built by default (kernels.hip, launch_one): the packer then
+// leaves its weight image out of the model blob
+#ifdef XVEC_P8_MX2
+constexpr bool kP8Mx2Built = true;
+#else
+constexpr bool kP8Mx2Built = false;
+#endif
 // tdnn_gemm_kernel_p8 can run this launch in kPrecFp16 / kPrecFp16Mx (see GemmArgs::p8)
 bool gemm_p8_applicable(const GemmArgs& a, int precision);
 // Stream-K workspace (partial-tile exchange) of a stream: allocated on first use, released by the owner of the

@@ -2947,9 +2947,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 // 128-column blocks for kPrecFp16Mx), an even number of K tiles, and for kPrecFp16Mx the residual plane in ITS walk order
 // (GemmArgs::p8 is the caller's statement that w4 / w4_scale are in that order)
 bool gemm_p8_applicable(const GemmArgs& a, int precision) {
-#ifndef XVEC_P8_MX2
-  if (precision == kPrecFp16Mx2) return false;   // experimental, not built by default (launch_one)
-#endif
+  if (precision == kPrecFp16Mx2 && !kP8Mx2Built) return false;   // experimental, not built by default (launch_one)
   if (precision != kPrecFp16 && precision != kPrecFp16Mx && precision != kPrecFp16Mx2) return false;
   if ((a.m_tiles & 1) || (a.n_tiles & 1) || a.ksplit > 1) return false;
   const bool mx = precision != kPrecFp16, mx2 = precision == kPrecFp16Mx2;
@@ -3063,12 +3061,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
     // tdnn4 0.131 against 0.144; whole step 237 k against 246 k utt/s), one statistics-epilogue case with cuts inside a
     // time-offset group differs from the emulation, and two runs differ in the last bits (a race somewhere in the second walk's
     // staging).  The 1.5-pass launches stay on tdnn_gemm_kernel_sk.
-#ifdef XVEC_P8_MX2
-    constexpr bool kP8Mx2 = true;
-#else
-    constexpr bool kP8Mx2 = false;
-#endif
-    if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx || (kP8Mx2 && PREC == kPrecFp16Mx2)) && (EPI == kEpiAct || EPI == kEpiStats))
+    if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx || (kP8Mx2Built && PREC == kPrecFp16Mx2)) && (EPI == kEpiAct || EPI == kEpiStats))
       return launch_one_p8<PREC, EPI>(a, s);
     else return hipErrorInvalidValue;
   }
