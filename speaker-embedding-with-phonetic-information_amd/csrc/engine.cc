@@ -1513,6 +1513,7 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
   if (row_offsets[0] != 0) throw EngineError("SubmitHost: row_offsets[0] must be 0");
   Check(hipSetDevice(device_), "hipSetDevice");
   const size_t lane = (size_t)seq % lanes_.size();
+  S.lane = (int)lane;
   hipStream_t s = lanes_[lane].stream;
   if (!S.done) Check(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate(slot)");
   if (!S.h2d_done) Check(hipEventCreateWithFlags(&S.h2d_done, hipEventDisableTiming), "hipEventCreate(slot)");
@@ -1584,13 +1585,25 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
   S.pending = true;
 }
 
-void Engine::CheckKernelFaults() const {
+void Engine::CheckKernelFaults(int lane) const {
   // a stream-K workgroup that gave up waiting for another workgroup's partial tile (bounded spin, kernels.hip) left
   // a word behind on its launch stream; the results of that launch are not to be trusted.  The word belongs to the
-  // stream, i.e. to this engine, and reading it clears it: the caller may retry (XVEC_GEMM_VARIANT=2) or exit cleanly
+  // stream, i.e. to this engine, and reading it clears it: the caller may retry (XVEC_GEMM_VARIANT=2) or exit cleanly.
+  // The words of all streams are collected into fault_mask_, but a caller that waited for ONE lane's batch is only told about
+  // that lane: a fault of the batch still in flight on the other lane stays recorded until its own WaitHost.
   (void)hipSetDevice(device_);
-  unsigned err = sk_take_error(stream_);
-  for (const Lane& L : lanes_) err |= sk_take_error(L.stream);
+  if (sk_take_error(stream_)) fault_mask_ |= 1u << 31;
+  for (size_t i = 0; i < lanes_.size() && i < 31; ++i)
+    if (sk_take_error(lanes_[i].stream)) fault_mask_ |= 1u << i;
+  unsigned err;
+  if (lane < 0) {
+    err = fault_mask_;
+    fault_mask_ = 0;
+  } else {
+    const unsigned bits = (1u << (lane & 31)) | (1u << 31);
+    err = fault_mask_ & bits;
+    fault_mask_ &= ~bits;
+  }
   if (err)
     throw EngineError("a stream-K GEMM launch timed out waiting for a partial tile of another workgroup (results invalid); "
                       "XVEC_GEMM_VARIANT=2 selects the per-tile kernels");
@@ -1602,7 +1615,7 @@ const float* Engine::WaitHost(int slot) {
   if (!S.pending) throw EngineError("WaitHost: nothing submitted on this slot");
   Check(hipEventSynchronize(S.done), "hipEventSynchronize(slot)");
   S.pending = false;   // before the fault check: the slot is free again whatever the launch reported
-  CheckKernelFaults();
+  CheckKernelFaults(S.lane);
   return (const float*)S.h_out;
 }
 

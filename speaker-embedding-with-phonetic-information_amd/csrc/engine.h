@@ -212,6 +212,7 @@ class Engine {
     hipEvent_t done = nullptr;
     hipEvent_t h2d_done = nullptr;   // uploads run on copy_stream_, ahead of the lane that will consume them
     bool pending = false;
+    int lane = 0;                 // the lane (stream) the batch was submitted on: whose stream-K fault word concerns this slot
     std::unique_ptr<Plan> plan;   // its tables live in d_tables (not owned by the plan)
   };
   HostSlot host_slots_[kNumHostSlots];
@@ -223,7 +224,10 @@ class Engine {
   void Check(hipError_t e, const char* what) const;
  public:
   // throws when a kernel of this process reported a fault the HIP API cannot see (called after synchronising)
-  void CheckKernelFaults() const;
+  // lane >= 0: only that lane's launches are the caller's (a fault another lane's batch raised stays recorded for the slot it
+  // belongs to); -1: everything this engine launched
+  void CheckKernelFaults(int lane = -1) const;
+  mutable unsigned fault_mask_ = 0;   // bit i: lane i's stream reported a timed-out stream-K wait; bit 31: the engine's own stream
  private:
   void Ensure(Buf* b, size_t bytes, bool zero);
   void EnsureCapacity(Lane& L, int rows, int b_pad);

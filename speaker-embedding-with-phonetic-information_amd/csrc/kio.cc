@@ -96,6 +96,11 @@ long Input::FileTell() {
 
 void Input::Skip(long n) {
   if (!IsRegularFile() || fseek(f_, n, SEEK_CUR) != 0) throw KioError("cannot seek in " + name_);
+  // fseek moves past the end of a truncated file without a word: the index pass of a table must notice where the sequential
+  // reader would have ("unexpected end of file"), not a whole job later
+  struct stat st;
+  const long pos = ftell(f_);
+  if (pos >= 0 && fstat(fileno(f_), &st) == 0 && pos > (long)st.st_size) throw KioError("unexpected end of file in " + name_);
 }
 
 void Input::OpenMemory(const void* data, size_t n) {

@@ -269,7 +269,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   // index pass: batches by the same rule as the sequential reader, from the headers (objects whose size is not known
   // without reading them - text, pipes - count as 0 rows: such batches are bounded by max_batch_chunks only, and the
   // extractor splits what does not fit one forward pass)
-  auto index_pass = [&] {
+  auto index_pass_body = [&] {
     PlanBatch cur;
     long rows = 0;
     auto push = [&](bool last) {
@@ -307,7 +307,31 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
     }
     push(true);
   };
-  auto parallel_reader = [&] {
+  // anything thrown outside the guarded calls above (an allocation failing while a batch is assembled) must not leave the
+  // thread: an exception escaping a std::thread is std::terminate.  It becomes the job's reader error, and a terminal batch
+  // releases whoever waits.
+  auto reader_failed = [&](const char* what) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (reader_error.empty()) reader_error = what;
+    Batch b;
+    b.last = true;
+    queue.push_back(std::move(b));
+    PlanBatch again;
+    again.seq = -1;
+    again.last = true;
+    plans.push_back(std::move(again));
+    cv.notify_all();
+  };
+  auto index_pass = [&] {
+    try {
+      index_pass_body();
+    } catch (const std::exception& ex) {
+      reader_failed(ex.what());
+    } catch (...) {
+      reader_failed("unknown error in the index pass");
+    }
+  };
+  auto parallel_reader_body = [&] {
     Input in;
     std::string in_path;
     for (;;) {
@@ -359,6 +383,15 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
         cv.notify_all();
         if (pb.last) return;
       }
+    }
+  };
+  auto parallel_reader = [&] {
+    try {
+      parallel_reader_body();
+    } catch (const std::exception& ex) {
+      reader_failed(ex.what());
+    } catch (...) {
+      reader_failed("unknown error in a reader thread");
     }
   };
   bool calibrated = !(opt.calibrate && engine->can_switch_fast_mode());   // nothing to choose: no batch is held back

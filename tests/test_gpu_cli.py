@@ -86,6 +86,23 @@ def test_cli_exit_status_when_nothing_succeeds(job):
     assert r.returncode == 255 and b"unknown node" in r.stderr
 
 
+def test_cli_truncated_archive_is_an_error_at_index_time(job):
+    """A feature archive cut off inside its last matrix: the sequential reader fails with "unexpected end of file"; the index
+    pass of the multi-threaded reader seeks over payloads and must say the same - at once, not after the rest of the job
+     - with and without calibration; exit status 255 like any exception."""
+    d, utts, ev = job
+    blob = (d / "feats.ark").read_bytes()
+    (d / "cut.ark").write_bytes(blob[:len(blob) - 1000])
+    for extra in ([], ["--calibrate=false"], ["--precision=fp16x3"]):
+        r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine"] + extra +
+                 [str(d / "final.raw"), "ark:%s/cut.ark" % d, "ark:/dev/null"])
+        assert r.returncode == 255 and b"unexpected end of file" in r.stderr, r.stderr.decode()[-600:]
+    env = dict(os.environ, XVEC_READERS="1")    # the sequential reader: the same verdict
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine", "--calibrate=false",
+              str(d / "final.raw"), "ark:%s/cut.ark" % d, "ark:/dev/null"], env=env)
+    assert r.returncode == 255 and b"unexpected end of file" in r.stderr, r.stderr.decode()[-600:]
+
+
 def test_extract_table_through_the_c_abi(job):
     d, utts, ev = job
     P = H.pkg()
