@@ -458,8 +458,10 @@ std::vector<uint8_t> ReadBlobHead(const void* device_blob, size_t n) {
   BlobHeader h;
   if (hipMemcpy(&h, device_blob, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
     throw EngineError("cannot read the header of the device-resident model blob");
-  if (memcmp(h.magic, "XVHIPBLB", 8) != 0 || h.version != kBlobVersion || h.total_bytes != n || h.data_offset > n ||
-      h.data_offset < sizeof h)
+  if (memcmp(h.magic, "XVHIPBLB", 8) == 0 && h.version != kBlobVersion)
+    throw EngineError("model blob (device image) has format version " + std::to_string(h.version) + ", this library reads version " +
+                      std::to_string(kBlobVersion) + ": repack the model");
+  if (memcmp(h.magic, "XVHIPBLB", 8) != 0 || h.total_bytes != n || h.data_offset > n || h.data_offset < sizeof h)
     throw EngineError("bad model blob header (device image)");
   std::vector<uint8_t> head((size_t)h.data_offset);
   if (hipMemcpy(head.data(), device_blob, head.size(), hipMemcpyDeviceToHost) != hipSuccess)
@@ -471,7 +473,10 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
   if (n < sizeof(BlobHeader)) throw EngineError("model blob too small");
   BlobHeader h;
   memcpy(&h, blob, sizeof h);
-  if (memcmp(h.magic, "XVHIPBLB", 8) != 0 || h.version != kBlobVersion) throw EngineError("bad model blob header");
+  if (memcmp(h.magic, "XVHIPBLB", 8) != 0) throw EngineError("bad model blob header");
+  if (h.version != kBlobVersion)
+    throw EngineError("model blob has format version " + std::to_string(h.version) + ", this library reads version " +
+                      std::to_string(kBlobVersion) + ": repack the model");
   if (h.total_bytes != n) throw EngineError("model blob size mismatch");
   if (h.n_layers < 1 || h.n_layers > 4096 || h.data_offset > n ||
       sizeof(BlobHeader) + (uint64_t)h.n_layers * sizeof(BlobLayer) > h.data_offset)

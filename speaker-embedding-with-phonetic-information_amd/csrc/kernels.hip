@@ -2989,14 +2989,7 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
     build_lo_groups(&b);   // second walk: the 4-bit planes, steps of 128 columns (a tile = two of them)
     for (int i = 0; i < b.ngrp_lo; ++i) b.p8_ktiles_lo += (b.grp[b.ngrp + i].ksteps >> 1) * b.grp[b.ngrp + i].nshift;
   }
-  {
-    static int flags = -1;
-    if (flags < 0) {
-      const char* e = getenv("XVEC_P8_FLAGS");   // experiments: 1 = no priority for the MFMA part, 2 = priority for the LOAD part
-      flags = (e && *e) ? atoi(e) & 3 : 0;
-    }
-    b.p8 = 1 | (flags << 1);
-  }
+  b.p8 = 1;
   b.sk_mtiles = a.m_tiles >> 1;
   const int nt = a.n_tiles >> 1;
   int grid = device_cu_count() / 8 * 8;

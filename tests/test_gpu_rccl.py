@@ -47,6 +47,14 @@ def test_context_from_device_blob():
     bad[200:264] = 255
     with pytest.raises(P.XvError):
         P.Context(device_blob=(bad.data_ptr(), bad.numel()), device=0)
+    # an image of another format version (an older build's pack) is refused by name, from the host and from the device
+    old = bytearray(blob)
+    old[8:12] = (5).to_bytes(4, "little")     # BlobHeader: char magic[8]; uint32 version
+    with pytest.raises(P.XvError, match="format version 5"):
+        P.Context(blob=bytes(old))
+    oldt = torch.frombuffer(old, dtype=torch.uint8).cuda()
+    with pytest.raises(P.XvError, match="format version 5"):
+        P.Context(device_blob=(oldt.data_ptr(), oldt.numel()), device=0)
 
 
 def test_dist_extract_nccl_one_rank(tmp_path):
