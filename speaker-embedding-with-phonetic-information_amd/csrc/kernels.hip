@@ -393,6 +393,76 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
     // h = p>>1, position inside the group (p&1)*4 + r
     const int ncol = nbase + fr_g * 8;
+    if constexpr (LAZY && !PrecEmitsLo4(PREC)) {
+      // Parameters from LDS, column pair outermost: the 24 parameter words of a lane's 8 contiguous columns are read once
+      // and serve the four 16-row groups (with the rows outermost they were read again for every group: 96 LDS reads and
+      // as many round trips per 64 x 128 wave tile, a third of the epilogue's time).  Same arithmetic per element, same
+      // bytes per store instruction.
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        f32x4 b4[2], s4[2], o4[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = pcol + fr_g * 8 + pp * 32 + j * 4;
+          b4[j] = *(const f32x4*)(par + c);
+          s4[j] = *(const f32x4*)(par + 128 + c);
+          o4[j] = *(const f32x4*)(par + 256 + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = mbase + q * 16 + fr_i;
+          f32x2 y2[4];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              f32x2 z = f32x2{acc[pp * 2 + j][q][2 * k], acc[pp * 2 + j][q][2 * k + 1]} + f32x2{b4[j][2 * k], b4[j][2 * k + 1]};
+              z = f32x2{apply_floor(z[0], relu_floor), apply_floor(z[1], relu_floor)};
+              y2[j * 2 + k] = __builtin_elementwise_fma(z, f32x2{s4[j][2 * k], s4[j][2 * k + 1]}, f32x2{o4[j][2 * k], o4[j][2 * k + 1]});
+            }
+          if constexpr (EPI == kEpiF32) {
+            if (row < a.m_valid) {
+              float* dst = a.out_f32 + (long)row * a.ldf + ncol + pp * 32;
+              *(f32x4*)(dst) = f32x4{y2[0][0], y2[0][1], y2[1][0], y2[1][1]};
+              *(f32x4*)(dst + 4) = f32x4{y2[2][0], y2[2][1], y2[3][0], y2[3][1]};
+            }
+          } else {
+            unsigned int hw[4], lw[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              hw[v] = to16x2<F16>(y2[v]);
+              if constexpr (SPLIT) {
+                const f32x2 back = {from16<F16>((uint16_t)hw[v]), from16<F16>((uint16_t)(hw[v] >> 16))};
+                lw[v] = to16x2<F16>(y2[v] - back);
+              }
+            }
+            if (a.gmax_out) {
+              float ymax = gm[q];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) ymax = fmaxf(fmaxf(ymax, fabsf(y2[v][0])), fabsf(y2[v][1]));
+              gm[q] = ymax;
+            }
+            *(u32x4*)(a.out_hi + (long)row * a.ldo + ncol + pp * 32) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+            if constexpr (SPLIT) *(u32x4*)(a.out_lo + (long)row * a.ldo + ncol + pp * 32) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+          }
+        }
+      }
+      if constexpr (EPI == kEpiAct) {
+        if (a.gmax_out && gm_phase != 1) {
+          // max |y| of each 16-row group -> one atomic max per wave (see the general path below)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int first_q = (int)((e.rng[q >> 1] >> (16 * (q & 1))) & 255u), last_q = (int)((e.rng[q >> 1] >> (16 * (q & 1) + 8)) & 255u);
+            float m = gm[q];
+            if (fr_i < first_q || fr_i >= last_q) m = 0.f;
+            const unsigned u = wave_max_u32(__builtin_bit_cast(unsigned, m));
+            if (lane == 0)
+              (void)__hip_atomic_fetch_max(a.gmax_out + ((mbase + q * 16) >> 4), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      return;
+    }
     unsigned e4 = 0u;   // PrecEmitsLo4: scale byte of row q * 16 + fr_i in byte q (the same in the row's four lanes)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
