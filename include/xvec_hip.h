@@ -129,6 +129,10 @@ xv_status xv_forward_batch(xv_ctx* c, const float* feats, const int32_t* row_off
  * asynchronous on hip_stream (a hipStream_t, NULL = the context's own stream). out rows are out_ld apart. */
 xv_status xv_forward_batch_device(xv_ctx* c, const float* feats_dev, const int32_t* row_offsets, int32_t B,
                                   float* out_dev, int32_t out_ld, void* hip_stream);
+/* Waits for everything the context launched, on its own streams and on callers' streams, and reports what only shows
+ * once the kernels ran: XV_ERR_DEVICE if a persistent GEMM launch gave up waiting for another workgroup's partial tile
+ * (results of that launch are invalid; xv_last_error() says how to select the per-tile kernels).  A caller of
+ * xv_forward_batch_device on its own stream calls this before trusting the results. */
 xv_status xv_ctx_synchronize(xv_ctx* c);
 /* Per-kernel timing with HIP events recorded on the stream the kernels are launched on (used by bench.py for
  * the roofline figure).  xv_ctx_profile_report synchronises, writes "label<TAB>launches<TAB>total_ms" lines for

@@ -1017,6 +1017,11 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
   Check(hipSetDevice(device_), "hipSetDevice");
   Lane& L = lanes_[lane % lanes_.size()];
   hipStream_t s = stream ? stream : L.stream;
+  if (stream && stream != stream_ && std::find(ext_streams_.begin(), ext_streams_.end(), stream) == ext_streams_.end()) {
+    bool own = false;
+    for (const Lane& l : lanes_) own = own || l.stream == stream;
+    if (!own) ext_streams_.push_back(stream);
+  }
   if (L.busy) Check(hipStreamWaitEvent(s, L.done, 0), "hipStreamWaitEvent(lane)");
   EnsureCapacity(L, plan.rows, plan.b_pad);
   const int prec = slow_prec_;
@@ -1600,6 +1605,11 @@ void Engine::CheckKernelFaults(int lane) const {
   if (sk_take_error(stream_)) fault_mask_ |= 1u << 31;
   for (size_t i = 0; i < lanes_.size() && i < 31; ++i)
     if (sk_take_error(lanes_[i].stream)) fault_mask_ |= 1u << i;
+  // launches on a caller's stream (xv_forward_batch_device) leave their word with that stream: read when the caller asks
+  // about everything (xv_ctx_synchronize), never on behalf of one lane's batch
+  if (lane < 0)
+    for (hipStream_t s : ext_streams_)
+      if (sk_take_error(s)) fault_mask_ |= 1u << 30;
   unsigned err;
   if (lane < 0) {
     err = fault_mask_;

@@ -227,7 +227,9 @@ class Engine {
   // lane >= 0: only that lane's launches are the caller's (a fault another lane's batch raised stays recorded for the slot it
   // belongs to); -1: everything this engine launched
   void CheckKernelFaults(int lane = -1) const;
-  mutable unsigned fault_mask_ = 0;   // bit i: lane i's stream reported a timed-out stream-K wait; bit 31: the engine's own stream
+  mutable unsigned fault_mask_ = 0;   // bit i: lane i's stream reported a timed-out stream-K wait; bit 31: the engine's own stream;
+                                      // bit 30: a caller's stream (xv_forward_batch_device)
+  std::vector<hipStream_t> ext_streams_;   // callers' streams this engine launched on (their fault words are read with the others)
  private:
   void Ensure(Buf* b, size_t bytes, bool zero);
   void EnsureCapacity(Lane& L, int rows, int b_pad);
