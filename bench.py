@@ -44,6 +44,12 @@ KERNEL_PASSES = {"bf16x3": 3, "fp16x3": 3, "fp16x2": 2, "fp16mx": 1.25, "fp16mx2
 PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
+
+def arithmetic_name(ctx):
+    """fast-chunk arithmetic of a context; "fp16mx2+lite<k>": k of its layers run the 1.25-pass arithmetic (xv_calibration.lite_mask)"""
+    m = ctx.lite_mask
+    return ctx.fast_mode + ("+lite%d" % bin(m).count("1") if m else "")
+
 def cpu_baseline(topology, frames, seconds):
     """CPU baseline B0 of BASELINE.md section 3: oracle/xvec_cpu_baseline.c (this repo's C + OpenMP restatement of
     Kaldi's semantics - "port", NOT Kaldi, which is neither vendored by the reference nor installed), file in / file
@@ -264,7 +270,7 @@ def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_n
         err = H.rel_err(out[:nchk].cpu().numpy(), ref)
     return {"workload": "%s, %s, %d chunks x %s frames, output %s" % (topology, precision, batch,
                                                                    "%d-%d" % ragged if ragged else "400", output_node or "embedding"),
-            "arithmetic": ctx.fast_mode, "calibration": cal,
+            "arithmetic": arithmetic_name(ctx), "calibration": cal,
             "value": batch * steps / dt, "unit": "utt/s", "frames_per_sec": float(lens.sum()) * steps / dt,
             "ms_per_step": dt / steps * 1e3, "alg_gflop_per_utt": 2.0 * macs / 1e9,
             "alg_tflops": 2.0 * macs * batch * steps / dt / 1e12, "rel_err_vs_oracle_fp32": err}
@@ -364,7 +370,7 @@ def main():
         nb = len(o) - 1
         n = min(64, nb)
         picks = list(range(nb)) if nb <= 64 else sorted({((2 * i + 1) * nb) // 128 for i in range(64)})
-        choice = torch.tensor([-1], dtype=torch.int64, device=cdev)
+        choice = torch.tensor([-1, 0], dtype=torch.int64, device=cdev)   # arithmetic, lite-layer mask
         cal = None
         if rank == 0:
             fh = f_dev.cpu().numpy()
@@ -373,10 +379,13 @@ def main():
             cal = c.calibrate(_np.concatenate(sub), so, 7.5e-5)
             cal["sample"] = "%d chunks spread evenly over the %d of %s" % (n, nb, what)
             choice[0] = P.PRECISIONS[cal["chosen"]]
+            choice[1] = cal.get("lite_mask", 0)
         if world > 1:
             dist.broadcast(choice, 0)
             if rank != 0:
                 c.set_fast_mode(P.PRECISION_NAMES[int(choice[0])])
+                if int(choice[1]):
+                    c.set_lite_mask(int(choice[1]))
         return cal
 
     # ---- synthetic inputs resident in HBM (N(0,1)*sigma_d, sigma_d = 8*0.9^d) ---------------
@@ -495,7 +504,7 @@ def main():
             "config": {"workload": "%s TDNN, %d chunks x %s frames per GPU per step, utterance-sharded, weights broadcast once over RCCL"
                                    % (args.topology, B, args.ragged or T), "topology": args.topology, "batch_chunks_per_gpu": B,
                        "frames_per_chunk": T if not ragged else None, "precision": args.precision,
-                       "arithmetic": ctx.fast_mode, "calibration": calibration, "kernel_precisions": kernel_precs,
+                       "arithmetic": arithmetic_name(ctx), "calibration": calibration, "kernel_precisions": kernel_precs,
                        "lanes": args.lanes, "alg_gflop_per_utt": 2.0 * macs / 1e9, "output_node": args.output_node or "embedding",
                        "chunk_lengths": args.ragged or str(T), "frames_per_step": total_rows},
             "frames_per_sec": world * total_rows * args.steps / dt,
@@ -526,6 +535,8 @@ def main():
             c3 = P.Context(model, device=local_rank, precision=prec)
             if calibration:
                 c3.set_fast_mode(calibration["chosen"])
+                if calibration.get("lite_mask"):
+                    c3.set_lite_mask(calibration["lite_mask"])
             f3 = lambda: c3.forward_batch_device(feats.data_ptr(), offs, outs[1].data_ptr(), outs[1].shape[1], None)  # noqa: E731
             prewarm(torch, f3, 0.3)
             d3 = time_steps(torch, f3, args.steps)

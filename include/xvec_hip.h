@@ -60,8 +60,10 @@ typedef enum {
                           dropped (the producing layer writes that residual as a 4-bit plane): 1.5 passes per product,
                           error independent of how well the pooling averages the activation rounding.  Layers whose K
                           length is not a multiple of 128 run XV_PREC_FP16X3E */
-  XV_PREC_FP16X3E = 8  /* kernel mode of XV_PREC_FP16MX2 passes: XV_PREC_FP16X3 whose planes epilogue writes the fp16
+  XV_PREC_FP16X3E = 8, /* kernel mode of XV_PREC_FP16MX2 passes: XV_PREC_FP16X3 whose planes epilogue writes the fp16
                           plane + its 4-bit residual instead of two fp16 planes */
+  XV_PREC_FP16MXE = 9  /* kernel mode of XV_PREC_FP16MX2 passes: XV_PREC_FP16MX whose planes epilogue writes the fp16 plane +
+                          its 4-bit residual (a "lite" layer, xv_calibration.lite_mask, in front of a 1.5-pass consumer) */
 } xv_precision;
 
 typedef struct xv_model xv_model; /* host side: parsed nnet3 model lowered to a TDNN program */
@@ -158,10 +160,19 @@ typedef struct {
   float err_mx;     /* XV_PREC_FP16MX against XV_PREC_FP16X3 */
   float err_mx2;    /* XV_PREC_FP16MX2 against XV_PREC_FP16X3 */
   int32_t checked_mx;  /* of them, chunks XV_PREC_FP16MX would run fast (what err_mx was measured on; fewer than 16: not chosen) */
+  float err_lite;      /* chosen == XV_PREC_FP16MX2 with lite_mask != 0: error of that mixture over the checked_mx chunks */
+  uint64_t lite_mask;  /* chosen == XV_PREC_FP16MX2: the layers (bit = index in xv_model_describe's table) that compute in 1.25 passes
+                          inside the 1.5-pass context - where XV_PREC_FP16MX as a whole misses tol, the calibration keeps the
+                          second walk (the correction of the activations' fp16 rounding) only on the layers that need it and
+                          takes it off the most expensive ones the tolerance allows, measured on the same chunks; 0: none */
 } xv_calibration;
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out);
-xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision);
+xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision);   /* also clears the lite layers */
 xv_status xv_ctx_fast_mode(const xv_ctx* c, int32_t* precision);
+/* The lite layers of a context running XV_PREC_FP16MX2 (xv_calibration.lite_mask): set applies a choice made elsewhere
+ * (bits of layers that cannot run the 1.25-pass arithmetic are dropped; XV_ERR_ARG in any other fast mode), get reports it. */
+xv_status xv_ctx_set_lite_layers(xv_ctx* c, uint64_t mask);
+xv_status xv_ctx_lite_layers(const xv_ctx* c, uint64_t* mask);
 xv_status xv_calibrate_table(xv_ctx* c, const char* feature_rspecifier, int32_t chunk_size, int32_t min_chunk_size,
                              int32_t pad_input, int32_t max_utts, float tol, xv_calibration* out);
 /* xv_extract_table calibrates on a sample of its own table first (as xv_calibrate_table) when this is enabled (default: off) */
@@ -236,7 +247,7 @@ typedef struct {
   int32_t k_len;    /* multiple of 32 */
   const void* gmax; /* XV_PREC_FP16MX: device uint32 [rows/16], float bits of max |x| per 16-row group of this plane */
   /* XV_PREC_FP16MX2: 4-bit image of (activation - hi), [rows][ld / 2 bytes], and its E8M0 scales [rows][ld / 64 rounded up to a multiple of 4] (what
-   * epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E wrote to out_lo4 / out_lo4_scale), both at logical row 0 */
+   * epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E / XV_PREC_FP16MXE wrote to out_lo4 / out_lo4_scale), both at logical row 0 */
   const void* lo4; const void* lo4_scale;
 } xv_seg_desc;
 typedef struct {
@@ -258,7 +269,7 @@ typedef struct {
   const void* w4; int32_t ldw4; const void* w4_scale;
   void* gmax_out;
   /* XV_PREC_FP16MX2: 4-bit image of the weights for the second K walk (xv_pack_mx_weights) + scales in staging order;
-   * out_lo4 / out_lo4_scale (epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E): see xv_seg_desc */
+   * out_lo4 / out_lo4_scale (epilogue 0 of XV_PREC_FP16MX2 / XV_PREC_FP16X3E / XV_PREC_FP16MXE): see xv_seg_desc */
   const void* w4b; int32_t ldw4b; const void* w4b_scale;
   void* out_lo4; void* out_lo4_scale;
   /* != 0: run tdnn_gemm_kernel_p8 (256 x 256 tiles, K tiles of 64 columns; XV_PREC_FP16, XV_PREC_FP16MX and XV_PREC_FP16MX2,

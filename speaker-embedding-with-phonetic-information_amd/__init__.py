@@ -66,7 +66,15 @@ class GemmDesc(ctypes.Structure):
 class Calibration(ctypes.Structure):
     """xv_calibration: what xv_ctx_calibrate measured and chose."""
     _fields_ = [("chosen", ctypes.c_int32), ("checked", ctypes.c_int32), ("err_mx", ctypes.c_float), ("err_mx2", ctypes.c_float),
-                ("checked_mx", ctypes.c_int32)]
+                ("checked_mx", ctypes.c_int32), ("err_lite", ctypes.c_float), ("lite_mask", ctypes.c_uint64)]
+
+    def as_dict(self):
+        d = {"chosen": PRECISION_NAMES.get(self.chosen, str(self.chosen)), "checked": self.checked, "checked_mx": self.checked_mx,
+             "err_mx": self.err_mx, "err_mx2": self.err_mx2}
+        if self.lite_mask:
+            d["lite_mask"] = int(self.lite_mask)
+            d["err_lite"] = self.err_lite
+        return d
 
 
 # every symbol include/xvec_hip.h declares (tests check the library exports exactly these)
@@ -76,7 +84,7 @@ ABI_SYMBOLS = [
     "xv_ctx_create_from_device_blob", "xv_ctx_free",
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances", "xv_ctx_calibrate", "xv_ctx_set_fast_mode", "xv_ctx_fast_mode",
-    "xv_calibrate_table", "xv_ctx_set_calibration",
+    "xv_calibrate_table", "xv_ctx_set_calibration", "xv_ctx_set_lite_layers", "xv_ctx_lite_layers",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
     "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_pack_mx_residual64", "xv_tile_mx_scales", "xv_pack_mx_weights", "xv_pack_mx_weights64",
 ]
@@ -158,6 +166,8 @@ def lib():
                                    ctypes.POINTER(Calibration)]
     L.xv_ctx_set_fast_mode.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.xv_ctx_fast_mode.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+    L.xv_ctx_set_lite_layers.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    L.xv_ctx_lite_layers.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
     L.xv_calibrate_table.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.c_int32, ctypes.c_float, ctypes.POINTER(Calibration)]
     L.xv_ctx_set_calibration.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float]
@@ -314,14 +324,14 @@ class Context:
         offs = np.ascontiguousarray(row_offsets, dtype=np.int32)
         c = Calibration()
         _check(lib().xv_ctx_calibrate(self._h, feats.ctypes.data, offs.ctypes.data, len(offs) - 1, tol, ctypes.byref(c)))
-        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "checked_mx": c.checked_mx, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
+        return c.as_dict()
 
     def calibrate_table(self, feature_rspecifier, chunk_size=-1, min_chunk_size=100, pad_input=True, max_utts=64, tol=7.5e-5):
         """The same on the first chunk of the first max_utts utterances of a feature table."""
         c = Calibration()
         _check(lib().xv_calibrate_table(self._h, feature_rspecifier.encode(), chunk_size, min_chunk_size, 1 if pad_input else 0,
                                         max_utts, tol, ctypes.byref(c)))
-        return {"chosen": PRECISION_NAMES.get(c.chosen, str(c.chosen)), "checked": c.checked, "checked_mx": c.checked_mx, "err_mx": c.err_mx, "err_mx2": c.err_mx2}
+        return c.as_dict()
 
     @property
     def fast_mode(self):
@@ -332,6 +342,16 @@ class Context:
 
     def set_fast_mode(self, name):
         _check(lib().xv_ctx_set_fast_mode(self._h, PRECISIONS[name]))
+
+    @property
+    def lite_mask(self):
+        """Layers (bit = index) that run the 1.25-pass arithmetic inside the fp16mx2 context (xv_ctx_lite_layers)."""
+        m = ctypes.c_uint64()
+        _check(lib().xv_ctx_lite_layers(self._h, ctypes.byref(m)))
+        return int(m.value)
+
+    def set_lite_mask(self, mask):
+        _check(lib().xv_ctx_set_lite_layers(self._h, ctypes.c_uint64(int(mask))))
 
     def set_calibration(self, enable=True, tol=7.5e-5):
         """extract_table then calibrates on the head of its own table before the first batch."""

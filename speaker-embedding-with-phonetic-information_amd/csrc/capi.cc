@@ -229,6 +229,8 @@ static void FillCalibration(const xv::Engine::Calibration& c, xv_calibration* ou
   out->err_mx = c.err_mx;
   out->err_mx2 = c.err_mx2;
   out->checked_mx = c.checked_mx;
+  out->err_lite = c.err_lite;
+  out->lite_mask = c.lite_mask;
 }
 
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out) {
@@ -254,6 +256,23 @@ xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision) {
 xv_status xv_ctx_fast_mode(const xv_ctx* c, int32_t* precision) {
   if (!c || !precision) return Fail(XV_ERR_ARG, "xv_ctx_fast_mode: null argument");
   *precision = c->eng->fast_mode();
+  return XV_OK;
+}
+
+xv_status xv_ctx_set_lite_layers(xv_ctx* c, uint64_t mask) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_lite_layers: null context");
+  return Guard([&] {
+    if (mask == c->eng->lite_mask()) return XV_OK;
+    if (!c->eng->can_switch_fast_mode() || c->eng->fast_mode() != XV_PREC_FP16MX2)
+      return Fail(XV_ERR_ARG, "xv_ctx_set_lite_layers: the context must be running XV_PREC_FP16MX2");
+    c->eng->SetLiteMask(mask);
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_lite_layers(const xv_ctx* c, uint64_t* mask) {
+  if (!c || !mask) return Fail(XV_ERR_ARG, "xv_ctx_lite_layers: null argument");
+  *mask = c->eng->lite_mask();
   return XV_OK;
 }
 

@@ -431,8 +431,8 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
 }
 
 const char* PrecisionName(int precision) {
-  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e"};
-  return precision == kPrecDefault ? "default" : (precision >= 0 && precision <= 8) ? n[precision] : "?";
+  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e", "fp16mxe"};
+  return precision == kPrecDefault ? "default" : (precision >= 0 && precision <= 9) ? n[precision] : "?";
 }
 
 std::vector<uint8_t> PackModelPolicy(const TdnnProgram& prog, int precision, int* resolved) {
@@ -1210,7 +1210,8 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         fa.g.gmax_out = nullptr;
         fa.g.out_range = nullptr;
         if (region == 0) {
-          eprec = fast_mx2_ ? (int)kPrecFp16x3E : (int)kPrecFp16x2;
+          // (mixed mode: a first layer whose consumers are all lite writes the fp16 plane only)
+          eprec = (fast_mx2_ && (!lite_mask_ || lite_emits_[i])) ? (int)kPrecFp16x3E : (int)kPrecFp16x2;
           if (mx_pass) {
             fa.g.gmax_out = gmax_of((int)i);
             fa.g.out_range = plan.d_act_range + (size_t)i * plan.ngrp * 2;
@@ -1260,7 +1261,24 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         gr.m_valid = (int)(r1 - r0);
         int rprec = prec;
         if (region == 0) {
-          if (fast_mx2_) {
+          if (fast_mx2_ && lite_mask_ && lite_[i] && mx_pass && gemm_mx_applicable(gr)) {
+            // a lite layer of the mixed mode (SetLiteMask): the 1.25-pass product, on the 256 x 256 kernel where no consumer
+            // needs the residual plane of its output, else with the planes epilogue that writes it
+            if (lite_emits_[i] && epi == kEpiAct) {
+              rprec = kPrecFp16MxE;
+            } else {
+              rprec = kPrecFp16Mx;
+              gr.out_lo4 = nullptr;
+              gr.out_lo4s = nullptr;
+              if (use_p8_ && dl.w4p && (epi == kEpiAct || epi == kEpiStats)) {
+                GemmArgs g8 = gr;
+                g8.p8 = 1;
+                g8.w4 = dl.w4p;
+                g8.w4_scale = dl.w4p_scale + (epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0);
+                if (gemm_p8_applicable(g8, kPrecFp16Mx)) gr = g8;
+              }
+            }
+          } else if (fast_mx2_) {
             // every layer emits the 4-bit residual of its fp16 plane; a layer that cannot run the second walk reads the
             // network input only (PackModel checked it) and runs the three-pass arithmetic on the planes of prep_input
             rprec = gemm_mx2_applicable(gr) ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3E;
@@ -1367,7 +1385,42 @@ void Engine::SetFastMode(int mode) {
   fast_mx_ = mode != kPrecFp16x3;
   has_fast_ = mode != kPrecFp16x3;
   fast_min_pooled_ = mode == kPrecFp16Mx2 ? mx2_min_pooled_ : mx_min_pooled_;
+  lite_mask_ = 0;
+  lite_.assign(layers_.size(), 0);
+  lite_emits_.assign(layers_.size(), 0);
   plan_cache_.clear();   // the row regions of a plan depend on the threshold
+}
+
+void Engine::SetLiteMask(uint64_t mask) {
+  if (!can_switch_fast_mode() || fast_mode_ != kPrecFp16Mx2) throw EngineError("SetLiteMask: the context must be running fp16mx2");
+  Check(hipSetDevice(device_), "hipSetDevice");
+  Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  for (const HostSlot& S : host_slots_)
+    if (S.pending) throw EngineError("SetLiteMask with a batch in flight");
+  const size_t nl = layers_.size();
+  lite_.assign(nl, 0);
+  lite_emits_.assign(nl, 0);
+  uint64_t kept = 0;
+  for (size_t i = 0; i < nl && i < 64; ++i) {
+    const BlobLayerInfo& li = info_.layers[i];
+    // a layer can be lite when it is a frame-level GEMM over other layers' planes with the residual image of the 1.25-pass
+    // arithmetic (the layers that read the network input run the first-layer kernel in its own arithmetic)
+    bool ok = ((mask >> i) & 1) && !li.segment_level && li.has_w4 && !layers_[i].first;
+    for (const LayerSource& src : li.src) ok = ok && src.layer >= 0 && !info_.layers[src.layer].segment_level;
+    if (ok) {
+      lite_[i] = 1;
+      kept |= 1ull << i;
+    }
+  }
+  // who still has to write the residual plane of its output: a layer with a frame-level consumer that walks it
+  for (size_t c = 0; c < nl; ++c) {
+    if (info_.layers[c].segment_level || lite_[c]) continue;
+    for (const LayerSource& src : info_.layers[c].src)
+      if (src.layer >= 0) lite_emits_[src.layer] = 1;
+  }
+  lite_mask_ = kept;
+  fast_min_pooled_ = kept ? std::max(mx2_min_pooled_, mx_min_pooled_) : mx2_min_pooled_;
+  plan_cache_.clear();
 }
 
 Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_offsets, int B, float tol) {
@@ -1438,6 +1491,51 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   const bool mx_ok = n_mx >= kCalibMinChunks && c.err_mx <= tol;
   c.chosen = mx_ok ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
   SetFastMode(c.chosen);
+  if (c.chosen == kPrecFp16Mx2 && n_mx >= kCalibMinChunks && c.err_mx2 <= tol) {
+    // Between the two: the 1.5-pass context with its most expensive layers in 1.25 passes, as many of them as the tolerance
+    // allows on the same evidence (what the second walk corrects - the activations' fp16 rounding - matters less the further
+    // a layer is from the pooled statistics: on the c-vector network the 650-wide phonetic branch takes it, the x-vector
+    // branch does not).  Layers by cost, the longest prefix found by bisection (the error grows with the prefix); every
+    // candidate is measured, so the choice is within the tolerance whether or not the growth is monotonic.
+    std::vector<int> order;
+    for (size_t i = 0; i < layers_.size() && i < 64; ++i) {
+      const BlobLayerInfo& li = info_.layers[i];
+      bool ok = !li.segment_level && li.has_w4 && !layers_[i].first;
+      for (const LayerSource& src : li.src) ok = ok && src.layer >= 0 && !info_.layers[src.layer].segment_level;
+      if (ok) order.push_back((int)i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return (long)info_.layers[a].k_pad * info_.layers[a].n_pad > (long)info_.layers[b].k_pad * info_.layers[b].n_pad;
+    });
+    auto mask_of = [&](int k) {
+      uint64_t m = 0;
+      for (int j = 0; j < k; ++j) m |= 1ull << order[j];
+      return m;
+    };
+    std::vector<float> got((size_t)n * E);
+    int lo = 0, hi = (int)order.size();   // lo: known good (0 = the plain mode), hi: first count not known good + ... (all = fp16mx, failed)
+    float err_lo = 0.f;
+    try {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        SetLiteMask(mask_of(mid));
+        ForwardHost(f.data(), offs.data(), n, got.data());
+        const float e = worst(got, true);
+        if (e <= tol) {
+          lo = mid;
+          err_lo = e;
+        } else {
+          hi = mid;
+        }
+      }
+      SetLiteMask(mask_of(lo));
+    } catch (...) {
+      SetFastMode(before);
+      throw;
+    }
+    c.lite_mask = lite_mask_;
+    c.err_lite = lite_mask_ ? err_lo : 0.f;
+  }
   return c;
 }
 

@@ -137,11 +137,20 @@ class Engine {
     float err_mx2 = 0.f;      // the same for kPrecFp16Mx2
     int checked_mx = 0;       // chunks among `checked` that kPrecFp16Mx runs fast: err_mx is over these, and fewer than
                               // kCalibMinChunks of them never select kPrecFp16Mx
+    uint64_t lite_mask = 0;   // chosen == kPrecFp16Mx2 only: the layers (bit = layer index) that run the 1.25-pass arithmetic
+                              // inside the 1.5-pass context (SetLiteMask) - the most expensive ones the tolerance allows
+    float err_lite = 0.f;     // worst error of that mixture over the `checked_mx` chunks (0 when lite_mask == 0)
   };
   static constexpr int kCalibMinChunks = 16;
   bool can_switch_fast_mode() const { return info_.precision == kPrecFp16Mx2 && !frame_mode_; }
   int fast_mode() const { return can_switch_fast_mode() ? fast_mode_ : info_.precision; }
-  void SetFastMode(int mode);   // throws unless can_switch_fast_mode() and mode is one of the three
+  void SetFastMode(int mode);   // throws unless can_switch_fast_mode() and mode is one of the three; clears the lite mask
+  // Mixed arithmetic inside the kPrecFp16Mx2 mode: the frame-level layers named by `mask` (bit = layer index; bits of layers
+  // that cannot run it are ignored) compute their products in 1.25 passes (kPrecFp16Mx: no walk over the residual plane of
+  // their inputs); a lite layer still writes the residual plane of its own output when a consumer walks it (kPrecFp16MxE).
+  // Fast chunks are then those of the kPrecFp16Mx threshold.  Throws unless the current fast mode is kPrecFp16Mx2.
+  void SetLiteMask(uint64_t mask);
+  uint64_t lite_mask() const { return lite_mask_; }
   Calibration Calibrate(const float* feats, const int32_t* row_offsets, int B, float tol);
 
   hipStream_t stream() const { return stream_; }
@@ -255,6 +264,8 @@ class Engine {
   bool logits16() const { return frame_mode_ && info_.precision == kPrecFp16 && info_.layers[info_.output_layer].log_softmax; }
   int fast_min_pooled_ = 0;
   int fast_mode_ = 0;       // see SetFastMode
+  uint64_t lite_mask_ = 0;  // see SetLiteMask
+  std::vector<char> lite_, lite_emits_;   // per layer: runs the 1.25-pass arithmetic in the kPrecFp16Mx2 mode / and still emits its residual plane
   int mx2_min_pooled_ = 0, mx_min_pooled_ = 0;   // thresholds of the two fast modes (XVEC_FAST_MIN_POOLED overrides both)
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;   // host-slot uploads (SubmitHost)

@@ -51,14 +51,17 @@ enum Precision : int {
                     // error no longer depends on how well the pooling averages the activation rounding.
   kPrecFp16x3E = 8, // kPrecFp16x3 whose planes epilogue emits (fp16 plane, 4-bit residual) instead of (hi, lo): the layers
                     // of a kPrecFp16Mx2 pass that cannot run it themselves (K walk not in whole 128-column blocks)
+  kPrecFp16MxE = 9, // kPrecFp16Mx whose planes epilogue emits (fp16 plane, 4-bit residual): a layer of a kPrecFp16Mx2 pass that
+                    // the calibration lets run the 1.25-pass arithmetic ("lite" layers, Engine::SetLiteMask) in front of a
+                    // consumer that still walks the residual plane
 };
-constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16x3E; }
-constexpr bool PrecMx(int p) { return p == kPrecFp16Mx || p == kPrecFp16Mx2; }
+constexpr bool PrecF16(int p) { return p == kPrecFp16 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16x3E || p == kPrecFp16MxE; }
+constexpr bool PrecMx(int p) { return p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16MxE; }
 constexpr bool PrecMx2(int p) { return p == kPrecFp16Mx2; }
-constexpr bool PrecEmitsLo4(int p) { return p == kPrecFp16Mx2 || p == kPrecFp16x3E; }   // planes epilogue: fp16 plane + 4-bit residual
+constexpr bool PrecEmitsLo4(int p) { return p == kPrecFp16Mx2 || p == kPrecFp16x3E || p == kPrecFp16MxE; }   // planes epilogue: fp16 plane + 4-bit residual
 constexpr int PrecXPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x3E) ? 2 : 1; }   // kernel modes only
 // weight planes staged per K step (the 4-bit residual plane of kPrecFp16Mx uses the slot of the fp16 residual plane)
-constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16x3E) ? 2 : 1; }
+constexpr int PrecWPlanes(int p) { return (p == kPrecBf16x3 || p == kPrecFp16x3 || p == kPrecFp16x2 || p == kPrecAuto || p == kPrecFp16Mx || p == kPrecFp16Mx2 || p == kPrecFp16x3E || p == kPrecFp16MxE) ? 2 : 1; }
 constexpr int PrecPasses(int p) { return PrecXPlanes(p) + PrecWPlanes(p) - 1; }   // MFMAs per algorithmic product (Mx: 1.25)
 
 enum Epilogue : int {

@@ -67,8 +67,8 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop) {
 static thread_local char g_last_kernel[96] = "";
 const char* last_gemm_kernel() { return g_last_kernel; }
 static const char* prec_name(int p) {
-  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e"};
-  return (p >= 0 && p <= 8) ? n[p] : "?";
+  static const char* n[] = {"bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "auto", "fp16mx", "fp16mx2", "fp16x3e", "fp16mxe"};
+  return (p >= 0 && p <= 9) ? n[p] : "?";
 }
 static const char* epi_name(int e) { return e == kEpiAct ? "act" : e == kEpiF32 ? "f32" : e == kEpiStats ? "stats" : "splitk"; }
 static void note_kernel(const char* variant, int prec, int epi, int mf) {
@@ -3138,26 +3138,27 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
     if (PrecMx2(PREC) ? !gemm_mx2_applicable(a) : !gemm_mx_applicable(a)) return hipErrorInvalidValue;
     if (variant != 2 && variant != 1 && sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
     return launch_one_v2<PREC, EPI>(a, s);
+  } else {
+    if (variant == 4 || (variant == 0 && sk_default)) {
+      if (sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
+      if ((variant == 4 || PrecXPlanes(PREC) == 2) && sk_applicable<PREC, 4>(a)) return launch_one_sk<PREC, EPI, 4>(a, s);
+    }
+    if (variant != 1 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
+    constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
+    static std::atomic<unsigned long long> attr_done{0};
+    int attr_dev = 0;
+    if (lds_attr_needed(&attr_done, &attr_dev)) {
+      hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, EPI>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
+    }
+    const int mt8 = (a.m_tiles + 7) / 8 * 8;
+    dim3 grid(mt8 * a.n_tiles), block(256);
+    note_kernel("", PREC, EPI, 0);
+    XV_LAUNCH((tdnn_gemm_kernel<PREC, EPI>), grid, block, lds, s, a);
+    return hipGetLastError();
   }
-  if (variant == 4 || (variant == 0 && sk_default)) {
-    if (sk_max_mf() == 8 && sk_applicable<PREC, 8>(a)) return launch_one_sk<PREC, EPI, 8>(a, s);
-    if ((variant == 4 || PrecXPlanes(PREC) == 2) && sk_applicable<PREC, 4>(a)) return launch_one_sk<PREC, EPI, 4>(a, s);
-  }
-  if (variant != 1 && (a.m_tiles & 1) == 0) return launch_one_v2<PREC, EPI>(a, s);
-  constexpr int lds = kTileBytes * (PrecXPlanes(PREC) + PrecWPlanes(PREC)) * 2;
-  static std::atomic<unsigned long long> attr_done{0};
-  int attr_dev = 0;
-  if (lds_attr_needed(&attr_done, &attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)tdnn_gemm_kernel<PREC, EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done.fetch_or(1ull << (attr_dev & 63), std::memory_order_release);
-  }
-  const int mt8 = (a.m_tiles + 7) / 8 * 8;
-  dim3 grid(mt8 * a.n_tiles), block(256);
-  note_kernel("", PREC, EPI, 0);
-  XV_LAUNCH((tdnn_gemm_kernel<PREC, EPI>), grid, block, lds, s, a);
-  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3246,23 +3247,26 @@ static hipError_t launch_prec(const GemmArgs& a, int epi, hipStream_t s) {
   if constexpr (PREC == kPrecFp16x3E) {   // planes out only (the layers in front of a kPrecFp16Mx2 consumer)
     if (a.ksplit > 1 || epi != kEpiAct || !a.out_lo4 || !a.out_lo4s) return hipErrorInvalidValue;
     return launch_one<PREC, kEpiAct>(a, s);
-  }
-  if constexpr (PrecMx(PREC)) {   // frame-level layers only: planes out or pooled statistics
+  } else if constexpr (PREC == kPrecFp16MxE) {   // planes out only: the 1.25-pass product in front of a kPrecFp16Mx2 consumer
+    if (a.ksplit > 1 || epi != kEpiAct || !a.out_lo4 || !a.out_lo4s || a.p8) return hipErrorInvalidValue;
+    return launch_one<PREC, kEpiAct>(a, s);
+  } else if constexpr (PrecMx(PREC)) {   // frame-level layers only: planes out or pooled statistics
     if (a.ksplit > 1) return hipErrorInvalidValue;
     if (epi == kEpiAct) return launch_one<PREC, kEpiAct>(a, s);
     if (epi == kEpiStats) return launch_one<PREC, kEpiStats>(a, s);
     return hipErrorInvalidValue;
-  }
-  if (a.ksplit > 1 && a.splitk_ws) {
-    if (epi == kEpiAct) return launch_splitk<PREC, kEpiAct>(a, s);
-    if (epi == kEpiF32) return launch_splitk<PREC, kEpiF32>(a, s);
-    return hipErrorInvalidValue;
-  }
-  switch (epi) {
-    case kEpiAct: return launch_one<PREC, kEpiAct>(a, s);
-    case kEpiF32: return launch_one<PREC, kEpiF32>(a, s);
-    case kEpiStats: return launch_one<PREC, kEpiStats>(a, s);
-    default: return hipErrorInvalidValue;
+  } else {
+    if (a.ksplit > 1 && a.splitk_ws) {
+      if (epi == kEpiAct) return launch_splitk<PREC, kEpiAct>(a, s);
+      if (epi == kEpiF32) return launch_splitk<PREC, kEpiF32>(a, s);
+      return hipErrorInvalidValue;
+    }
+    switch (epi) {
+      case kEpiAct: return launch_one<PREC, kEpiAct>(a, s);
+      case kEpiF32: return launch_one<PREC, kEpiF32>(a, s);
+      case kEpiStats: return launch_one<PREC, kEpiStats>(a, s);
+      default: return hipErrorInvalidValue;
+    }
   }
 }
 
@@ -3277,6 +3281,7 @@ hipError_t launch_tdnn_gemm(const GemmArgs& a, int precision, int epilogue, hipS
     case kPrecFp16Mx: return launch_prec<kPrecFp16Mx>(a, epilogue, s);
     case kPrecFp16Mx2: return launch_prec<kPrecFp16Mx2>(a, epilogue, s);
     case kPrecFp16x3E: return launch_prec<kPrecFp16x3E>(a, epilogue, s);
+    case kPrecFp16MxE: return launch_prec<kPrecFp16MxE>(a, epilogue, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -83,6 +83,16 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
     m << "calibration on " << c.checked << " chunks against the three-pass arithmetic: fp16mx " << c.err_mx << " (on the " << c.checked_mx
       << " chunks it runs fast; it takes " << Engine::kCalibMinChunks << " to choose it), fp16mx2 " << c.err_mx2 << " (tolerance "
       << opt.calibrate_tol << ") -> " << PrecisionName(c.chosen);
+    if (c.lite_mask) {
+      m << " with " << __builtin_popcountll(c.lite_mask) << " of its layers in 1.25 passes (";
+      bool first = true;
+      for (size_t i = 0; i < engine->info().layers.size() && i < 64; ++i)
+        if ((c.lite_mask >> i) & 1) {
+          m << (first ? "" : ", ") << engine->info().layers[i].name;
+          first = false;
+        }
+      m << ": " << c.err_lite << ")";
+    }
   }
   log("LOG", m.str());
   return c;

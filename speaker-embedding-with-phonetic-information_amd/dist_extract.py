@@ -140,7 +140,7 @@ def main(argv=None):
     scp = os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, job))
     done = failed = error = 0
     ctx = None
-    mode = torch.tensor([-1], dtype=torch.int64, device=dev)
+    mode = torch.tensor([-1, 0], dtype=torch.int64, device=dev)   # rank 0's calibration: arithmetic, lite-layer mask
     try:
         if not args.dry_run:
             if use_cuda:
@@ -162,14 +162,17 @@ def main(argv=None):
                                           64, args.calibrate_tol)
                 print("rank 0 calibration: %s" % cal, flush=True)
                 mode[0] = P.PRECISIONS[cal["chosen"]]
+                mode[1] = cal.get("lite_mask", 0)
     except Exception as e:   # noqa: BLE001 - counted below with the extraction errors
         print("ERROR (dist_extract) rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
         error = 1
     if grouped and not args.dry_run:
-        dist.broadcast(mode, 0)          # one integer: the arithmetic rank 0 chose (bookkeeping, not a data-path collective)
+        dist.broadcast(mode, 0)          # two integers: the arithmetic rank 0 chose (bookkeeping, not a data-path collective)
     try:
         if ctx is not None and not error and int(mode[0]) >= 0 and rank != 0:
             ctx.set_fast_mode(P.PRECISION_NAMES[int(mode[0])])
+            if int(mode[1]):
+                ctx.set_lite_mask(int(mode[1]))
         if error:
             pass
         elif args.dry_run:

@@ -418,14 +418,19 @@ def test_calibration_picks_the_lighter_mode_only_where_it_is_accurate():
         assert cal["checked"] == 19 and cal["checked_mx"] == 18   # the 120-frame chunk runs three-pass in every mode: not compared
         assert cal["err_mx2"] < 7e-5 and (cal["err_mx"] <= 7.5e-5) == (want == "fp16mx"), cal
         out = ctx.forward_batch(feats, offs)
-        same = P.Context(model, precision=P.PRECISIONS["auto" if want == "fp16mx" else "fp16mx2"]).forward_batch(feats, offs)
-        assert np.array_equal(out, same)
+        twin = P.Context(model, precision=P.PRECISIONS["auto" if want == "fp16mx" else "fp16mx2"])
+        if cal.get("lite_mask"):   # fp16mx2 with some layers in 1.25 passes (the next test): still within the tolerance it measured
+            assert cal["err_lite"] <= 7.5e-5 and ctx.lite_mask == cal["lite_mask"], cal
+            twin.set_lite_mask(cal["lite_mask"])
+        assert np.array_equal(out, twin.forward_batch(feats, offs))
         ev64 = _oracle(net, line, np.float64)
         for i, u in enumerate(utts):
             assert H.rel_err(out[i:i + 1], ev64.compute(u)) < TOL_PARITY, (which, i)
         # a choice made elsewhere (the other ranks of a multi-GPU job) is applied with set_fast_mode
         other = P.Context(model)
         other.set_fast_mode(want)
+        if cal.get("lite_mask"):
+            other.set_lite_mask(cal["lite_mask"])
         assert np.array_equal(other.forward_batch(feats, offs), out)
     # a handful of qualifying chunks is not a measurement: the packed mode stays, whatever they show
     net, line = H.synth_model("v2_xvector", 123)
@@ -439,3 +444,54 @@ def test_calibration_picks_the_lighter_mode_only_where_it_is_accurate():
     assert cal["checked"] == 0 and cal["chosen"] == "fp16x3"
     with pytest.raises(P.XvError):
         c3.set_fast_mode("fp16mx")
+
+
+def test_calibration_mixes_the_two_fast_arithmetics_on_the_cvector_network():
+    """Where fp16mx as a whole misses the tolerance (the c-vector network: 8 - 9e-5 against 7.5e-5), the calibration keeps the
+    1.5-pass context and takes the second walk off the most expensive layers the tolerance allows (xv_calibration.lite_mask:
+    on this network the 650-wide phonetic branch, train_am.sh:30-38).  The mixture is a property of the context like the
+    mode: applied elsewhere with set_lite_mask it computes the same bits, whatever the batch."""
+    P = H.pkg()
+    net, line = H.synth_model("v5_cvector", 123)
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    utts = [H.features(80 + i, T) for i, T in enumerate([400, 333, 350] * 6 + [200, 120])]
+    feats, offs = H.pack(utts)
+    ctx = P.Context(model)
+    tol = 7.5e-5
+    cal = ctx.calibrate(feats, offs, tol)
+    print(cal)
+    print(model.describe())
+    assert cal["checked_mx"] == 18
+    if cal["chosen"] == "fp16mx":
+        # on these 18 chunks the lighter mode passes outright (6.8e-5; 8.0e-5 on the bench's 64): the same question with a
+        # tolerance it misses
+        assert cal["err_mx"] <= tol and ctx.lite_mask == 0
+        tol = 0.9 * cal["err_mx"]
+        ctx = P.Context(model)
+        cal = ctx.calibrate(feats, offs, tol)
+        print(cal)
+    assert cal["chosen"] == "fp16mx2" and cal["err_mx"] > tol and cal["err_mx2"] <= tol, cal
+    mask = cal.get("lite_mask", 0)
+    assert mask and ctx.lite_mask == mask and 0 < cal["err_lite"] <= tol, cal
+    out = ctx.forward_batch(feats, offs)
+    ev64 = _oracle(net, line, np.float64)
+    for i in (0, 1, 2, 18, 19):
+        assert H.rel_err(out[i:i + 1], ev64.compute(utts[i])) < TOL_PARITY, i
+    # not the plain 1.5-pass arithmetic, and not the 1.25-pass one either
+    plain = P.Context(model, precision=P.PRECISIONS["fp16mx2"])
+    assert not np.array_equal(plain.forward_batch(feats, offs)[:18], out[:18])
+    # the same mixture on another context; an utterance's embedding does not depend on its batch
+    other = P.Context(model)
+    other.set_lite_mask(mask)
+    assert other.lite_mask == mask and np.array_equal(other.forward_batch(feats, offs), out)
+    f1, o1 = H.pack(utts[3:5])
+    assert np.array_equal(other.forward_batch(f1, o1), out[3:5])
+    # bits of layers that cannot run the 1.25-pass arithmetic are dropped; a change of mode clears the mixture
+    other.set_lite_mask((1 << 62) - 1)
+    kept = other.lite_mask
+    assert kept and kept & mask == mask and kept != (1 << 62) - 1
+    assert H.rel_err(other.forward_batch(f1, o1), out[3:5]) < 2e-4
+    other.set_fast_mode("fp16mx")
+    assert other.lite_mask == 0
+    with pytest.raises(P.XvError):
+        other.set_lite_mask(mask)          # only inside the 1.5-pass context

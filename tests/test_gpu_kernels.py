@@ -386,7 +386,7 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6, p8=0
         gm_out = torch.zeros(rows // 16, dtype=torch.int32, device=dev)
         d.out_hi, d.out_lo, d.ldo = oh.data_ptr(), None, n_pad
         d.gmax_out = gm_out.data_ptr()
-        if prec == 7:
+        if prec in (7, 9):
             o4 = torch.zeros(rows, n_pad // 2, dtype=torch.uint8, device=dev)
             o4s = torch.zeros(rows, (n_pad // 64 + 3) // 4 * 4, dtype=torch.uint8, device=dev)
             d.out_lo4, d.out_lo4_scale = o4.data_ptr(), o4s.data_ptr()
@@ -396,7 +396,9 @@ def _run_mx_case(epi, rows, n_pad, segs, seed=0, variant_rows=None, prec=6, p8=0
         want = z.float().abs().reshape(rows // 16, 16, -1).amax(dim=(1, 2))[:run_rows // 16]
         got = gm_out.view(torch.float32)[:run_rows // 16]
         assert torch.allclose(got, want, rtol=1e-4, atol=0), (got[:4], want[:4])
-        if prec == 7:   # the output plane with its own 4-bit residual: two to three bits better than fp16 alone
+        if prec in (7, 9):   # the output plane with its own 4-bit residual: two to three bits better than fp16 alone
+            if prec == 9:
+                return oh.double().cpu().numpy() + _decode_lo4(o4, o4s, n_pad), z.cpu().numpy(), oh.cpu().numpy()
             return oh.double().cpu().numpy() + _decode_lo4(o4, o4s, n_pad), z.cpu().numpy()
         return oh.double().cpu().numpy(), z.cpu().numpy()
     ngrp = rows // 16
@@ -477,6 +479,18 @@ def test_gemm_mx2_per_tile_kernel(epi, segs):
         assert (np.abs(out - ref) / scale).max() < 3e-5
     else:
         assert np.abs(out - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13
+
+
+@pytest.mark.parametrize("rows", [66 * 512, 768], ids=["stream_k", "per_tile"])
+@pytest.mark.parametrize("segs", [TDNN3, AM_MX], ids=["tdnn3", "am768"])
+def test_gemm_mxe_is_the_mx_product_with_the_residual_plane_of_its_output(rows, segs):
+    """Precision 9 (kPrecFp16MxE, the lite layers of a calibrated fp16mx2 context in front of a consumer that walks the
+    residual plane): the 1.25-pass product - its fp16 plane is bit-identical to precision 6's - and, next to it, the 4-bit
+    residual of that plane, which brings plane + residual two to three bits closer to the exact result."""
+    full, ref, hi = _run_mx_case(0, rows, 512, segs, seed=23, prec=9)
+    plain, ref6 = _run_mx_case(0, rows, 512, segs, seed=23, prec=6)
+    assert np.array_equal(hi.astype(np.float64), plain)
+    assert np.abs(full - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13
 
 
 # ---------------------------------------------------------------------------------------------------------------------

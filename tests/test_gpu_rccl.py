@@ -138,6 +138,40 @@ def test_two_ranks_on_one_gpu_equal_one_rank_byte_for_byte(tmp_path):
     assert cat == (one / "xvector_t.1.ark").read_bytes()
 
 
+def test_two_ranks_apply_the_mixture_rank_0_calibrated(tmp_path):
+    """The c-vector network, where the calibration mixes the two fast arithmetics (xv_calibration.lite_mask): rank 0 measures on
+    a sample of the whole list, arithmetic AND layer mask travel to the other rank, and the two-rank job writes the bytes of
+    the one-rank job."""
+    import ast
+    import re
+    net, line = H.synth_model("v5_cvector", 123)
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    lens = [400, 333, 350] * 6 + [200, 120, 400, 64]
+    utts = [("utt%02d" % i, H.features(80 + i, T)) for i, T in enumerate(lens)]
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"))
+    node = ["--output-node", line.split("input=")[1]]     # (argparse keeps the last --output-node)
+
+    def cal_of(log):
+        return ast.literal_eval(re.search(r"rank 0 calibration: (\{.*\})", log).group(1))
+    extra = ["--backend", "gloo", "--force-device", "0"] + node
+    one, log1 = _run_dist_extract(tmp_path, 1, "probe", extra)
+    cal = cal_of(log1)
+    if not cal.get("lite_mask"):      # fp16mx passed outright on this sample: ask again with a tolerance it misses
+        assert cal["chosen"] == "fp16mx", cal
+        extra += ["--calibrate-tol", "%.3e" % (0.9 * cal["err_mx"])]
+        one, log1 = _run_dist_extract(tmp_path, 1, "one", extra)
+        cal = cal_of(log1)
+    assert cal["chosen"] == "fp16mx2" and cal["lite_mask"], cal
+    two, log2 = _run_dist_extract(tmp_path, 2, "two", extra)
+    assert cal_of(log2) == cal
+    assert "Done 22 utterances, failed for 0 (over 2 ranks)" in log2
+    v1 = dict(kio.read_scp(str(one / "xvector_t.scp"), "vector"))
+    v2 = dict(kio.read_scp(str(two / "xvector_t.scp"), "vector"))
+    assert list(v1) == list(v2) == [k for k, _ in utts]
+    for k in v1:
+        assert v1[k].tobytes() == v2[k].tobytes(), k
+
+
 def test_bench_two_ranks_on_one_gpu_prints_one_line():
     """bench.py's N > 1 path (process group, size + weight broadcast, per-rank context from the broadcast image, barrier +
     max-over-ranks timing) executed for real: two ranks sharing device 0 over gloo.  The throughput of such a run means
