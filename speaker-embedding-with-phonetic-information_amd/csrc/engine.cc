@@ -1491,12 +1491,17 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   const bool mx_ok = n_mx >= kCalibMinChunks && c.err_mx <= tol;
   c.chosen = mx_ok ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
   SetFastMode(c.chosen);
-  if (c.chosen == kPrecFp16Mx2 && n_mx >= kCalibMinChunks && c.err_mx2 <= tol) {
-    // Between the two: the 1.5-pass context with its most expensive layers in 1.25 passes, as many of them as the tolerance
-    // allows on the same evidence (what the second walk corrects - the activations' fp16 rounding - matters less the further
-    // a layer is from the pooled statistics: on the c-vector network the 650-wide phonetic branch takes it, the x-vector
-    // branch does not).  Layers by cost, the longest prefix found by bisection (the error grows with the prefix); every
-    // candidate is measured, so the choice is within the tolerance whether or not the growth is monotonic.
+  // (the mixture runs fast what fp16mx runs fast - chunks of >= 300 pooled frames - and sends the shorter ones, which plain
+  // fp16mx2 runs fast from 160, to the three-pass arithmetic: on a job with many of those it would lose more than it saves,
+  // so it is considered only where they are at most an eighth of the sample)
+  if (c.chosen == kPrecFp16Mx2 && n_mx >= kCalibMinChunks && c.err_mx2 <= tol && (n - n_mx) * 8 <= n) {
+    // Between the two: the 1.5-pass context with some of its layers in 1.25 passes - as much of the second walk taken off as the
+    // tolerance allows on the same evidence.  What the second walk corrects (the activations' fp16 rounding) matters less the
+    // further a layer is from the pooled statistics: on the c-vector network the 650-wide phonetic branch hardly needs it,
+    // the x-vector branch does.  So every candidate layer is first measured alone; the excess over the plain mode adds up
+    // roughly in squares, and the layers are ranked by second-walk work saved (k_pad x n_pad) per unit of squared error
+    // added.  Then the longest prefix of that ranking within the tolerance, by bisection: every mixture that is adopted was
+    // itself measured on the sample, whatever the ranking assumed.
     std::vector<int> order;
     for (size_t i = 0; i < layers_.size() && i < 64; ++i) {
       const BlobLayerInfo& li = info_.layers[i];
@@ -1504,18 +1509,28 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
       for (const LayerSource& src : li.src) ok = ok && src.layer >= 0 && !info_.layers[src.layer].segment_level;
       if (ok) order.push_back((int)i);
     }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return (long)info_.layers[a].k_pad * info_.layers[a].n_pad > (long)info_.layers[b].k_pad * info_.layers[b].n_pad;
-    });
-    auto mask_of = [&](int k) {
-      uint64_t m = 0;
-      for (int j = 0; j < k; ++j) m |= 1ull << order[j];
-      return m;
-    };
     std::vector<float> got((size_t)n * E);
-    int lo = 0, hi = (int)order.size();   // lo: known good (0 = the plain mode), hi: first count not known good + ... (all = fp16mx, failed)
+    int lo = 0;
     float err_lo = 0.f;
     try {
+      std::vector<double> gain(layers_.size(), 0.0);
+      const double base2 = (double)c.err_mx2 * c.err_mx2;
+      for (int i : order) {
+        SetLiteMask(1ull << i);
+        if (!lite_mask_) continue;
+        ForwardHost(f.data(), offs.data(), n, got.data());
+        const double e = worst(got, true);
+        const double v = std::max(e * e - base2, 1e-4 * base2 + 1e-30);
+        gain[i] = (double)info_.layers[i].k_pad * info_.layers[i].n_pad / v;
+      }
+      order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return gain[i] <= 0.0; }), order.end());
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gain[a] > gain[b]; });
+      auto mask_of = [&](int k) {
+        uint64_t m = 0;
+        for (int j = 0; j < k; ++j) m |= 1ull << order[j];
+        return m;
+      };
+      int hi = (int)order.size() + 1;   // lo: a prefix known to be within the tolerance (0 = the plain mode); hi: one that is not
       while (hi - lo > 1) {
         const int mid = (lo + hi) / 2;
         SetLiteMask(mask_of(mid));
