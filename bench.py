@@ -226,10 +226,14 @@ def time_steps(torch, fn, steps):
     return time.perf_counter() - t0
 
 
-def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_node, ragged, batch, steps):
-    """One of the other BASELINE.json configurations, measured the same way as the headline (never `value`)."""
+def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_node, ragged, batch, steps, trained_seed=None):
+    """One of the other BASELINE.json configurations, measured the same way as the headline (never `value`).
+    trained_seed: the topology with heavy-tailed weights and calibrated BatchNorm statistics (helpers.trained_like_model) - what
+    a trained Kaldi model looks like to the arithmetic, where the random-initialisation model of SURVEY.md section 8(d) is benign."""
     cfgs, _ = H.TOPOLOGIES[topology]
-    if output_node:
+    if trained_seed is not None:
+        net, line = H.trained_like_model(topology, trained_seed)
+    elif output_node:
         net = H.nm.synthesize([H.config_text(c) for c in cfgs], seed=123, head_stddev=1.0)   # non-zero senone head
         line = "output-node name=output input=%s" % output_node
     else:
@@ -268,8 +272,9 @@ def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_n
     else:
         ref = np.stack([ev.compute(f_host[offs[i]:offs[i + 1]])[0] for i in range(nchk)])
         err = H.rel_err(out[:nchk].cpu().numpy(), ref)
-    return {"workload": "%s, %s, %d chunks x %s frames, output %s" % (topology, precision, batch,
-                                                                   "%d-%d" % ragged if ragged else "400", output_node or "embedding"),
+    return {"workload": "%s%s, %s, %d chunks x %s frames, output %s" % (topology, " (trained-like weights, seed %d)" % trained_seed if trained_seed is not None else "",
+                                                                     precision, batch,
+                                                                     "%d-%d" % ragged if ragged else "400", output_node or "embedding"),
             "arithmetic": arithmetic_name(ctx), "calibration": cal,
             "value": batch * steps / dt, "unit": "utt/s", "frames_per_sec": float(lens.sum()) * steps / dt,
             "ms_per_step": dt / steps * 1e3, "alg_gflop_per_utt": 2.0 * macs / 1e9,
@@ -586,6 +591,9 @@ def main():
             # BASELINE.json configs 3 and 5 on this GPU
             oc = {}
             for key, kw in (("v5_cvector", dict(topology="v5_cvector", precision=args.precision, output_node=None, ragged=None)),
+                            # the headline's network with heavy-tailed weights (what a trained model looks like to the arithmetic)
+                            ("v2_trained_like", dict(topology="v2_xvector", precision=args.precision, output_node=None, ragged=None,
+                                                     trained_seed=11)),
                             ("v3_senone_fp16_ragged", dict(topology="v3_multitask", precision="fp16",
                                                            output_node="output_am.log-softmax", ragged=(200, 600))),
                             # the same job in the parity-grade arithmetic nnet3-compute defaults to (config 5 names fp16)
