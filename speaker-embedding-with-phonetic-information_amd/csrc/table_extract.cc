@@ -73,7 +73,13 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
     offs.push_back(offs.back() + len);
   }
   const int n = (int)offs.size() - 1;
+  const auto t_cal = std::chrono::steady_clock::now();
   if (n > 0) c = engine->Calibrate(feats.data(), offs.data(), n, opt.calibrate_tol);
+  if (getenv("XVEC_TIMING")) {
+    std::ostringstream t;
+    t << "calibration: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cal).count() << " s for " << n << " chunks";
+    log("LOG", t.str());
+  }
   std::ostringstream m;
   m.precision(3);
   if (c.checked == 0) {
