@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -55,6 +56,15 @@ __device__ __forceinline__ void mfma16_vin(const s16x8& a, const s16x8& b, f32x4
 }
 __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+
+template <class F>
+__device__ __forceinline__ void static_for4(F&& f) {
+  f(std::integral_constant<int, 0>{});
+  f(std::integral_constant<int, 1>{});
+  f(std::integral_constant<int, 2>{});
+  f(std::integral_constant<int, 3>{});
 }
 
 struct PArgs {
@@ -309,6 +319,220 @@ __global__ __launch_bounds__(256) void f4_kernel(const PArgs a) {
   }
 }
 
+
+// ---- variant G: F with the frame tile NOT staged at all: a wave's 64 frames are private to it in this geometry, and the
+// MFMA fragment layout is 16 bytes of one row per lane, so the fragments come straight from memory into registers
+// (global_load_dwordx4, four register stages = three K tiles ahead), only the 128-column weight tile goes through the
+// LDS-DMA and LDS.  Per K tile and wave: 8 vector loads, 4 LDS-DMA instructions, 16 fragment reads, 64 MFMAs.
+// T (K tiles) must be a multiple of 4 and >= 8.   V: bit 0 no W reads, bit 1 no DMA / no X loads, bit 2 no MFMAs
+__device__ __forceinline__ void gload16(s16x8& dst, const void* sbase, unsigned voff, const int imm) {
+  if (imm == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int V>
+__global__ __launch_bounds__(256) void f4g_kernel(const PArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool RD = !(V & 1), DMA = !(V & 2), MM = !(V & 4);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nt = slot % a.n_tiles, mt = (slot / a.n_tiles) * 8 + xcd;
+  if (mt >= a.m_tiles) return;
+  const int m0 = mt * 256, n0 = nt * 128;
+  const unsigned lds_base = (unsigned)(size_t)(AS3 char*)smem;
+  constexpr int kWB = 16384;   // W tile per buffer: 128 rows x 128 B
+  unsigned woff[2], xlane[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rho = wave * 16 + j * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((j * 4 + (lane >> 4)) & 7);
+    woff[j] = (unsigned)(swap_fields(rho) * a.ldw + c * 8) * 2u;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) xlane[q] = (unsigned)((wm * 64 + q * 16 + fi) * a.ldx + fg * 8) * 2u;
+  const int T = a.nshift * a.ks64;
+  // two walkers over the K tiles: the weight side (LDS-DMA, two tiles ahead) and the frame side (vector loads, three ahead)
+  const long x_next = (long)a.dstep * a.ldx * 2, x_wrap = 128 - (long)(a.nshift - 1) * a.dstep * a.ldx * 2;
+  const long w_next = (long)a.ks64 * 128, w_wrap = 128 - (long)(a.nshift - 1) * a.ks64 * 128;
+  int ijw = 0, ijx = 0;
+  const char* xb = (const char*)a.x + (long)(m0 + a.shift0) * a.ldx * 2;
+  const char* wb = (const char*)a.w + (long)n0 * a.ldw * 2;
+  auto adv_w = [&]() __attribute__((always_inline)) {
+    if (++ijw == a.nshift) { ijw = 0; wb += w_wrap; } else { wb += w_next; }
+  };
+  auto adv_x = [&]() __attribute__((always_inline)) {
+    if (++ijx == a.nshift) { ijx = 0; xb += x_wrap; } else { xb += x_next; }
+  };
+  const long w64 = (long)a.ldw * 128;
+  auto issue_w = [&](const int buf) __attribute__((always_inline)) {   // the weight tile the weight walker stands on: 4 instructions
+    if constexpr (DMA) {
+      const unsigned dst = lds_base + buf * kWB + wave * 2048;
+      glds16_sbase(wb, woff[0], dst);
+      glds16_sbase(wb, woff[1], dst + 1024);
+      glds16_sbase(wb + w64, woff[0], dst + 8192);
+      glds16_sbase(wb + w64, woff[1], dst + 8192 + 1024);
+    }
+  };
+  s16x8 X[4][2][4];   // [stage][k half][frame fragment]
+  auto issue_x = [&](auto SS, const int q0, const int nq) __attribute__((always_inline)) {   // fragments q0 .. q0 + nq - 1 of the tile the frame walker stands on
+    constexpr int S = decltype(SS)::value;
+    if constexpr (DMA) {
+      static_for4([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        if (q >= q0 && q < q0 + nq) {
+          gload16(X[S][0][q], xb, xlane[q], 0);
+          gload16(X[S][1][q], xb, xlane[q], 64);
+        }
+      });
+    }
+  };
+  const int sw = (fg ^ ((fi >> 1) & 7)) * 16;
+  const int wrd0 = fi * 128 + sw, wrd1 = wrd0 ^ 64;
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[h][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  s16x8 W0[4], W1[4];
+  if constexpr (!RD) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      W0[q] = s16x8{(short)tid, 1, 2, 3, 4, 5, 6, 7};
+      W1[q] = s16x8{(short)tid, 3, 2, 3, 4, 5, 6, 7};
+    }
+  }
+  if constexpr (!DMA) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        X[st][0][q] = s16x8{(short)lane, 1, 2, 3, 4, 5, 6, 7};
+        X[st][1][q] = s16x8{(short)lane, 2, 2, 3, 4, 5, 6, 7};
+      }
+  }
+  // One K tile: stage S of the frame registers, buffer B of the weight tile.  iw: stage the weight tile two ahead (after the
+  // rendezvous, into buffer B); ix: load the frame tile three ahead (stage S ^ 3 ... = (S + 3) & 3), two fragments per phase.
+  auto tile = [&](auto SS, auto BB, const bool iw, const bool ix, const bool steady, const bool next) __attribute__((always_inline)) {
+    constexpr int S = decltype(SS)::value, B = decltype(BB)::value;
+    typedef std::integral_constant<int, (S + 3) & 3> SN;
+    static_for4([&](auto PP) {
+      constexpr int P = decltype(PP)::value;
+      if constexpr (P == 3) {
+        // rendezvous: the weight tile of the next K tile has landed (what was issued after it - six vector loads of this
+        // tile's share of the frame prefetch - may stay in flight), my reads of this tile's buffer have retired
+        __builtin_amdgcn_sched_barrier(0);
+        if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (iw) {
+          adv_w();
+          issue_w(B);
+        }
+      }
+      if (ix) {
+        if constexpr (P == 0) adv_x();
+        issue_x(SN{}, P, 1);
+      }
+      if constexpr (RD) {
+        if constexpr (P == 0) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) W1[p] = *(const s16x8*)(smem + B * kWB + wrd1 + p * 2048);
+        } else if constexpr (P == 1) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) W0[p] = *(const s16x8*)(smem + B * kWB + wrd0 + 8192 + p * 2048);
+        } else if constexpr (P == 2) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) W1[p] = *(const s16x8*)(smem + B * kWB + wrd1 + 8192 + p * 2048);
+        } else {
+          if (next) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) W0[p] = *(const s16x8*)(smem + (B ^ 1) * kWB + wrd0 + p * 2048);
+          }
+        }
+      }
+      if constexpr (MM) {
+        constexpr int H = P >> 1;
+        static_for4([&](auto PW) {
+          static_for4([&](auto QX) {
+            constexpr int p = decltype(PW)::value, q = decltype(QX)::value;
+            if constexpr ((P & 1) == 0) mfma16_acc(W0[p], X[S][0][q], acc[H][p][q]);
+            else mfma16_acc(W1[p], X[S][1][q], acc[H][p][q]);
+          });
+        });
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(X[S][0][q]), "v"(W0[q]), "v"(X[S][1][q]), "v"(W1[q]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 3> I3;
+  // ---- prologue: weight tiles 0 and 1, frame tiles 0, 1, 2
+  issue_w(0);
+  issue_x(I0{}, 0, 4);
+  adv_w();
+  issue_w(1);
+  adv_x();
+  issue_x(I1{}, 0, 4);
+  adv_x();
+  issue_x(I2{}, 0, 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (RD) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) W0[p] = *(const s16x8*)(smem + wrd0 + p * 2048);
+  }
+  // (the frame walker stands on tile 2, the weight walker on tile 1: a tile's issue side advances before it issues)
+  int t = 0;
+#pragma nounroll
+  for (; t + 8 <= T; t += 4) {
+    tile(I0{}, I0{}, true, true, true, true);
+    tile(I1{}, I1{}, true, true, true, true);
+    tile(I2{}, I0{}, true, true, true, true);
+    tile(I3{}, I1{}, true, true, true, true);
+  }
+  tile(I0{}, I0{}, true, true, false, true);    // T - 4: stages the weight tile T - 2, loads the frame tile T - 1
+  tile(I1{}, I1{}, true, false, false, true);   // T - 3: weight tile T - 1
+  tile(I2{}, I0{}, false, false, false, true);
+  tile(I3{}, I1{}, false, false, false, false);
+
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ncol = n0 + h * 64 + fg * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + wm * 64 + q * 16 + fi;
+      unsigned hw[8];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int c = ncol + (p >> 1) * 32 + (p & 1) * 4;
+        const f32x4 b4 = *(const f32x4*)(a.bias + c);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float z0 = fmaxf(acc[h][p][q][2 * j] + b4[2 * j], 0.f), z1 = fmaxf(acc[h][p][q][2 * j + 1] + b4[2 * j + 1], 0.f);
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          hw[p * 2 + j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{z0, z1}, h2));
+        }
+      }
+      uint16_t* dh = a.y + (long)row * a.ldy + ncol;
+      *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+      *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+    }
+  }
+}
+
 static uint16_t f2h(float f) {
   _Float16 h = (_Float16)f;
   uint16_t u;
@@ -352,6 +576,8 @@ static float run_k(kern_t k, const PArgs& a, int iters, hipStream_t s) {
 }
 template <int V>
 static float runf(const PArgs& a, int iters, hipStream_t s) { return run_k(f4_kernel<V>, a, iters, s); }
+template <int V>
+static float rung(const PArgs& a, int iters, hipStream_t s) { return run_k(f4g_kernel<V>, a, iters, s); }
 
 struct Shape {
   const char* name;
@@ -439,6 +665,10 @@ int main(int argc, char** argv) {
       CK(hipMemset(dy, 0xff, ny * 2));
     };
     check("F ", runf<0>(a, iters, s));   // four waves, 256 x 128 tiles
+    check("G ", rung<0>(a, iters, s));   // the same, frame fragments by vector loads into registers
+    if (argc > 3)
+      printf("   G: again %.4f  no W reads %.4f  no loads / dma %.4f  no mfma %.4f  mfma only %.4f  loads + dma only %.4f\n",
+             rung<0>(a, iters, s), rung<1>(a, iters, s), rung<2>(a, iters, s), rung<4>(a, iters, s), rung<3>(a, iters, s), rung<5>(a, iters, s));
     if (argc > 3)
       printf("   F: again %.4f  unpinned %.4f  prio %.4f  no reads %.4f  no dma %.4f  no mfma %.4f  mfma only %.4f  dma only %.4f  reads only %.4f\n",
              runf<0>(a, iters, s), runf<32>(a, iters, s), runf<16>(a, iters, s), runf<1>(a, iters, s), runf<2>(a, iters, s), runf<4>(a, iters, s), runf<3>(a, iters, s),
