@@ -495,3 +495,10 @@ def test_calibration_mixes_the_two_fast_arithmetics_on_the_cvector_network():
     assert other.lite_mask == 0
     with pytest.raises(P.XvError):
         other.set_lite_mask(mask)          # only inside the 1.5-pass context
+    # a job with many chunks between the two thresholds (160 .. 299 pooled frames: fast in plain fp16mx2, three-pass in a
+    # mixture) keeps the plain mode: the mixture would slow those down by more than it saves on the others
+    ragged = utts[:18] + [H.features(300 + i, 200) for i in range(6)]
+    fr, orr = H.pack(ragged)
+    c2 = P.Context(model)
+    cal2 = c2.calibrate(fr, orr, tol)
+    assert cal2["checked"] == 24 and cal2["checked_mx"] == 18 and cal2["chosen"] == "fp16mx2" and not cal2.get("lite_mask"), cal2
