@@ -244,7 +244,7 @@ xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_off
 xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision) {
   if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_fast_mode: null context");
   return Guard([&] {
-    if (precision == c->eng->fast_mode()) return XV_OK;
+    if (precision == c->eng->fast_mode() && c->eng->lite_mask() == 0) return XV_OK;
     if (!c->eng->can_switch_fast_mode() || (precision != XV_PREC_FP16MX2 && precision != XV_PREC_FP16MX && precision != XV_PREC_FP16X3))
       return Fail(XV_ERR_ARG, "xv_ctx_set_fast_mode: the context must be packed as XV_PREC_FP16MX2 (pooled output) and the mode one of "
                               "XV_PREC_FP16MX2, XV_PREC_FP16MX, XV_PREC_FP16X3");

@@ -1375,7 +1375,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
 void Engine::SetFastMode(int mode) {
   if (!can_switch_fast_mode()) throw EngineError("this context cannot switch its arithmetic (it was not packed as fp16mx2 with a pooled output)");
   if (mode != kPrecFp16Mx2 && mode != kPrecFp16Mx && mode != kPrecFp16x3) throw EngineError("SetFastMode: fp16mx2, fp16mx or fp16x3");
-  if (mode == fast_mode_) return;
+  if (mode == fast_mode_ && lite_mask_ == 0) return;   // (the same mode again still clears a mixture)
   Check(hipSetDevice(device_), "hipSetDevice");
   Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
   for (const HostSlot& S : host_slots_)

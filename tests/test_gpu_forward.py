@@ -491,6 +491,8 @@ def test_calibration_mixes_the_two_fast_arithmetics_on_the_cvector_network():
     kept = other.lite_mask
     assert kept and kept & mask == mask and kept != (1 << 62) - 1
     assert H.rel_err(other.forward_batch(f1, o1), out[3:5]) < 2e-4
+    other.set_fast_mode("fp16mx2")          # the mode it is in: the mixture goes, the plain mode stays
+    assert other.lite_mask == 0 and np.array_equal(other.forward_batch(f1, o1), plain.forward_batch(f1, o1))
     other.set_fast_mode("fp16mx")
     assert other.lite_mask == 0
     with pytest.raises(P.XvError):
