@@ -264,7 +264,7 @@ def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_n
     n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
     n2.apply_nnet_config(line)
     ev = H.xo.GraphEvaluator(n2, np.float32)
-    nchk = min(2, batch)
+    nchk = min(2 if frame_level else 8, batch)   # chunks compared with the fp32 oracle (a frame-level one is 4096 columns x every frame)
     f_host = feats[:int(offs[nchk])].cpu().numpy()
     if frame_level:
         ref = np.concatenate([H.xo.compute_all_frames(ev, f_host[offs[i]:offs[i + 1]]) for i in range(nchk)])
@@ -278,7 +278,7 @@ def extra_config(torch, P, H, np, dev, local_rank, topology, precision, output_n
             "arithmetic": arithmetic_name(ctx), "calibration": cal,
             "value": batch * steps / dt, "unit": "utt/s", "frames_per_sec": float(lens.sum()) * steps / dt,
             "ms_per_step": dt / steps * 1e3, "alg_gflop_per_utt": 2.0 * macs / 1e9,
-            "alg_tflops": 2.0 * macs * batch * steps / dt / 1e12, "rel_err_vs_oracle_fp32": err}
+            "alg_tflops": 2.0 * macs * batch * steps / dt / 1e12, "rel_err_vs_oracle_fp32": err, "parity_chunks_vs_oracle": nchk}
 
 
 def main():
