@@ -1255,8 +1255,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       const char* w4s = smem + WBASE + (rblk % 3) * WSLOT + WT + w_rd;
 #pragma unroll
       for (int w = 0; w < 4; ++w) f.wh[w] = *(const s16x8*)(w4s + w * 1024);
-      // scales of the block: one dword = the four fragments of this wave's 64-row half for (fr_i, fr_g)
-      ws_v = *(const int*)(smem + SCB + (rblk % 3) * 512 + wave_n * 256 + (fr_i * 4 + fr_g) * 4);
+      // (scales of the block: ws_v, read in the LOAD segment - read_scales)
       asm volatile("s_nop 4" ::: "memory");
       static_for<0, 4>([&](auto P) {
         static_for<0, 4>([&](auto Q) {
@@ -1268,9 +1267,16 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     }
   };
 
-  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj, const int slab) __attribute__((always_inline)) {
+  // The weight scales of a block (first walk) / of a step (second walk) share one ring of three 512-byte slots, and the slot
+  // of step j + 2 is the slot of step j - 1: they are read in the LOAD segment, like the weight tiles, never in the COMPUTE
+  // segment - wave group 1's COMPUTE of step j - 1 runs beside wave group 0's LOAD of step j, which stages the scales of step
+  // j + 2 into that slot (found by tools/repeat_mx_case.py with a second stream keeping the chip busy: a late wave of group 1
+  // read the scales of a step three ahead; run-to-run differences of 1e-4 on the c-vector network)
+  auto read_scales = [&](const int slot) __attribute__((always_inline)) {
+    return *(const int*)(smem + SCB + slot * 512 + wave_n * 256 + (fr_i * 4 + fr_g) * 4);
+  };
+  auto lo_mfmas = [&](Frags& f, const int ws_lo, const int lg, const int lkk, const int lj, const int slab) __attribute__((always_inline)) {
     if constexpr (MX2) {
-      const int ws_lo = *(const int*)(smem + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + wave_n * 256 + (fr_i * 4 + fr_g) * 4);
       const uint8_t* sl = (const uint8_t*)smem + SLB + slab * SLAB_BYTES + (wave_m * 64 + fr_i + lj * a.grp[lg].dstep) * 4 +
                           2 * (lkk & 1) + (fr_g >> 1);
       int xs_lo = 0;
@@ -1336,6 +1342,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         read_step(f);
+        if (s == 3) ws_v = read_scales(rblk % 3);
         const int n = (j + s + 2 < S) ? issue_step() : 0;
         wait_and_barrier(n);
         __builtin_amdgcn_s_setprio(1);
@@ -1352,10 +1359,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
         const int lg = rg, lkk = rkk, lj = rj;
         if (lj == 0 && (lkk & 1) == 0) ++rslab;
         read_step(f);
+        const int ws_lo = read_scales((j - SH + (SH >> 2)) % 3);
         const int n = (j + 2 < S) ? issue_step() : 0;
         wait_and_barrier(n);
         __builtin_amdgcn_s_setprio(1);
-        lo_mfmas(f, j - SH, lg, lkk, lj, (rslab - 1) % 3);
+        lo_mfmas(f, ws_lo, lg, lkk, lj, (rslab - 1) % 3);
         __builtin_amdgcn_s_setprio(0);
         plain_barrier();
       }
@@ -1895,11 +1903,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       const char* w4s = smem + WBASE + (rblk % 3) * WSLOT + WT + w_rd;
 #pragma unroll
       for (int w = 0; w < WF; ++w) f.wh[w] = *(const s16x8*)(w4s + w * 1024);
-      // scales of the block (staged with its residual tile): one dword per 64-row half = the bytes of its four
-      // fragments for this lane's (fr_i, fr_g); fragment w in byte w & 3 of word w >> 2
-      const char* sc = smem + SCB + (rblk % 3) * 512 + (col_w >> 6) * 256 + (fr_i * 4 + fr_g) * 4;
-#pragma unroll
-      for (int h = 0; h < WW; ++h) ws_v[h] = *(const int*)(sc + h * 256);
+      // (scales of the block, staged with its residual tile: ws_v, read in the LOAD segment - read_scales)
       asm volatile("s_nop 4" ::: "memory");   // v_cvt results -> MFMA operands
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -1918,12 +1922,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   // columns of the step's 128); one block-scaled MFMA per fragment pair.  t_lo = index of the step in the walk, (lg, lkk,
   // lj) = its group / 128-column chunk / offset.  Scales: the weight rows' from the SCB ring (one dword per 64-row half),
   // the activation rows' from the group's slab - byte 2 lkk + (fr_g >> 1) of the row (one scale per 64 columns).
-  auto lo_mfmas = [&](Frags& f, const int t_lo, const int lg, const int lkk, const int lj, const int slab) __attribute__((always_inline)) {
-    if constexpr (MX2) {
-      const char* sc = smem + SCB + ((t_lo + (SH >> 2)) % 3) * 512 + (col_w >> 6) * 256 + (fr_i * 4 + fr_g) * 4;
-      int ws_lo[WW];
+  // Weight scales of ring slot `slot` into ws_v: one dword per 64-row half = the bytes of its four fragments for this lane's
+  // (fr_i, fr_g); fragment w in byte w & 3 of word w >> 2.  Called in the LOAD segment only: the blocks of the first walk and
+  // the steps of the second share the three slots, and the slot of step j + 2 - staged by wave group 0 in its LOAD of step j,
+  // beside wave group 1's COMPUTE of step j - 1 - is the slot of step j - 1 (see tdnn_gemm_kernel_v2).
+  auto read_scales = [&](const int slot) __attribute__((always_inline)) {
+    if constexpr (MX) {
+      const char* sc = smem + SCB + slot * 512 + (col_w >> 6) * 256 + (fr_i * 4 + fr_g) * 4;
 #pragma unroll
-      for (int h = 0; h < WW; ++h) ws_lo[h] = *(const int*)(sc + h * 256);
+      for (int h = 0; h < WW; ++h) ws_v[h] = *(const int*)(sc + h * 256);
+    }
+  };
+  auto lo_mfmas = [&](Frags& f, const int lg, const int lkk, const int lj, const int slab) __attribute__((always_inline)) {
+    if constexpr (MX2) {
+      const int (&ws_lo)[MX ? WW : 1] = ws_v;
       const uint8_t* sl = (const uint8_t*)smem + SLB + slab * SLAB_BYTES + (row_w + fr_i + lj * a.grp[lg].dstep) * 4 +
                           2 * (lkk & 1) + (fr_g >> 1);
       int xs_lo = 0;
@@ -2108,6 +2120,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           // priority (measured -4.5 % on tdnn2 against the opposite assignment the two-pass kernels use)
           __builtin_amdgcn_s_setprio(1);
           read_step(f);
+          if (s == 3) read_scales(rblk % 3);
           const int n = (j + s + 2 < ns) ? issue_step() : 0;
           wait_and_barrier(n);
           __builtin_amdgcn_s_setprio(0);
@@ -2125,10 +2138,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           const int lg = rg, lkk = rkk, lj = rj;
           if ((lj == 0 && (lkk & 1) == 0) || (j == ns_hi && ns_hi == 0)) ++rslab;   // the rule of issue_step
           read_step(f);
+          read_scales((rstep - SH + (SH >> 2)) % 3);
           const int n = (j + 2 < ns) ? issue_step() : 0;
           wait_and_barrier(n);
           __builtin_amdgcn_s_setprio(0);
-          lo_mfmas(f, rstep - SH, lg, lkk, lj, (rslab - 1) % 3);
+          lo_mfmas(f, lg, lkk, lj, (rslab - 1) % 3);
           plain_barrier();
         }
       }

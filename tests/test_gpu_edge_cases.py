@@ -98,6 +98,64 @@ def test_repeatability_and_single_utterance_batch(v2):
         ctx.forward_batch(x[:0], [0])               # empty batch is an argument error, not a crash
 
 
+def test_results_do_not_depend_on_what_else_the_gpu_is_doing():
+    """The same batch again and again while another stream keeps the CUs and the memory system busy and a second context
+    runs the same job from another thread: every result bit-identical to the first.  (Round 4 found a latent race of the
+    1.5-pass kernels this way - a wave of the late wave group read the weight scales of a K step three ahead out of a
+    three-slot ring when it was held up for a microsecond; alone on the chip the timing never allowed it.  The batch is the
+    shape that hit it: 100 chunks, small enough for the per-tile kernel on the c-vector network's layers.)"""
+    import threading
+    torch = pytest.importorskip("torch")
+    P = H.pkg()
+    net, line = H.synth_model("v5_cvector", 123)
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(40000)
+    feats = torch.randn(100 * 400, 23, generator=g, device=dev) * (8.0 * 0.9 ** torch.arange(23, device=dev))
+    offs = np.arange(101, dtype=np.int32) * 400
+    stop = []
+
+    def noise():
+        st = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device=dev, dtype=torch.float16)
+        b = torch.randn(1 << 25, device=dev)
+        with torch.cuda.stream(st):
+            while not stop:
+                for _ in range(4):
+                    (a @ a)
+                    b.add_(1.0)
+                st.synchronize()
+    bad = []
+
+    def worker(tag):
+        ctx = P.Context(model, device=0, precision=P.PRECISIONS["fp16mx2"])
+        outs = [torch.empty(100, 512, device=dev) for _ in range(3)]
+        ref = None
+        for it in range(240):
+            o = outs[it % 3]
+            ctx.forward_batch_device(feats.data_ptr(), offs, o.data_ptr(), 512, None)
+            if it % 3 == 0:
+                ctx.synchronize()
+                r = o.cpu().numpy().copy()
+                if ref is None:
+                    ref = r
+                elif not np.array_equal(ref, r):
+                    bad.append((tag, it, float(np.abs(ref - r).max())))
+        ctx.synchronize()
+    tn = threading.Thread(target=noise)
+    tn.start()
+    try:
+        ts = [threading.Thread(target=worker, args=("t%d" % i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        stop.append(1)
+        tn.join()
+    assert not bad, bad[:5]
+
+
 def test_batch_that_starts_at_a_large_row_offset(v2):
     """xv_forward_batch with row_offsets[0] > 0 (a window of a larger feature buffer).  The engine stages only the rows of
     the batch and hands the kernels a base shifted DOWN by row_offsets[0] rows, so element 0 of that base lies far below the

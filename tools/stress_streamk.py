@@ -1,7 +1,9 @@
 """GPU box: soak test of the stream-K exchange (partial tiles handed from workgroup to workgroup through the coherent
 workspace, flags keyed by a per-launch epoch).  Thousands of forward passes over several batch shapes, two engine lanes
 in flight, every result compared bit for bit with the first one of its shape; the same again with a second context on
-the same GPU running concurrently from another thread.  usage: stress_streamk.py [iterations] [precision]"""
+the same GPU running concurrently from another thread.  usage: stress_streamk.py [iterations] [precision] [topology]
+precision "default" calibrates first (on the c-vector network that is a mixture of 1.25- and 1.5-pass layers: the 256 x 256
+kernel, the 512 x 128 one in both arithmetics and its kPrecFp16MxE variant in one forward pass)."""
 import importlib
 import os
 import sys
@@ -18,17 +20,24 @@ import helpers as H  # noqa: E402
 P = importlib.import_module("speaker-embedding-with-phonetic-information_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 PREC = sys.argv[2] if len(sys.argv) > 2 else "auto"
-os.environ["XVEC_LANES"] = "2"
-net, line = H.synth_model("v2_xvector")
+os.environ.setdefault("XVEC_LANES", "2")
+TOPO = sys.argv[3] if len(sys.argv) > 3 else "v2_xvector"
+net, line = H.synth_model(TOPO)
 model = P.Model(raw=net.to_bytes(True), nnet_config=line)
 dev = torch.device("cuda:0")
 D = 23
 shapes = [np.full(256, 400), np.full(100, 400), np.random.default_rng(3).integers(200, 700, 180), np.full(331, 400)]
+if os.environ.get("STRESS_SHAPES"):   # e.g. "1,3": only these shapes (bisecting a mismatch)
+    shapes = [shapes[int(v)] for v in os.environ["STRESS_SHAPES"].split(",")]
 bad = []
 
 
 def worker(tag):
-    ctx = P.Context(model, device=0, precision=P.PRECISIONS[PREC])
+    ctx = P.Context(model, device=0) if PREC == "default" else P.Context(model, device=0, precision=P.PRECISIONS[PREC])
+    if PREC == "default":
+        cal = ctx.calibrate(*H.pack([H.features(40 + i, 400) for i in range(64)]))
+        if tag in ("solo", "t0"):
+            print(tag, "calibration:", cal, flush=True)
     data = []
     for lens in shapes:
         rows = int(np.sum(lens))
