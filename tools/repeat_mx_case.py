@@ -46,7 +46,7 @@ for prec in PRECS:
                 bad = 0
                 try:
                     for i in range(N):
-                        out = K._run_mx_case(epi, ROWS, n_pad, segs, seed=19, prec=prec)[0]
+                        out = K._run_mx_case(epi, ROWS, n_pad, segs, seed=19, prec=prec, p8=int(os.environ.get("REPEAT_P8", "0")))[0]
                         if ref is None:
                             ref = out
                         elif not np.array_equal(ref, out):
