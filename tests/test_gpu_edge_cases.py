@@ -98,16 +98,18 @@ def test_repeatability_and_single_utterance_batch(v2):
         ctx.forward_batch(x[:0], [0])               # empty batch is an argument error, not a crash
 
 
-def test_results_do_not_depend_on_what_else_the_gpu_is_doing():
+@pytest.mark.parametrize("topology,mode", [("v5_cvector", "fp16mx2"), ("v2_xvector", "auto"), ("v5_cvector", "auto")])
+def test_results_do_not_depend_on_what_else_the_gpu_is_doing(topology, mode):
     """The same batch again and again while another stream keeps the CUs and the memory system busy and a second context
     runs the same job from another thread: every result bit-identical to the first.  (Round 4 found a latent race of the
     1.5-pass kernels this way - a wave of the late wave group read the weight scales of a K step three ahead out of a
     three-slot ring when it was held up for a microsecond; alone on the chip the timing never allowed it.  The batch is the
-    shape that hit it: 100 chunks, small enough for the per-tile kernel on the c-vector network's layers.)"""
+    shape that hit it: 100 chunks, small enough for the per-tile kernel on the c-vector network's layers.  The 1.25-pass
+    arithmetic - the 256 x 256 kernel with few tiles per workgroup - runs the same gauntlet.)"""
     import threading
     torch = pytest.importorskip("torch")
     P = H.pkg()
-    net, line = H.synth_model("v5_cvector", 123)
+    net, line = H.synth_model(topology, 123)
     model = P.Model(raw=net.to_bytes(True), nnet_config=line)
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(40000)
@@ -128,7 +130,7 @@ def test_results_do_not_depend_on_what_else_the_gpu_is_doing():
     bad = []
 
     def worker(tag):
-        ctx = P.Context(model, device=0, precision=P.PRECISIONS["fp16mx2"])
+        ctx = P.Context(model, device=0, precision=P.PRECISIONS[mode])
         outs = [torch.empty(100, 512, device=dev) for _ in range(3)]
         ref = None
         for it in range(240):
