@@ -296,13 +296,17 @@ def test_bad_vad_rspecifier_is_an_error_exit_not_an_abort(job):
     assert "ERROR" in r.stderr.decode()
 
 
-def test_four_concurrent_processes_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("topology,precision,n_utts", [("v2_xvector", "auto", 20000), ("v5_cvector", "default", 6000)],
+                         ids=["x-vector-1.25-pass", "c-vector-default"])
+def test_four_concurrent_processes_share_one_gpu(tmp_path, topology, precision, n_utts):
     """The launch mode the recipes use: run.pl JOB=1:nj starts nj independent nnet3-xvector-compute processes
     (extract_xvectors_new.sh:91-93; nj = 32 on an 8-GPU node = 4 per GPU), each with its own persistent stream-K grids
     that wait on inter-workgroup flags.  Four concurrent processes on this GPU, >= 200 device batches each, exactly the
-    recipe's argv (--use-gpu=no included): all finish, and every output is byte-identical to a solo run."""
+    recipe's argv (--use-gpu=no included): all finish, and every output is byte-identical to a solo run.  (On the c-vector
+    network the default policy: every process calibrates on its own sample of the same table and arrives at the same
+    mixture of 1.25- and 1.5-pass layers.)"""
     import time
-    net, line = H.synth_model("v2_xvector")
+    net, line = H.synth_model(topology)
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
     import tempfile
     d = tempfile.mkdtemp(prefix="xvconc", dir=shm)
@@ -310,7 +314,7 @@ def test_four_concurrent_processes_share_one_gpu(tmp_path):
         open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
         open(os.path.join(d, "extract.config"), "w").write(line + "\n")
         pool = [H.features(3000 + i, 400) for i in range(32)]
-        n_utts, per_batch = 20000, 100          # 200 batches of 100 x 400 frames: large enough for the persistent grid
+        per_batch = 100                         # batches of 100 x 400 frames: large enough for the persistent grid
         with open(os.path.join(d, "feats.ark"), "wb") as f:
             for i in range(n_utts):
                 f.write(("utt%06d " % i).encode() + b"\0B")
@@ -318,7 +322,7 @@ def test_four_concurrent_processes_share_one_gpu(tmp_path):
 
         def cmd(job):
             return [os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=10000",
-                    "--precision=auto", "--batch-frames=%d" % (per_batch * 400),
+                    "--precision=" + precision, "--batch-frames=%d" % (per_batch * 400),
                     "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), d, d),
                     "ark:%s/feats.ark" % d, "ark,scp:%s/xvector.%s.ark,%s/xvector.%s.scp" % (d, job, d, job)]
         t0 = time.perf_counter()
