@@ -784,7 +784,14 @@ void Engine::Ensure(Buf* b, size_t bytes, bool zero) {
   b->p = nullptr;
   Check(hipMalloc(&b->p, bytes), "hipMalloc");
   b->bytes = bytes;
-  if (zero) Check(hipMemset(b->p, 0, bytes), "hipMemset");
+  if (zero) {
+    // hipMemset on device memory is asynchronous to the host and runs on the null stream, which the engine's non-blocking
+    // streams are not ordered behind: the fill has to be over before a kernel may touch the buffer.  (Found in round 4 by
+    // tools/stress_frames.py: with another stream keeping the chip busy the FIRST forward pass of a context could run beside
+    // the zero-fill of its own activation planes.)  Buffers only grow on the first batches of a job.
+    Check(hipMemset(b->p, 0, bytes), "hipMemset");
+    Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  }
 }
 
 void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {

@@ -80,3 +80,47 @@ def test_pooled_log_softmax_output():
     ref = np.stack([ev.compute(u)[0] for u in utts])
     assert H.rel_err(out, ref) < TOL
     assert np.abs(np.exp(out.astype(np.float64)).sum(axis=1) - 1).max() < 1e-3
+
+
+def test_first_forward_pass_of_a_context_on_a_busy_gpu():
+    """A context's first forward pass allocates and zero-fills its activation planes.  hipMemset returns before the fill has
+    run, on the null stream, which the engine's non-blocking streams are not ordered behind: with the chip busy (another
+    stream, another context - the recipes start four processes per GPU) the first pass could run beside the clearing of its
+    own buffers (round 4, tools/stress_frames.py: 2 runs in 5, in every arithmetic, errors up to 390 in bottleneck features).
+    Fresh contexts from two threads under a noise stream: the first result of each equals its later ones."""
+    import threading
+    torch = pytest.importorskip("torch")
+    P, model, ev = _case(["v3_multitask"], "tdnn5_am.batchnorm")
+    lens = [int(t) for t in np.random.default_rng(5).integers(200, 601, 24)]
+    feats, offs = H.pack([H.features(700 + i, T) for i, T in enumerate(lens)])
+    stop, bad = [], []
+
+    def noise():
+        st = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+        with torch.cuda.stream(st):
+            while not stop:
+                for _ in range(4):
+                    (a @ a)
+                st.synchronize()
+
+    def worker(tag):
+        for rep in range(8):
+            ctx = P.Context(model, precision=P.PREC_FP16X3 if rep % 2 else P.PREC_FP16)
+            first = ctx.forward_batch(feats, offs)
+            for k in range(2):
+                if not np.array_equal(first, ctx.forward_batch(feats, offs)):
+                    bad.append((tag, rep, k))
+            ctx.close()
+    tn = threading.Thread(target=noise)
+    tn.start()
+    try:
+        ts = [threading.Thread(target=worker, args=("t%d" % i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        stop.append(1)
+        tn.join()
+    assert not bad, bad
