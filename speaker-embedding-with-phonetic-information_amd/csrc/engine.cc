@@ -673,6 +673,9 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     layers_[i].w4bp = b.w4bp == kNone ? nullptr : base + b.w4bp;
     layers_[i].w4bp_scale = b.w4bp_scale == kNone ? nullptr : base + b.w4bp_scale;
   }
+  // the weight upload above ran on the null stream, which the engine's non-blocking streams are not ordered behind (and a
+  // device-to-device copy returns before it has run): it is over before the constructor returns
+  Check(hipDeviceSynchronize(), "hipDeviceSynchronize(weights)");
   {
     const char* e = getenv("XVEC_P8");   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
     use_p8_ = !(e && *e && atoi(e) == 0);
@@ -1006,6 +1009,7 @@ std::shared_ptr<Engine::Plan> Engine::MakePlan(const int32_t* row_offsets, int B
   FillPlan(row_offsets, B, plan.get(), &host);
   Check(hipMalloc(&plan->d_tables, host.size()), "hipMalloc(plan)");
   Check(hipMemcpy(plan->d_tables, host.data(), host.size(), hipMemcpyHostToDevice), "hipMemcpy(plan)");
+  Check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(plan)");   // null-stream copy; the kernels run on non-blocking streams
   BindPlan(plan.get(), plan->d_tables);
   if (plan_cache_.size() >= 64) plan_cache_.clear();
   plan_cache_[key] = plan;
