@@ -1511,8 +1511,8 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     // further a layer is from the pooled statistics: on the c-vector network the 650-wide phonetic branch hardly needs it,
     // the x-vector branch does.  So every candidate layer is first measured alone; the excess over the plain mode adds up
     // roughly in squares, and the layers are ranked by second-walk work saved (k_pad x n_pad) per unit of squared error
-    // added.  Then the longest prefix of that ranking within the tolerance, by bisection: every mixture that is adopted was
-    // itself measured on the sample, whatever the ranking assumed.
+    // added.  Then greedily in that ranking: every mixture that is adopted was itself measured on the sample, whatever the
+    // ranking assumed.
     std::vector<int> order;
     for (size_t i = 0; i < layers_.size() && i < 64; ++i) {
       const BlobLayerInfo& li = info_.layers[i];
@@ -1521,7 +1521,6 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
       if (ok) order.push_back((int)i);
     }
     std::vector<float> got((size_t)n * E);
-    int lo = 0;
     float err_lo = 0.f;
     try {
       std::vector<double> gain(layers_.size(), 0.0);
@@ -1531,30 +1530,26 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
         if (!lite_mask_) continue;
         ForwardHost(f.data(), offs.data(), n, got.data());
         const double e = worst(got, true);
+        if (e > tol) continue;   // not even alone
         const double v = std::max(e * e - base2, 1e-4 * base2 + 1e-30);
         gain[i] = (double)info_.layers[i].k_pad * info_.layers[i].n_pad / v;
       }
       order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return gain[i] <= 0.0; }), order.end());
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gain[a] > gain[b]; });
-      auto mask_of = [&](int k) {
-        uint64_t m = 0;
-        for (int j = 0; j < k; ++j) m |= 1ull << order[j];
-        return m;
-      };
-      int hi = (int)order.size() + 1;   // lo: a prefix known to be within the tolerance (0 = the plain mode); hi: one that is not
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) / 2;
-        SetLiteMask(mask_of(mid));
+      // in that order, a layer joins the mixture if the mixture with it - run on the sample - is still within the tolerance
+      // (one pass per candidate; a layer that does not fit is skipped, the cheaper ones behind it still get their turn)
+      uint64_t mask = 0;
+      for (int i : order) {
+        SetLiteMask(mask | (1ull << i));
+        if (lite_mask_ == mask) continue;
         ForwardHost(f.data(), offs.data(), n, got.data());
         const float e = worst(got, true);
         if (e <= tol) {
-          lo = mid;
+          mask = lite_mask_;
           err_lo = e;
-        } else {
-          hi = mid;
         }
       }
-      SetLiteMask(mask_of(lo));
+      SetLiteMask(mask);
     } catch (...) {
       SetFastMode(before);
       throw;
