@@ -375,7 +375,7 @@ def main():
         nb = len(o) - 1
         n = min(64, nb)
         picks = list(range(nb)) if nb <= 64 else sorted({((2 * i + 1) * nb) // 128 for i in range(64)})
-        choice = torch.tensor([-1, 0], dtype=torch.int64, device=cdev)   # arithmetic, lite-layer mask
+        choice = torch.tensor([-1, 0, 0], dtype=torch.int64, device=cdev)   # arithmetic, lite-layer mask (uint64) as two 32-bit halves
         cal = None
         if rank == 0:
             fh = f_dev.cpu().numpy()
@@ -384,13 +384,15 @@ def main():
             cal = c.calibrate(_np.concatenate(sub), so, 7.5e-5)
             cal["sample"] = "%d chunks spread evenly over the %d of %s" % (n, nb, what)
             choice[0] = P.PRECISIONS[cal["chosen"]]
-            choice[1] = cal.get("lite_mask", 0)
+            choice[1] = cal.get("lite_mask", 0) & 0xFFFFFFFF
+            choice[2] = cal.get("lite_mask", 0) >> 32
         if world > 1:
             dist.broadcast(choice, 0)
             if rank != 0:
                 c.set_fast_mode(P.PRECISION_NAMES[int(choice[0])])
-                if int(choice[1]):
-                    c.set_lite_mask(int(choice[1]))
+                lite = int(choice[1]) | (int(choice[2]) << 32)
+                if lite:
+                    c.set_lite_mask(lite)
         return cal
 
     # ---- synthetic inputs resident in HBM (N(0,1)*sigma_d, sigma_d = 8*0.9^d) ---------------

@@ -160,17 +160,25 @@ typedef struct {
   float err_mx;     /* XV_PREC_FP16MX against XV_PREC_FP16X3 */
   float err_mx2;    /* XV_PREC_FP16MX2 against XV_PREC_FP16X3 */
   int32_t checked_mx;  /* of them, chunks XV_PREC_FP16MX would run fast (what err_mx was measured on; fewer than 16: not chosen) */
-  float err_lite;      /* chosen == XV_PREC_FP16MX2 with lite_mask != 0: error of that mixture over the checked_mx chunks */
+  float err_lite;      /* chosen == XV_PREC_FP16MX2 with lite_mask != 0: error of that mixture over ALL checked_mx chunks */
   uint64_t lite_mask;  /* chosen == XV_PREC_FP16MX2: the layers (bit = index in xv_model_describe's table) that compute in 1.25 passes
                           inside the 1.5-pass context - where XV_PREC_FP16MX as a whole misses tol, the calibration keeps the
                           second walk (the correction of the activations' fp16 rounding) only on the layers that need it and
-                          takes it off the most expensive ones the tolerance allows, measured on the same chunks; 0: none */
+                          takes it off the most expensive ones the tolerance allows; 0: none.  The mixture is SELECTED on the
+                          chunks at even positions of the sample and CONFIRMED on those at odd positions, which took no part
+                          in the selection: layers are dropped again, last added first, until the held-out half is within tol */
+  float err_holdout;        /* error of the adopted mixture over the held-out half (what confirmed it) */
+  int32_t checked_holdout;  /* chunks of the held-out half XV_PREC_FP16MX would run fast */
+  int32_t lite_dropped;     /* layers the selection half admitted and the held-out half threw out again */
+  int32_t reserved;
 } xv_calibration;
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out);
 xv_status xv_ctx_set_fast_mode(xv_ctx* c, int32_t precision);   /* also clears the lite layers */
 xv_status xv_ctx_fast_mode(const xv_ctx* c, int32_t* precision);
 /* The lite layers of a context running XV_PREC_FP16MX2 (xv_calibration.lite_mask): set applies a choice made elsewhere
- * (bits of layers that cannot run the 1.25-pass arithmetic are dropped; XV_ERR_ARG in any other fast mode), get reports it. */
+ * (bits of layers that cannot run the 1.25-pass arithmetic are dropped; XV_ERR_ARG in any other fast mode), get reports it.
+ * The mask has 64 bits: a layer with index >= 64 in xv_model_describe's table is never lite (the reference's deepest graph on
+ * this path has 13 layers). */
 xv_status xv_ctx_set_lite_layers(xv_ctx* c, uint64_t mask);
 xv_status xv_ctx_lite_layers(const xv_ctx* c, uint64_t* mask);
 xv_status xv_calibrate_table(xv_ctx* c, const char* feature_rspecifier, int32_t chunk_size, int32_t min_chunk_size,

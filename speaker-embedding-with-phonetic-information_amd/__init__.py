@@ -66,7 +66,9 @@ class GemmDesc(ctypes.Structure):
 class Calibration(ctypes.Structure):
     """xv_calibration: what xv_ctx_calibrate measured and chose."""
     _fields_ = [("chosen", ctypes.c_int32), ("checked", ctypes.c_int32), ("err_mx", ctypes.c_float), ("err_mx2", ctypes.c_float),
-                ("checked_mx", ctypes.c_int32), ("err_lite", ctypes.c_float), ("lite_mask", ctypes.c_uint64)]
+                ("checked_mx", ctypes.c_int32), ("err_lite", ctypes.c_float), ("lite_mask", ctypes.c_uint64),
+                ("err_holdout", ctypes.c_float), ("checked_holdout", ctypes.c_int32), ("lite_dropped", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
         d = {"chosen": PRECISION_NAMES.get(self.chosen, str(self.chosen)), "checked": self.checked, "checked_mx": self.checked_mx,
@@ -74,6 +76,10 @@ class Calibration(ctypes.Structure):
         if self.lite_mask:
             d["lite_mask"] = int(self.lite_mask)
             d["err_lite"] = self.err_lite
+            d["err_holdout"] = self.err_holdout
+            d["checked_holdout"] = self.checked_holdout
+        if self.lite_dropped:
+            d["lite_dropped"] = self.lite_dropped
         return d
 
 

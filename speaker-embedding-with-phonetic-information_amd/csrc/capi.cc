@@ -12,6 +12,7 @@
 #include "engine.h"
 #include "extractor.h"
 #include "kernels.h"
+#include "multi_gpu.h"
 #include "nnet3_raw.h"
 #include "program.h"
 #include "table_extract.h"
@@ -231,6 +232,10 @@ static void FillCalibration(const xv::Engine::Calibration& c, xv_calibration* ou
   out->checked_mx = c.checked_mx;
   out->err_lite = c.err_lite;
   out->lite_mask = c.lite_mask;
+  out->err_holdout = c.err_holdout;
+  out->checked_holdout = c.checked_holdout;
+  out->lite_dropped = c.lite_dropped;
+  out->reserved = 0;
 }
 
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out) {
@@ -437,77 +442,17 @@ xv_status xv_segment_mean(int device, const float* x, int32_t n, int32_t dim, co
   });
 }
 
-// RCCL is bound lazily so that the library loads (and every non-collective entry works) on hosts where
-// librccl cannot initialise.
+// One process, several GPUs: multi_gpu.cc (one ncclBroadcast of the packed image, bounded wait, contexts from the device copies).
 xv_status xv_ctx_create_broadcast(const xv_model* m, const int* devices, int n, int precision, xv_ctx** out) {
   if (!m || !devices || !out || n < 1) return Fail(XV_ERR_ARG, "xv_ctx_create_broadcast: bad argument");
   return Guard([&]() -> xv_status {
-    std::vector<uint8_t> blob = xv::PackModelPolicy(m->prog, precision);
-    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) return Fail(XV_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
-    typedef void* comm_t;
-    typedef int (*CommInitAll_t)(comm_t*, int, const int*);
-    typedef int (*Broadcast_t)(const void*, void*, size_t, int, int, comm_t, hipStream_t);
-    typedef int (*Group_t)(void);
-    typedef int (*CommDestroy_t)(comm_t);
-    CommInitAll_t comm_init_all = (CommInitAll_t)dlsym(lib, "ncclCommInitAll");
-    Broadcast_t bcast = (Broadcast_t)dlsym(lib, "ncclBroadcast");
-    Group_t gstart = (Group_t)dlsym(lib, "ncclGroupStart");
-    Group_t gend = (Group_t)dlsym(lib, "ncclGroupEnd");
-    CommDestroy_t cdestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
-    if (!comm_init_all || !bcast || !gstart || !gend || !cdestroy) return Fail(XV_ERR_DEVICE, "librccl lacks expected symbols");
-    std::vector<comm_t> comms(n, nullptr);
-    if (comm_init_all(comms.data(), n, devices) != 0) return Fail(XV_ERR_DEVICE, "ncclCommInitAll failed");
-    std::vector<void*> dbuf(n, nullptr);
-    std::vector<hipStream_t> st(n, nullptr);
-    xv_status rc = XV_OK;
-    for (int i = 0; i < n && rc == XV_OK; ++i) {
-      if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc(&dbuf[i], blob.size()) != hipSuccess ||
-          hipStreamCreate(&st[i]) != hipSuccess)
-        rc = Fail(XV_ERR_DEVICE, "device allocation for the weight broadcast failed");
-    }
-    if (rc == XV_OK) {
-      (void)hipSetDevice(devices[0]);
-      if (hipMemcpy(dbuf[0], blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess)
-        rc = Fail(XV_ERR_DEVICE, "upload of the weight blob failed");
-    }
-    if (rc == XV_OK) {
-      // ONE broadcast of the packed image, ncclChar elements (type id 0), root = rank 0
-      gstart();
-      for (int i = 0; i < n; ++i) {
-        (void)hipSetDevice(devices[i]);
-        if (bcast(dbuf[i], dbuf[i], blob.size(), /*ncclChar*/ 0, 0, comms[i], st[i]) != 0)
-          rc = Fail(XV_ERR_DEVICE, "ncclBroadcast failed");
-      }
-      gend();
-    }
-    // every rank builds its context from the bytes *its device received* (device to device), so a bad broadcast
-    // cannot go unnoticed: header and layer table are read back from that copy and validated like any blob
-    std::vector<std::unique_ptr<xv_ctx>> ctxs;
-    for (int i = 0; i < n && rc == XV_OK; ++i) {
-      (void)hipSetDevice(devices[i]);
-      if (hipStreamSynchronize(st[i]) != hipSuccess) {
-        rc = Fail(XV_ERR_DEVICE, "the weight broadcast did not complete");
-        break;
-      }
-      try {
-        std::vector<uint8_t> head = xv::ReadBlobHead(dbuf[i], blob.size());
-        std::unique_ptr<xv_ctx> c(new xv_ctx);
-        c->eng.reset(new xv::Engine(head.data(), blob.size(), devices[i], dbuf[i]));
-        ctxs.push_back(std::move(c));
-      } catch (const std::exception& e) {
-        rc = Fail(XV_ERR_DEVICE, std::string("context from the broadcast image: ") + e.what());
-      }
-    }
+    const std::vector<uint8_t> blob = xv::PackModelPolicy(m->prog, precision);
+    std::vector<std::unique_ptr<xv::Engine>> engines = xv::CreateEnginesBroadcast(blob, std::vector<int>(devices, devices + n));
     for (int i = 0; i < n; ++i) {
-      (void)hipSetDevice(devices[i]);
-      if (dbuf[i]) (void)hipFree(dbuf[i]);
-      if (st[i]) (void)hipStreamDestroy(st[i]);
-      if (comms[i]) cdestroy(comms[i]);
+      xv_ctx* c = new xv_ctx;
+      c->eng = std::move(engines[i]);
+      out[i] = c;
     }
-    if (rc != XV_OK) return rc;
-    for (int i = 0; i < n; ++i) out[i] = ctxs[i].release();
     return XV_OK;
   });
 }

@@ -522,6 +522,20 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
       if (b.w4b != kNone)
         ok = ok && b.w4 != kNone && b.ldw4b == b.k_pad / 128 * 64 && inside(b.w4b, (uint64_t)b.n_pad * b.ldw4b) &&
              b.w4b_scale != kNone && inside(b.w4b_scale, 2 * (uint64_t)b.n_pad * (uint64_t)(b.k_pad / kBK));
+      // the same images in the K-walk order of tdnn_gemm_kernel_p8 (these become device pointers the kernel DMAs
+      // n_pad * ldw4 / n_pad * k_pad * 2 bytes from, a GPU fault is fatal): each needs what it is a re-ordering of, its scales,
+      // and whole 256-column tiles
+      const uint64_t sc_bytes = 2 * (uint64_t)b.n_pad * (uint64_t)(b.k_pad / kBK);
+      if (b.w4p != kNone)
+        ok = ok && b.w4 != kNone && b.n_pad % 256 == 0 && inside(b.w4p, (uint64_t)b.n_pad * b.ldw4) && b.w4p_scale != kNone &&
+             inside(b.w4p_scale, sc_bytes);
+      else
+        ok = ok && b.w4p_scale == kNone;
+      if (b.w4bp != kNone)
+        ok = ok && b.w4p != kNone && b.w4b != kNone && inside(b.w4bp, (uint64_t)b.n_pad * b.k_pad * 2) && b.w4bp_scale != kNone &&
+             inside(b.w4bp_scale, sc_bytes);
+      else
+        ok = ok && b.w4bp_scale == kNone;
       if (!ok) throw EngineError("model blob: layer " + std::to_string(i) + " is inconsistent");
     }
     BlobLayerInfo li;
@@ -634,7 +648,7 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     const char* e = getenv("XVEC_LANES");
     int nl = e && *e ? atoi(e) : 2;
     if (nl < 1) nl = 1;
-    if (nl > 4) nl = 4;
+    if (nl > kMaxLanes) nl = kMaxLanes;   // (CheckKernelFaults keeps one bit per lane below the engine-stream and caller-stream bits)
     lanes_.resize(nl);
     for (Lane& L : lanes_) {
       Check(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking), "hipStreamCreate(lane)");
@@ -674,8 +688,9 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
     layers_[i].w4bp_scale = b.w4bp_scale == kNone ? nullptr : base + b.w4bp_scale;
   }
   // the weight upload above ran on the null stream, which the engine's non-blocking streams are not ordered behind (and a
-  // device-to-device copy returns before it has run): it is over before the constructor returns
-  Check(hipDeviceSynchronize(), "hipDeviceSynchronize(weights)");
+  // device-to-device copy returns before it has run): it is over before the constructor returns.  Waiting for the null stream
+  // is enough - other contexts' (non-blocking) streams on this device keep running
+  Check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(weights)");
   {
     const char* e = getenv("XVEC_P8");   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
     use_p8_ = !(e && *e && atoi(e) == 0);
@@ -781,63 +796,66 @@ Engine::~Engine() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-void Engine::Ensure(Buf* b, size_t bytes, bool zero) {
+void Engine::Ensure(Buf* b, size_t bytes, bool zero, hipStream_t consumer) {
   if (b->bytes >= bytes && b->p) return;
   if (b->p) Check(hipFree(b->p), "hipFree");
   b->p = nullptr;
   Check(hipMalloc(&b->p, bytes), "hipMalloc");
   b->bytes = bytes;
   if (zero) {
-    // hipMemset on device memory is asynchronous to the host and runs on the null stream, which the engine's non-blocking
-    // streams are not ordered behind: the fill has to be over before a kernel may touch the buffer.  (Found in round 4 by
-    // tools/stress_frames.py: with another stream keeping the chip busy the FIRST forward pass of a context could run beside
-    // the zero-fill of its own activation planes.)  Buffers only grow on the first batches of a job.
-    Check(hipMemset(b->p, 0, bytes), "hipMemset");
-    Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    // The fill is ordered on the stream that will consume the buffer (hipMemsetAsync on `consumer`): a plain hipMemset runs on
+    // the null stream, which the engine's non-blocking streams are not ordered behind - with another stream keeping the chip
+    // busy the FIRST forward pass of a context could run beside the zero-fill of its own activation planes (round 4,
+    // tools/stress_frames.py).  Round 4 waited for the whole device here; only the ordering against one stream is needed
+    // (four processes / threads per GPU is the recipes' launch mode, and a device-wide wait stalls them all).
+    // Later users of the buffer on another stream are ordered behind this one by the lane's `done` event.
+    Check(hipMemsetAsync(b->p, 0, bytes, consumer), "hipMemsetAsync");
   }
 }
 
-void Engine::EnsureCapacity(Lane& L, int rows, int b_pad) {
+void Engine::EnsureCapacity(Lane& L, int rows, int b_pad, hipStream_t s) {
+  // Growing = freeing planes this lane's previous batch may still be using: wait for THAT batch (hipFree then does what it
+  // does); the fills of the new planes are ordered on `s`, the stream about to consume them.  No device-wide wait of ours.
   if (rows > L.cap_rows) {
-    Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (L.busy) Check(hipEventSynchronize(L.done), "hipEventSynchronize(lane)");
     const size_t r = (size_t)rows + 2 * kHalo;
-    Ensure(&L.in_hi, r * in_ld_ * 2, true);
-    if (nplanes_ == 2) Ensure(&L.in_lo, r * in_ld_ * 2, true);
+    Ensure(&L.in_hi, r * in_ld_ * 2, true, s);
+    if (nplanes_ == 2) Ensure(&L.in_lo, r * in_ld_ * 2, true, s);
     for (size_t i = 0; i < layers_.size(); ++i) {
       const BlobLayerInfo& li = info_.layers[i];
       if (li.segment_level) continue;
       if ((int)i == info_.pooled_layer) {
-        Ensure(&L.partial, (size_t)(rows / kRowAlign) * 2 * li.n_pad * 4, true);
+        Ensure(&L.partial, (size_t)(rows / kRowAlign) * 2 * li.n_pad * 4, true, s);
         continue;
       }
       if (frame_mode_ && (int)i == info_.output_layer) {
         Ensure(&L.frame_f32, (size_t)rows * li.n_pad * (logits16() ? 2 : 4), false);
         continue;
       }
-      Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true);
-      if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true);
+      Ensure(&L.act[i].act_hi, r * li.n_pad * 2, true, s);
+      if (nplanes_ == 2) Ensure(&L.act[i].act_lo, r * li.n_pad * 2, true, s);
       if (info_.precision == kPrecFp16Mx2 && !frame_mode_) {   // whatever the current fast mode is (SetFastMode)
-        Ensure(&L.act[i].act_lo4, r * (li.n_pad / 2), true);
-        Ensure(&L.act[i].act_lo4s, r * Lo4ScalePitch(li.n_pad), true);
+        Ensure(&L.act[i].act_lo4, r * (li.n_pad / 2), true, s);
+        Ensure(&L.act[i].act_lo4s, r * Lo4ScalePitch(li.n_pad), true, s);
       }
     }
     // per layer: max |activation| of every 16-row group (what a kPrecFp16Mx consumer scales its 4-bit copy by)
-    if (fast_mx_ || can_switch_fast_mode()) Ensure(&L.gmax, layers_.size() * (size_t)(rows / kRowAlign) * 4, true);
+    if (fast_mx_ || can_switch_fast_mode()) Ensure(&L.gmax, layers_.size() * (size_t)(rows / kRowAlign) * 4, true, s);
     L.gmax_stride = rows / kRowAlign;
     L.cap_rows = rows;
   }
   if (!frame_mode_ && b_pad > L.cap_b) {
-    Check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-    Ensure(&L.stats_hi, (size_t)b_pad * stats_ld_ * 2, true);
-    if (nplanes_ == 2) Ensure(&L.stats_lo, (size_t)b_pad * stats_ld_ * 2, true);
+    if (L.busy) Check(hipEventSynchronize(L.done), "hipEventSynchronize(lane)");
+    Ensure(&L.stats_hi, (size_t)b_pad * stats_ld_ * 2, true, s);
+    if (nplanes_ == 2) Ensure(&L.stats_lo, (size_t)b_pad * stats_ld_ * 2, true, s);
     for (size_t i = 0; i < layers_.size(); ++i) {
       const BlobLayerInfo& li = info_.layers[i];
       if (!li.segment_level) continue;
       if ((int)i == info_.output_layer) {
-        Ensure(&L.out_f32, (size_t)b_pad * li.n_pad * 4, true);
+        Ensure(&L.out_f32, (size_t)b_pad * li.n_pad * 4, true, s);
       } else {
-        Ensure(&L.act[i].act_hi, (size_t)b_pad * li.n_pad * 2, true);
-        if (nplanes_ == 2) Ensure(&L.act[i].act_lo, (size_t)b_pad * li.n_pad * 2, true);
+        Ensure(&L.act[i].act_hi, (size_t)b_pad * li.n_pad * 2, true, s);
+        if (nplanes_ == 2) Ensure(&L.act[i].act_lo, (size_t)b_pad * li.n_pad * 2, true, s);
       }
     }
     L.cap_b = b_pad;
@@ -1034,7 +1052,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
     if (!own) ext_streams_.push_back(stream);
   }
   if (L.busy) Check(hipStreamWaitEvent(s, L.done, 0), "hipStreamWaitEvent(lane)");
-  EnsureCapacity(L, plan.rows, plan.b_pad);
+  EnsureCapacity(L, plan.rows, plan.b_pad, s);
   const int prec = slow_prec_;
 
   PrepArgs pa;
@@ -1412,7 +1430,7 @@ void Engine::SetLiteMask(uint64_t mask) {
   lite_.assign(nl, 0);
   lite_emits_.assign(nl, 0);
   uint64_t kept = 0;
-  for (size_t i = 0; i < nl && i < 64; ++i) {
+  for (size_t i = 0; i < nl && i < (size_t)kMaxLiteLayers; ++i) {
     const BlobLayerInfo& li = info_.layers[i];
     // a layer can be lite when it is a frame-level GEMM over other layers' planes with the residual image of the 1.25-pass
     // arithmetic (the layers that read the network input run the first-layer kernel in its own arithmetic)
@@ -1464,6 +1482,7 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   }
   const int n = (int)pick.size();
   const int before = fast_mode_;
+  const uint64_t lite_before = lite_mask_;
   std::vector<float> ref((size_t)n * E), mx((size_t)n * E), mx2((size_t)n * E);
   try {
     SetFastMode(kPrecFp16x3);
@@ -1474,12 +1493,15 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     ForwardHost(f.data(), offs.data(), n, mx2.data());
   } catch (...) {
     SetFastMode(before);
+    if (before == kPrecFp16Mx2 && lite_before) SetLiteMask(lite_before);
     throw;
   }
-  auto worst = [&](const std::vector<float>& got, bool only_mx) {
+  // half: -1 = every chunk, 0 / 1 = the chunks at even / odd positions of the sample (selection / held-out half of the mixture)
+  auto worst = [&](const std::vector<float>& got, bool only_mx, int half) {
     float w = 0.f;
     for (int i = 0; i < n; ++i) {
       if (only_mx && !runs_mx[i]) continue;
+      if (half >= 0 && (i & 1) != half) continue;
       float d = 0.f, m = 0.f;
       for (int k = 0; k < E; ++k) {
         d = std::max(d, std::fabs(got[(size_t)i * E + k] - ref[(size_t)i * E + k]));
@@ -1490,46 +1512,58 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     }
     return w;
   };
-  int n_mx = 0;
-  for (int i = 0; i < n; ++i) n_mx += runs_mx[i] ? 1 : 0;
+  int n_mx = 0, n_mx_hold = 0;
+  for (int i = 0; i < n; ++i) {
+    n_mx += runs_mx[i] ? 1 : 0;
+    n_mx_hold += (runs_mx[i] && (i & 1)) ? 1 : 0;
+  }
   c.checked = n;
   c.checked_mx = n_mx;
-  c.err_mx = worst(mx, true);
-  c.err_mx2 = worst(mx2, false);
+  c.err_mx = worst(mx, true, -1);
+  c.err_mx2 = worst(mx2, false, -1);
   // The lighter mode governs a whole job: it is taken only on the evidence of at least kCalibMinChunks chunks it would run
   // (the margin between the tolerance and the bar is argued for a sample of that order; one or two
-  // qualifying chunks are not a measurement).  Fewer: the packed mode stays.
+  // qualifying chunks are not a measurement).  Fewer: the packed mode stays.  This is ONE hypothesis fixed in advance,
+  // tested once on the whole sample - nothing is selected, so nothing has to be held out.
   const bool mx_ok = n_mx >= kCalibMinChunks && c.err_mx <= tol;
   c.chosen = mx_ok ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
   SetFastMode(c.chosen);
   // (the mixture runs fast what fp16mx runs fast - chunks of >= 300 pooled frames - and sends the shorter ones, which plain
   // fp16mx2 runs fast from 160, to the three-pass arithmetic: on a job with many of those it would lose more than it saves,
   // so it is considered only where they are at most an eighth of the sample)
-  if (c.chosen == kPrecFp16Mx2 && n_mx >= kCalibMinChunks && c.err_mx2 <= tol && (n - n_mx) * 8 <= n) {
+  const int n_mx_fit = n_mx - n_mx_hold;
+  if (c.chosen == kPrecFp16Mx2 && n_mx_fit >= kCalibMinChunks / 2 && n_mx_hold >= kCalibMinChunks / 2 && c.err_mx2 <= tol &&
+      (n - n_mx) * 8 <= n) {
     // Between the two: the 1.5-pass context with some of its layers in 1.25 passes - as much of the second walk taken off as the
-    // tolerance allows on the same evidence.  What the second walk corrects (the activations' fp16 rounding) matters less the
-    // further a layer is from the pooled statistics: on the c-vector network the 650-wide phonetic branch hardly needs it,
-    // the x-vector branch does.  So every candidate layer is first measured alone; the excess over the plain mode adds up
-    // roughly in squares, and the layers are ranked by second-walk work saved (k_pad x n_pad) per unit of squared error
-    // added.  Then greedily in that ranking: every mixture that is adopted was itself measured on the sample, whatever the
-    // ranking assumed.
+    // tolerance allows.  What the second walk corrects (the activations' fp16 rounding) matters less the further a layer is
+    // from the pooled statistics: on the c-vector network the 650-wide phonetic branch hardly needs it, the x-vector branch
+    // does.  This IS a selection - up to 2 x (candidate layers) configurations are tried and the cheapest that passes is
+    // kept, so the error of the winner on the chunks that chose it is biased low.  Hence two halves:
+    //   selection half (even positions): every candidate layer measured alone, ranked by second-walk work saved
+    //     (k_pad x n_pad) per unit of squared error added (the excesses add up roughly in squares), then greedily in that
+    //     ranking - a layer joins if the mixture with it is still within the tolerance on THIS half;
+    //   held-out half (odd positions): the adopted mixture must be within the tolerance here as well; while it is not, the
+    //     layer added last is taken out again (fp16mx2 itself, the empty mixture, passed on the whole sample above).
+    // Every forward pass runs the whole sample (the halves share the batch), only the comparison is restricted.
     std::vector<int> order;
-    for (size_t i = 0; i < layers_.size() && i < 64; ++i) {
+    for (size_t i = 0; i < layers_.size() && i < (size_t)kMaxLiteLayers; ++i) {
       const BlobLayerInfo& li = info_.layers[i];
       bool ok = !li.segment_level && li.has_w4 && !layers_[i].first;
       for (const LayerSource& src : li.src) ok = ok && src.layer >= 0 && !info_.layers[src.layer].segment_level;
       if (ok) order.push_back((int)i);
     }
     std::vector<float> got((size_t)n * E);
-    float err_lo = 0.f;
+    float err_all = 0.f, err_hold = 0.f;
+    int dropped = 0;
     try {
       std::vector<double> gain(layers_.size(), 0.0);
-      const double base2 = (double)c.err_mx2 * c.err_mx2;
+      const double fit_mx2 = worst(mx2, true, 0);
+      const double base2 = fit_mx2 * fit_mx2;
       for (int i : order) {
         SetLiteMask(1ull << i);
         if (!lite_mask_) continue;
         ForwardHost(f.data(), offs.data(), n, got.data());
-        const double e = worst(got, true);
+        const double e = worst(got, true, 0);
         if (e > tol) continue;   // not even alone
         const double v = std::max(e * e - base2, 1e-4 * base2 + 1e-30);
         gain[i] = (double)info_.layers[i].k_pad * info_.layers[i].n_pad / v;
@@ -1537,25 +1571,42 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
       order.erase(std::remove_if(order.begin(), order.end(), [&](int i) { return gain[i] <= 0.0; }), order.end());
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gain[a] > gain[b]; });
       // in that order, a layer joins the mixture if the mixture with it - run on the sample - is still within the tolerance
-      // (one pass per candidate; a layer that does not fit is skipped, the cheaper ones behind it still get their turn)
+      // on the selection half (one pass per candidate; a layer that does not fit is skipped, the cheaper ones behind it
+      // still get their turn)
       uint64_t mask = 0;
+      std::vector<int> added;
       for (int i : order) {
         SetLiteMask(mask | (1ull << i));
         if (lite_mask_ == mask) continue;
         ForwardHost(f.data(), offs.data(), n, got.data());
-        const float e = worst(got, true);
-        if (e <= tol) {
+        if (worst(got, true, 0) <= tol) {
           mask = lite_mask_;
-          err_lo = e;
+          added.push_back(i);
         }
+      }
+      // confirmation on the half that did not choose
+      while (mask) {
+        SetLiteMask(mask);
+        ForwardHost(f.data(), offs.data(), n, got.data());
+        err_hold = worst(got, true, 1);
+        err_all = std::max(err_hold, worst(got, true, 0));
+        if (err_hold <= tol) break;
+        mask &= ~(1ull << added.back());
+        added.pop_back();
+        ++dropped;
+        err_hold = err_all = 0.f;
       }
       SetLiteMask(mask);
     } catch (...) {
       SetFastMode(before);
+      if (before == kPrecFp16Mx2 && lite_before) SetLiteMask(lite_before);
       throw;
     }
     c.lite_mask = lite_mask_;
-    c.err_lite = lite_mask_ ? err_lo : 0.f;
+    c.err_lite = lite_mask_ ? err_all : 0.f;
+    c.err_holdout = lite_mask_ ? err_hold : 0.f;
+    c.checked_holdout = n_mx_hold;
+    c.lite_dropped = dropped;
   }
   return c;
 }
@@ -1722,7 +1773,8 @@ void Engine::CheckKernelFaults(int lane) const {
   // that lane: a fault of the batch still in flight on the other lane stays recorded until its own WaitHost.
   (void)hipSetDevice(device_);
   if (sk_take_error(stream_)) fault_mask_ |= 1u << 31;
-  for (size_t i = 0; i < lanes_.size() && i < 31; ++i)
+  static_assert(kMaxLanes <= 30, "fault_mask_: bits 0..29 lanes, 30 callers' streams, 31 the engine's stream");
+  for (size_t i = 0; i < lanes_.size(); ++i)
     if (sk_take_error(lanes_[i].stream)) fault_mask_ |= 1u << i;
   // launches on a caller's stream (xv_forward_batch_device) leave their word with that stream: read when the caller asks
   // about everything (xv_ctx_synchronize), never on behalf of one lane's batch
@@ -1734,7 +1786,7 @@ void Engine::CheckKernelFaults(int lane) const {
     err = fault_mask_;
     fault_mask_ = 0;
   } else {
-    const unsigned bits = (1u << (lane & 31)) | (1u << 31);
+    const unsigned bits = (1u << lane) | (1u << 31);   // lane < kMaxLanes
     err = fault_mask_ & bits;
     fault_mask_ &= ~bits;
   }

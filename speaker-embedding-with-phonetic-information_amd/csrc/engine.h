@@ -139,9 +139,17 @@ class Engine {
                               // kCalibMinChunks of them never select kPrecFp16Mx
     uint64_t lite_mask = 0;   // chosen == kPrecFp16Mx2 only: the layers (bit = layer index) that run the 1.25-pass arithmetic
                               // inside the 1.5-pass context (SetLiteMask) - the most expensive ones the tolerance allows
-    float err_lite = 0.f;     // worst error of that mixture over the `checked_mx` chunks (0 when lite_mask == 0)
+    float err_lite = 0.f;     // worst error of that mixture over ALL `checked_mx` chunks, both halves (0 when lite_mask == 0)
+    // The mixture is SELECTED on one half of the sample (even positions of the picked chunks) and CONFIRMED on the other
+    // (odd positions), which took no part in the selection: layers are dropped, last added first, until the held-out half
+    // is within the tolerance too.
+    int checked_holdout = 0;  // chunks of the held-out half that kPrecFp16Mx would run fast
+    float err_holdout = 0.f;  // worst error of the adopted mixture over them (0 when lite_mask == 0)
+    int lite_dropped = 0;     // layers the selection half had admitted and the held-out half threw out again
   };
   static constexpr int kCalibMinChunks = 16;
+  static constexpr int kMaxLanes = 4;       // XVEC_LANES is clamped to this
+  static constexpr int kMaxLiteLayers = 64; // lite_mask is a uint64: only layers with index < 64 can be "lite" (SetLiteMask drops the rest)
   bool can_switch_fast_mode() const { return info_.precision == kPrecFp16Mx2 && !frame_mode_; }
   int fast_mode() const { return can_switch_fast_mode() ? fast_mode_ : info_.precision; }
   void SetFastMode(int mode);   // throws unless can_switch_fast_mode() and mode is one of the three; clears the lite mask
@@ -240,8 +248,8 @@ class Engine {
                                       // bit 30: a caller's stream (xv_forward_batch_device)
   std::vector<hipStream_t> ext_streams_;   // callers' streams this engine launched on (their fault words are read with the others)
  private:
-  void Ensure(Buf* b, size_t bytes, bool zero);
-  void EnsureCapacity(Lane& L, int rows, int b_pad);
+  void Ensure(Buf* b, size_t bytes, bool zero, hipStream_t consumer = nullptr);   // zero: filled on `consumer`, the stream that will use it
+  void EnsureCapacity(Lane& L, int rows, int b_pad, hipStream_t s);
   uint16_t* ActBase(const Buf& b, int ld) const;
 
   BlobInfo info_;

@@ -2923,11 +2923,10 @@ static hipError_t sk_workspace(hipStream_t s, int grid, size_t ws_bytes, SkWorks
       return e;
     }
     if ((e = hipExtMallocWithFlags((void**)&w.flags, (size_t)grid * sizeof(unsigned), hipDeviceMallocFinegrained)) != hipSuccess ||
-        (e = hipMemset(w.flags, 0, (size_t)grid * sizeof(unsigned))) != hipSuccess ||
-        // hipMemset on device memory returns before the fill has run, and the fill is on the null stream, which the
-        // (non-blocking) launch stream is not ordered behind: without this wait the first launch on a stream could run beside
-        // the clearing of its own flags
-        (e = hipDeviceSynchronize()) != hipSuccess) {
+        // the fill is ordered on the stream whose launches use the flags (this table is keyed by it) - no device-wide wait
+        // under g_sk_mu.  A plain hipMemset would run on the null stream, which the non-blocking launch stream
+        // is not ordered behind: the first launch could run beside the clearing of its own flags (round 4)
+        (e = hipMemsetAsync(w.flags, 0, (size_t)grid * sizeof(unsigned), s)) != hipSuccess) {
       sk_free(&w);
       return e;
     }

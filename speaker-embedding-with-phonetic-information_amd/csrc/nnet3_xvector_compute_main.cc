@@ -28,6 +28,7 @@
 #include "kio.h"
 #include "nnet3_raw.h"
 #include "program.h"
+#include "multi_gpu.h"
 #include "table_extract.h"
 
 namespace {
@@ -92,6 +93,11 @@ const char* kUsage =
     "                                   kernels (default 300 / 160, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
     "  --device=<int>                   HIP device index (default: $XVEC_DEVICE, else job index mod #devices)\n"
+    "  --devices=all|<i,j,...>          ONE process driving several GPUs (default: $XVEC_DEVICES): the model is read and packed\n"
+    "                                   once, sent to the listed devices with one RCCL broadcast, whole batches are dealt\n"
+    "                                   to them in turn and written in table order - the output is byte-identical to a\n"
+    "                                   one-GPU run.  This is what `extract_xvectors_new.sh --nj 1 --use-gpu true` needs to\n"
+    "                                   use the whole node without a change of the script (nnet3-xvector-compute only)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
     "                                   run apply-cmvn-sliding (--norm-vars=false) and select-voiced-frames on the device\n"
     "                                   in front of the network; the features rspecifier is then the raw feats.scp\n"
@@ -115,6 +121,7 @@ struct Options {
   float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
   int calibrate_utts = 64;         // utterances sampled (spread over the list of an addressable table, the head of a stream)
   int device = -1;
+  std::string devices;             // --devices: "all" or a list; empty: one device (--device rule)
   bool print_args = true;
   int cmn_window = 0;
   bool cmn_center = true;
@@ -199,6 +206,13 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   }
   else if (name == "calibrate-utts") return need_int(&o->calibrate_utts);
   else if (name == "device") return need_int(&o->device);
+  else if (name == "devices") {
+    if (!has_value || value.empty()) {
+      *err = "--devices needs a value (all, or a comma-separated list of device indices)";
+      return false;
+    }
+    o->devices = value;
+  }
   else if (name == "cmn-window") return need_int(&o->cmn_window);
   else if (name == "vad-rspecifier") o->vad_rspecifier = value;
   else if (name == "profile-json") o->profile_json = value;
@@ -377,14 +391,40 @@ int main(int argc, char** argv) {
     if (device >= ndev) device %= ndev;
     const double t_hip = since_start();
     if (policy_default) opt.precision = std::string("default = ") + xv::PrecisionName(precision);
-    xv::Engine engine(blob.data(), blob.size(), device);
+    // one process, several GPUs (--devices / XVEC_DEVICES): one RCCL broadcast of the packed image, an engine per device
+    std::string dev_spec = opt.devices;
+    if (dev_spec.empty() && opt.device < 0 && getenv("XVEC_DEVICES")) dev_spec = getenv("XVEC_DEVICES");
+    std::vector<int> dev_list = xv::ParseDeviceList(dev_spec, ndev);
+    if (!dev_list.empty() && g_frame_job) {
+      XWARN("--devices is ignored by nnet3-compute (one device: " << dev_list[0] << ")");
+      device = dev_list[0];
+      dev_list.clear();
+    }
+    std::vector<std::unique_ptr<xv::Engine>> engines;
+    if (dev_list.empty()) {
+      engines.emplace_back(new xv::Engine(blob.data(), blob.size(), device));
+    } else {
+      engines = xv::CreateEnginesBroadcast(blob, dev_list);
+      device = dev_list[0];
+    }
+    xv::Engine& engine = *engines[0];
     if (getenv("XVEC_TIMING"))
       XLOG("start-up stages: model read + lowered " << t_model << " s, weights packed " << (t_pack - t_model)
                                                        << " s, HIP runtime up " << (t_hip - t_pack)
                                                        << " s, engine (upload, buffers, streams) " << (since_start() - t_hip) << " s");
-    XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
-                   << ", embedding dim " << prog.output_dim << "; device " << device << " of " << ndev << ", precision "
-                   << opt.precision << ", " << (engine.weight_bytes() >> 20) << " MiB of packed weights");
+    {
+      std::ostringstream dv;
+      if (dev_list.empty()) {
+        dv << "device " << device << " of " << ndev;
+      } else {
+        dv << dev_list.size() << " of " << ndev << " devices (";
+        for (size_t i = 0; i < dev_list.size(); ++i) dv << (i ? "," : "") << dev_list[i];
+        dv << "; weights sent with one RCCL broadcast from device " << dev_list[0] << ")";
+      }
+      XLOG("model: " << prog.layers.size() << " layers, context " << prog.left_context << "/" << prog.right_context
+                     << ", embedding dim " << prog.output_dim << "; " << dv.str() << ", precision " << opt.precision << ", "
+                     << (engine.weight_bytes() >> 20) << " MiB of packed weights");
+    }
 
     if (!opt.profile_json.empty()) engine.SetProfiling(true);
     // --profile-json: {"kernels": [{"name", "launches", "total_ms"}], "utterances", "failed", "frames", "seconds"}
@@ -442,8 +482,10 @@ int main(int argc, char** argv) {
     }
     eo.backend_normalize = opt.backend_normalize;
     eo.backend_scaleup = opt.backend_scaleup;
+    std::vector<xv::Engine*> eng_ptrs;
+    for (auto& e : engines) eng_ptrs.push_back(e.get());
     xv::TableExtractResult res = xv::RunTableExtraction(
-        &engine, eo, feat_rspec, vec_wspec, [](const char* level, const std::string& m) { LogLine(level, 0, m); });
+        eng_ptrs, eo, feat_rspec, vec_wspec, [](const char* level, const std::string& m) { LogLine(level, 0, m); });
     if (res.reader_status != 0) XWARN("feature input command exited with status " << res.reader_status);
     XLOG("Time taken " << res.seconds << "s: real-time factor assuming 100 frames/sec is "
                        << (res.seconds * 100.0 / std::max(res.frames, 1.0)));

@@ -97,8 +97,10 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
           m << (first ? "" : ", ") << engine->info().layers[i].name;
           first = false;
         }
-      m << ": " << c.err_lite << ")";
+      m << ": " << c.err_lite << "; chosen on one half of the sample, " << c.err_holdout << " on the " << c.checked_holdout
+        << " held-out chunks)";
     }
+    if (c.lite_dropped) m << "; " << c.lite_dropped << " layer(s) admitted by the selection half failed the held-out half and were taken out again";
   }
   log("LOG", m.str());
   return c;
@@ -110,20 +112,32 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
 // and the choice governs every utterance of the job.  Streams (the feature pipe of extract_xvectors_new.sh:79) can only be
 // read front to back: their sample is the head, and the log says so.  *strided tells which one it was.
 static void SampleTable(const ExtractOptions& opt, const std::string& feat_rspec, std::vector<std::string>* keys,
-                        std::vector<Matrix>* mats, bool* strided, long* n_list) {
+                        std::vector<Matrix>* mats, bool* strided, long* n_list, TableIndex* index) {
   *strided = false;
   *n_list = -1;
   const int want = std::max(1, opt.calibrate_utts);
   {
     MatrixTableIndexer ix(feat_rspec);
     if (ix.usable()) {
-      std::vector<MatrixTableIndexer::Entry> all;
-      MatrixTableIndexer::Entry e;
-      while (ix.Next(&e))
-        if (e.error.empty()) all.push_back(std::move(e));
+      // ONE index of the table serves the sample and, through `index`, the batching pass of the extraction (the
+      // headers of a 1 M-line scp were visited twice).  An object the indexer cannot get past (a text object, a truncated
+      // archive) ends the index there and is remembered: the sample comes from what was indexed, and the extraction writes
+      // everything in front of the bad object before it reports it - like the sequential reader and like the reference.
+      TableIndex local;
+      TableIndex& all = index ? *index : local;
+      try {
+        MatrixTableIndexer::Entry e;
+        while (ix.Next(&e)) all.entries.push_back(std::move(e));
+      } catch (const std::exception& ex) {
+        all.error = ex.what();
+      }
+      all.valid = true;
+      std::vector<size_t> good;
+      for (size_t i = 0; i < all.entries.size(); ++i)
+        if (all.entries[i].error.empty()) good.push_back(i);
       *strided = true;
-      *n_list = (long)all.size();
-      const long n = (long)all.size();
+      *n_list = (long)good.size();
+      const long n = (long)good.size();
       Input in;
       std::string in_path;
       long prev = -1;
@@ -134,11 +148,11 @@ static void SampleTable(const ExtractOptions& opt, const std::string& feat_rspec
         prev = k;
         Matrix m;
         try {
-          ReadIndexedMatrix(all[k], &in, &in_path, &m);
+          ReadIndexedMatrix(all.entries[good[k]], &in, &in_path, &m);
         } catch (const std::exception&) {
           continue;   // the extraction itself will report it
         }
-        keys->push_back(all[k].key);
+        keys->push_back(all.entries[good[k]].key);
         mats->push_back(std::move(m));
       }
       return;
@@ -155,12 +169,13 @@ static void SampleTable(const ExtractOptions& opt, const std::string& feat_rspec
   // (the reader is closed here; for a pipe that ends the producer early, which is what a "head" of the list wants)
 }
 
-Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec, const LogFn& log) {
+Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec, const LogFn& log,
+                                     TableIndex* index) {
   std::vector<std::string> keys;
   std::vector<Matrix> mats;
   bool strided = false;
   long n_list = -1;
-  SampleTable(opt, feat_rspec, &keys, &mats, &strided, &n_list);
+  SampleTable(opt, feat_rspec, &keys, &mats, &strided, &n_list, index);
   std::ostringstream m;
   if (strided) m << "calibration sample: " << keys.size() << " utterances spread evenly over the " << n_list << " of the table";
   else m << "calibration sample: the first " << keys.size() << " utterances of the stream (a stream cannot be sampled any other way)";
@@ -172,6 +187,29 @@ Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, 
 
 TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feat_rspec,
                                       const std::string& vec_wspec, const LogFn& log) {
+  return RunTableExtraction(std::vector<Engine*>(1, engine), opt, feat_rspec, vec_wspec, log);
+}
+
+// Several engines = several GPUs driven by this one process (nnet3-xvector-compute --devices=..., the `--nj 1` form of
+// extract_xvectors_new.sh:83-93).  Whole batches are dealt to the engines round-robin and finalised in the order they were
+// submitted, through the one writer: the output archive is byte-identical to a one-GPU run of the same job.  The arithmetic
+// is chosen once, on engines[0], and applied to the others (like rank 0's choice in dist_extract.py).
+TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const ExtractOptions& opt, const std::string& feat_rspec,
+                                      const std::string& vec_wspec, const LogFn& log) {
+  if (engines.empty() || !engines[0]) throw EngineError("RunTableExtraction: no engine");
+  Engine* const engine = engines[0];   // calibration, host-side front-end fallback, back-end
+  const int NE = (int)engines.size();
+  for (Engine* e : engines)
+    if (!e || e->info().input_dim != engine->info().input_dim || e->info().output_dim != engine->info().output_dim ||
+        e->can_switch_fast_mode() != engine->can_switch_fast_mode())
+      throw EngineError("RunTableExtraction: the engines do not hold the same model");
+  auto share_choice = [&] {   // what engines[0] was calibrated to, on every other engine
+    for (int k = 1; k < NE; ++k) {
+      if (!engines[k]->can_switch_fast_mode()) continue;
+      engines[k]->SetFastMode(engine->fast_mode());
+      if (engine->lite_mask()) engines[k]->SetLiteMask(engine->lite_mask());
+    }
+  };
   TableExtractResult res;
   const int D = engine->info().input_dim, E = engine->info().output_dim;
   // option errors are raised before the reader thread and the output files exist
@@ -208,7 +246,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   // pipeline of extract_xvectors_new.sh:79) can only be read front to back: one reader thread, as before.
   // Everything that can fail on a user error happens before a thread exists (the indexer opens the table here).
   const bool opt_is_scp = ParseRspecifier(feat_rspec).is_scp;
-  int n_readers = 4;
+  int n_readers = std::min(16, 4 * NE);
   if (const char* e = getenv("XVEC_READERS")) n_readers = std::max(1, std::min(16, atoi(e)));
   std::unique_ptr<MatrixTableIndexer> indexer;
   if (n_readers > 1) {
@@ -220,6 +258,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
     std::vector<MatrixTableIndexer::Entry> entries;
     bool last = false;
   };
+  TableIndex pre_index;                 // the calibration's index of an addressable table, reused by the index pass
   std::deque<PlanBatch> plans;          // under mu: index pass -> readers
   std::map<long, Batch> filled;         // under mu: readers -> sequencer (by batch number)
   long next_plan = 0, next_out = 0;     // batches planned / moved to the consumer's queue
@@ -301,7 +340,18 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
     };
     try {
       MatrixTableIndexer::Entry e;
-      while (indexer->Next(&e)) {
+      size_t pre_i = 0;
+      // the calibration's index of the table, when there is one (it is consumed: entries are moved out), else the indexer
+      auto next_entry = [&]() {
+        if (!pre_index.valid) return indexer->Next(&e);
+        if (pre_i < pre_index.entries.size()) {
+          e = std::move(pre_index.entries[pre_i++]);
+          return true;
+        }
+        if (!pre_index.error.empty()) throw KioError(pre_index.error);   // where that index stopped: reported after what precedes it
+        return false;
+      };
+      while (next_entry()) {
         {
           std::unique_lock<std::mutex> lk(mu);
           if (stop) break;
@@ -412,8 +462,15 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
   };
   bool calibrated = !(opt.calibrate && engine->can_switch_fast_mode());   // nothing to choose: no batch is held back
   if (!calibrated && indexer) {
-    // addressable table: the sample is spread over the whole list (SampleTable), drawn before the readers start
-    CalibrateOnTable(engine, opt, feat_rspec, log);
+    // addressable table: the sample is spread over the whole list (SampleTable), drawn before the readers start.  A failure
+    // here (unreadable sample, device error in a candidate arithmetic) is not the job's: the packed arithmetic stays
+    // (Calibrate restores it) and the extraction goes on - and reports a bad object itself, after writing the good ones.
+    try {
+      CalibrateOnTable(engine, opt, feat_rspec, log, &pre_index);
+    } catch (const std::exception& ex) {
+      warn(std::string("calibration failed (") + ex.what() + "); keeping " + PrecisionName(engine->fast_mode()));
+    }
+    share_choice();
     calibrated = true;
   }
   if (indexer) {
@@ -459,10 +516,12 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
     std::vector<int32_t> urows;
     ExtractJob job;
   };
-  Work work[Engine::kNumHostSlots];
+  // slot s of this ring = host slot s / NE of engine s % NE: consecutive batches go to consecutive engines, and the ring order
+  // is the submission order, which is the table order
+  const int NS = Engine::kNumHostSlots * NE;
+  std::vector<Work> work(NS);
   int cur = 0;
-  long seq = 0;
-  constexpr int NS = Engine::kNumHostSlots;
+  std::vector<long> eseq(NE, 0);   // running batch number per engine (selects its lane)
   // stage timing of the consumer thread (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
   const bool timing = getenv("XVEC_TIMING") != nullptr;
   double t_wait = 0, t_pack = 0, t_start = 0, t_fin = 0;
@@ -584,8 +643,8 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
           idx.swap(keep_idx);
           n = (int)idx.size();
           // device path: raw rows in, CMN + selection + network on the lane's stream, nothing comes back but embeddings
-          if (n) submitted = w.job.StartFrontEnd(engine, opt, cur, seq, n, rawp.data(), rrows.data(), vadp.data());
-          if (submitted) ++seq;
+          if (n) submitted = w.job.StartFrontEnd(engines[cur % NE], opt, cur / NE, eseq[cur % NE], n, rawp.data(), rrows.data(), vadp.data());
+          if (submitted) ++eseq[cur % NE];
           if (n && !submitted) {
             // utterances that are cut into several chunks or padded: front-end result back to the host, then Start()
             sel_row.clear();
@@ -616,8 +675,9 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
         t_pack += secs(tp0, tp1);
         if (n) {
           if (!submitted) {
-            if (use_frontend) w.job.Start(engine, opt, cur, seq++, packed.data(), offs.data(), n);   // front-end result (host)
-            else w.job.StartPtrs(engine, opt, cur, seq++, uptr.data(), urows.data(), n);
+            Engine* const eng = engines[cur % NE];
+            if (use_frontend) w.job.Start(eng, opt, cur / NE, eseq[cur % NE]++, packed.data(), offs.data(), n);   // front-end result (host)
+            else w.job.StartPtrs(eng, opt, cur / NE, eseq[cur % NE]++, uptr.data(), urows.data(), n);
           }
           const auto tp2 = now();
           t_start += secs(tp1, tp2);
@@ -666,6 +726,7 @@ TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt,
               log("LOG", "calibration sample: the first " + std::to_string(std::min(cu.size(), (size_t)opt.calibrate_utts)) +
                              " utterances of the stream (a stream cannot be sampled any other way)");
               CalibrateOnUtterances(engine, opt, cu, log);
+              share_choice();
             }
           } catch (const std::exception& ex) {
             fatal = ex.what();

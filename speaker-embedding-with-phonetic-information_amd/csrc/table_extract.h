@@ -5,6 +5,7 @@
 #pragma once
 #include <functional>
 #include <string>
+#include <vector>
 
 #include "engine.h"
 #include "extractor.h"
@@ -24,6 +25,11 @@ typedef std::function<void(const char* level, const std::string& msg)> LogFn;
 
 TableExtractResult RunTableExtraction(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
                                       const std::string& vector_wspecifier, const LogFn& log);
+// One process, several GPUs (nnet3-xvector-compute --devices=...; the `--nj 1` form of extract_xvectors_new.sh:83-93): whole
+// batches dealt round-robin to engines that hold the same model, finalised in submission order through one writer - the
+// output is byte-identical to a one-GPU run.  The arithmetic is calibrated once on engines[0] and applied to the others.
+TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const ExtractOptions& opt,
+                                      const std::string& feature_rspecifier, const std::string& vector_wspecifier, const LogFn& log);
 
 // Engine::Calibrate on the first chunk of up to opt.calibrate_utts utterances: (key, rows, row-major data) triples as the
 // readers deliver them.  The device front-end of opt (sliding CMN, VAD selection) is applied first, like the job will.
@@ -39,8 +45,16 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
 // can be addressed (archive file, script file: the reference's lists are speaker-sorted, utils/data/split_data.sh:18-21, so a
 // head of the list is one or two speakers), the head of the stream otherwise.  Multi-GPU jobs: one rank calibrates on the
 // whole list and the choice is applied on every rank, so that an N-way sharded job computes what the 1-way job does.
+// `index` (optional): receives the index of an addressable table that the sample was drawn from - every entry, those with an
+// error included, and the message of whatever stopped the indexing early - so that the extraction's batching pass can reuse it
+// instead of visiting every header a second time.
+struct TableIndex {
+  bool valid = false;
+  std::vector<MatrixTableIndexer::Entry> entries;
+  std::string error;
+};
 Engine::Calibration CalibrateOnTable(Engine* engine, const ExtractOptions& opt, const std::string& feature_rspecifier,
-                                     const LogFn& log);
+                                     const LogFn& log, TableIndex* index = nullptr);
 
 // nnet3-compute style job: one output MATRIX per utterance (a row per input frame) from a frame-level model
 // (reference call sites: sid/nnet3_cvector/cvector/extract_log_post.sh:77-84, sid/nnet3_cvector/am/extract_bn.sh:68,

@@ -140,7 +140,9 @@ def main(argv=None):
     scp = os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, job))
     done = failed = error = 0
     ctx = None
-    mode = torch.tensor([-1, 0], dtype=torch.int64, device=dev)   # rank 0's calibration: arithmetic, lite-layer mask
+    # rank 0's calibration: arithmetic, lite-layer mask as two 32-bit halves (the C ABI's mask is a uint64; an int64 tensor would
+    # overflow on bit 63 - ADVICE r04)
+    mode = torch.tensor([-1, 0, 0], dtype=torch.int64, device=dev)
     try:
         if not args.dry_run:
             if use_cuda:
@@ -162,17 +164,19 @@ def main(argv=None):
                                           64, args.calibrate_tol)
                 print("rank 0 calibration: %s" % cal, flush=True)
                 mode[0] = P.PRECISIONS[cal["chosen"]]
-                mode[1] = cal.get("lite_mask", 0)
+                mode[1] = cal.get("lite_mask", 0) & 0xFFFFFFFF
+                mode[2] = cal.get("lite_mask", 0) >> 32
     except Exception as e:   # noqa: BLE001 - counted below with the extraction errors
         print("ERROR (dist_extract) rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
         error = 1
     if grouped and not args.dry_run:
-        dist.broadcast(mode, 0)          # two integers: the arithmetic rank 0 chose (bookkeeping, not a data-path collective)
+        dist.broadcast(mode, 0)          # three integers: the arithmetic rank 0 chose (bookkeeping, not a data-path collective)
     try:
         if ctx is not None and not error and int(mode[0]) >= 0 and rank != 0:
             ctx.set_fast_mode(P.PRECISION_NAMES[int(mode[0])])
-            if int(mode[1]):
-                ctx.set_lite_mask(int(mode[1]))
+            lite = int(mode[1]) | (int(mode[2]) << 32)
+            if lite:
+                ctx.set_lite_mask(lite)
         if error:
             pass
         elif args.dry_run:

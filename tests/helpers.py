@@ -32,6 +32,11 @@ TOPOLOGIES = {
     "v4_cvector": (["am", "v4_cvector"], "tdnn6_xvec.affine"),
     "v5_cvector": (["am", "v5_cvector"], "tdnn6_xvec.affine"),
     "pa_wo_pretrain": (["pa_wo_pretrain"], "tdnn6.affine"),
+    # the multitask net sharing 2 / 3 / 4 layers between the senone and the speaker branch
+    # (egs/sre/v3/local/nnet3_cvector/cvector/prepare_nnet3_xconfig_{2,3,4}share.sh:47-69)
+    "v3_2share": (["v3_2share"], "tdnn6_xvec.affine"),
+    "v3_3share": (["v3_3share"], "tdnn6_xvec.affine"),
+    "v3_4share": (["v3_4share"], "tdnn6_xvec.affine"),
 }
 
 

@@ -97,6 +97,15 @@ def test_cli_truncated_archive_is_an_error_at_index_time(job):
         r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine"] + extra +
                  [str(d / "final.raw"), "ark:%s/cut.ark" % d, "ark:/dev/null"])
         assert r.returncode == 255 and b"unexpected end of file" in r.stderr, r.stderr.decode()[-600:]
+    # with the calibration's index of the table reused by the extraction (one pass over the headers instead of two), the bad
+    # object still ends the job, but only after everything in front of it was written - like the sequential reader and like
+    # the reference, which writes each vector as it goes
+    r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine",
+              str(d / "final.raw"), "ark:%s/cut.ark" % d, "ark,scp:%s/cut_out.ark,%s/cut_out.scp" % (d, d)])
+    assert r.returncode == 255 and b"unexpected end of file" in r.stderr, r.stderr.decode()[-600:]
+    written = [k for k, _ in kio.read_ark(str(d / "cut_out.ark"), "vector")]
+    good = [k for k, x in utts[:-1] if x.shape[0] >= 15]
+    assert written == good, (written, good)
     env = dict(os.environ, XVEC_READERS="1")    # the sequential reader: the same verdict
     r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine", "--calibrate=false",
               str(d / "final.raw"), "ark:%s/cut.ark" % d, "ark:/dev/null"], env=env)

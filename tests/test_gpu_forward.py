@@ -237,13 +237,15 @@ def test_v2_single_pass_modes(v2, prec):
     assert err > 1e-6   # it really is a different arithmetic from the parity mode
 
 
-@pytest.mark.parametrize("topology", ["v5_cvector", "v4_cvector", "v3_multitask", "pa_wo_pretrain"])
-def test_other_topologies_parity(topology):
+@pytest.mark.parametrize("topology", ["v5_cvector", "v4_cvector", "v3_multitask", "pa_wo_pretrain", "v3_2share", "v3_3share",
+                                      "v3_4share"])
+@pytest.mark.parametrize("mode", ["bf16x3", "default"])
+def test_other_topologies_parity(topology, mode):
     P = H.pkg()
     net, line = H.synth_model(topology)
     model = P.Model(raw=net.to_bytes(True), nnet_config=line)
-    ctx = P.Context(model, precision=P.PREC_BF16X3)
-    ev32 = _oracle(net, line, np.float32)
+    ctx = P.Context(model, precision=P.PRECISIONS[mode])
+    ev32 = _oracle(net, line, np.float64)
     lens = [400, 21 if "cvector" in topology or topology == "pa_wo_pretrain" else 15, 77]
     utts = [H.features(300 + i, T) for i, T in enumerate(lens)]
     feats, offs = H.pack(utts)

@@ -124,3 +124,46 @@ def test_first_forward_pass_of_a_context_on_a_busy_gpu():
         stop.append(1)
         tn.join()
     assert not bad, bad
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp16x3"])
+def test_config5_full_size_properties(prec):
+    """BASELINE config 5 at full size on one GPU: the multitask net with its senone head (prepare_nnet3_xconfig.sh:53-59),
+    256 chunks of 200-600 frames (seed 5, as bench.py draws them), frame-level log-posteriors - ~100 k rows x 3856 columns.
+    Too large for the oracle, so size-independent properties, on the device buffers:
+      * 32 distinct chunks, each 8 times at shuffled positions: equal inputs give equal rows wherever they sit in the batch;
+      * three chunks computed ALONE give the bits they have inside the full batch (other tile counts, other kernel variants);
+      * every row is a normalised distribution (logsumexp = 0 to fp32 accuracy), finite, with no positive entry;
+      * two chunks against the fp32 oracle: parity tolerance in fp16x3 (nnet3-compute's default arithmetic here), the loose
+        single-pass bound in fp16 (the mode config 5 names)."""
+    torch = pytest.importorskip("torch")
+    P, model, ev = _case(["v3_multitask"], "output_am.log-softmax")
+    ctx = P.Context(model, precision=P.PRECISIONS[prec])
+    rng = np.random.default_rng(5)
+    lens32 = [int(t) for t in rng.integers(200, 601, 32)]
+    pool = [H.features(900 + i, T) for i, T in enumerate(lens32)]
+    order = np.concatenate([rng.permutation(32) for _ in range(8)])
+    utts = [pool[i] for i in order]
+    feats, offs = H.pack(utts)
+    S = model.info.output_dim
+    f_dev = torch.from_numpy(feats).cuda()
+    out = torch.empty(int(offs[-1]), S, dtype=torch.float32, device="cuda")
+    ctx.forward_batch_device(f_dev.data_ptr(), offs, out.data_ptr(), S, None)
+    ctx.synchronize()
+    assert bool(torch.isfinite(out).all()) and float(out.max()) <= 0.0
+    lse = torch.logsumexp(out.double(), dim=1)
+    assert float(lse.abs().max()) < 2e-5, float(lse.abs().max())
+    first = {}
+    for pos, i in enumerate(order):
+        rows = out[int(offs[pos]):int(offs[pos + 1])]
+        if i in first:
+            assert torch.equal(rows, first[i]), (pos, int(i))
+        else:
+            first[int(i)] = rows
+    for i in (0, 7, 31):
+        solo = ctx.forward_batch(pool[i], [0, lens32[i]])
+        assert np.array_equal(solo, first[i].cpu().numpy()), i
+    for i in (3, 20):
+        ref = H.xo.compute_all_frames(ev, pool[i])
+        e = H.rel_err(first[i].cpu().numpy(), ref)
+        assert e < (TOL if prec == "fp16x3" else 5e-3), (prec, i, e)

@@ -258,3 +258,63 @@ def test_dist_extract_two_gpus_over_rccl_equal_one_rank(tmp_path):
         assert v1[k].tobytes() == v2[k].tobytes(), k
     cat = (two / "xvector_t.1.ark").read_bytes() + (two / "xvector_t.2.ark").read_bytes()
     assert cat == (one / "xvector_t.1.ark").read_bytes()
+
+
+def _cli_job(tmp_path, n_utts=150):
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    lens = [400, 137, 25, 333, 1000, 64, 400, 400, 211, 15, 399, 640, 87, 0, 10]
+    utts = [("utt%03d" % i, H.features(900 + i, lens[i % len(lens)]) if lens[i % len(lens)] else np.zeros((0, 23), np.float32))
+            for i in range(n_utts)]
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"))
+    return utts
+
+
+def _cli(tmp_path, tag, extra, env=None):
+    exe = os.path.join(H.ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
+    # small batches, so that a 150-utterance job is many batches and several devices all get some
+    cmd = [exe, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine", "--batch-frames=4096"] + extra + \
+          [str(tmp_path / "final.raw"), "scp:%s/feats.scp" % tmp_path, "ark,scp:%s/%s.ark,%s/%s.scp" % (tmp_path, tag, tmp_path, tag)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {})))
+    return r
+
+
+def test_cli_devices_option_one_device_is_the_one_gpu_job_byte_for_byte(tmp_path):
+    """nnet3-xvector-compute --devices=0 (and XVEC_DEVICES=all on a one-GPU box): the in-binary multi-GPU path with one device -
+    a real ncclBroadcast on a one-rank communicator, the engine built from the device copy, the round-robin dealer with one
+    engine - writes the archive and the script file of the plain one-GPU job, byte for byte (extract_xvectors_new.sh:83-93
+    at --nj 1; SURVEY.md section 7 hard part 8)."""
+    _cli_job(tmp_path)
+    r0 = _cli(tmp_path, "plain", [])
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    r1 = _cli(tmp_path, "dev0", ["--devices=0"])
+    assert r1.returncode == 0 and "one RCCL broadcast" in r1.stderr, r1.stderr[-2000:]
+    assert (tmp_path / "dev0.ark").read_bytes() == (tmp_path / "plain.ark").read_bytes()
+    assert (tmp_path / "dev0.scp").read_text().replace("dev0.ark", "plain.ark") == (tmp_path / "plain.scp").read_text()
+    import torch
+    if torch.cuda.device_count() == 1:
+        r2 = _cli(tmp_path, "all", [], env={"XVEC_DEVICES": "all"})
+        assert r2.returncode == 0 and "1 of 1 devices" in r2.stderr, r2.stderr[-2000:]
+        assert (tmp_path / "all.ark").read_bytes() == (tmp_path / "plain.ark").read_bytes()
+    # a bad list is an error before anything is written
+    r3 = _cli(tmp_path, "bad", ["--devices=0,0"])
+    assert r3.returncode == 255 and "twice" in r3.stderr, r3.stderr[-1000:]
+    r4 = _cli(tmp_path, "bad", ["--devices=97"])
+    assert r4.returncode == 255 and "visible devices" in r4.stderr, r4.stderr[-1000:]
+
+
+def test_cli_devices_all_on_a_multi_gpu_node_equals_one_gpu(tmp_path):
+    """The same with every GPU of the node (skipped on one-GPU boxes; first runs on the driver's 8-GPU node): batches dealt
+    round-robin to N engines, one ordered writer - byte-identical to the one-GPU job, whatever N."""
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    _cli_job(tmp_path, 600)
+    r0 = _cli(tmp_path, "plain", ["--device=0"])
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    r1 = _cli(tmp_path, "two", ["--devices=0,1"])
+    assert r1.returncode == 0 and "2 of" in r1.stderr, r1.stderr[-2000:]
+    assert (tmp_path / "two.ark").read_bytes() == (tmp_path / "plain.ark").read_bytes()
+    r2 = _cli(tmp_path, "all", ["--devices=all"])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert (tmp_path / "all.ark").read_bytes() == (tmp_path / "plain.ark").read_bytes()

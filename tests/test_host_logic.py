@@ -346,3 +346,47 @@ def test_default_precision_policy_is_one_rule_for_every_entry_point():
     cnet, cline = H.synth_model("v5_cvector")     # the c-vector network's 650-wide branch is padded to whole 128-column blocks
     assert packed_precision(P.Model(raw=cnet.to_bytes(True), nnet_config=cline).pack()) == P.PREC_FP16MX2
     assert P.PRECISIONS["default"] == P.PREC_DEFAULT == -1 and P.PRECISION_NAMES[P.PREC_FP16MX2] == "fp16mx2"
+
+
+def test_blob_layer_table_is_validated_before_anything_becomes_a_device_pointer():
+    """every offset of the layer table that the engine turns into base + offset device pointers - the images in the
+    K-walk order of tdnn_gemm_kernel_p8 (w4p / w4bp and their scales) included - is range-checked when the blob is parsed,
+    i.e. before the first HIP call: a corrupt or foreign image is XV_ERR_*, "layer i is inconsistent", never a GPU fault."""
+    import struct
+    net, line = H.synth_model("v2_xvector")
+    blob = bytearray(P.Model(raw=net.to_bytes(True), nnet_config=line).pack(P.PRECISIONS["fp16mx2"]))
+    HDR, LAYER = 112, 320                      # sizeof(BlobHeader), sizeof(BlobLayer) (engine.cc)
+    off = {"w4": 248, "w4_scale": 256, "w4p": 288, "w4p_scale": 296, "w4bp": 304, "w4bp_scale": 312}
+    n_layers = struct.unpack_from("<i", blob, 20)[0]
+    data_offset, total = struct.unpack_from("<QQ", blob, 96)
+    assert total == len(blob) and HDR + n_layers * LAYER <= data_offset
+    names = [bytes(blob[HDR + i * LAYER:HDR + i * LAYER + 64]).split(b"\0")[0].decode() for i in range(n_layers)]
+    i = names.index("tdnn2.batchnorm")
+    base = HDR + i * LAYER
+    NONE = (1 << 64) - 1
+    w4p, w4p_scale = struct.unpack_from("<QQ", blob, base + off["w4p"])
+    assert w4p != NONE and w4p_scale != NONE, "tdnn2 of the x-vector network carries the p8 residual image"
+
+    def message(mutate):
+        b = bytearray(blob)
+        mutate(b)
+        with pytest.raises(P.XvError) as e:
+            P.Context(blob=bytes(b), device=0)
+        return str(e.value)
+    data_bytes = total - data_offset
+    bad = {
+        "w4p beyond the image": lambda b: struct.pack_into("<Q", b, base + off["w4p"], data_bytes - 16),
+        "w4p without its scales": lambda b: struct.pack_into("<Q", b, base + off["w4p_scale"], NONE),
+        "w4p scales beyond the image": lambda b: struct.pack_into("<Q", b, base + off["w4p_scale"], data_bytes - 16),
+        "w4p without w4": lambda b: struct.pack_into("<QQ", b, base + off["w4"], NONE, NONE),
+        "w4bp without w4b": lambda b: (struct.pack_into("<QQ", b, base + off["w4bp"], 0, 0),
+                                       struct.pack_into("<QQ", b, base + 272, NONE, NONE)),      # w4b, w4b_scale
+        "w4bp scales without w4bp": lambda b: struct.pack_into("<QQ", b, base + off["w4bp"], NONE, 0),
+    }
+    for what, mut in bad.items():
+        assert "inconsistent" in message(mut), what
+    # the untouched image gets past the parser: with a GPU it loads, without one the failure is the device's, not the blob's
+    try:
+        P.Context(blob=bytes(blob), device=0).close()
+    except P.XvError as e:
+        assert "inconsistent" not in str(e) and e.status == 3, str(e)
