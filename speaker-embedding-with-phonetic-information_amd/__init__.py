@@ -9,6 +9,7 @@ library is missing or no gfx950 device is present, calls fail loudly.
 import ctypes
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -373,6 +374,42 @@ class Context:
         _check(lib().xv_extract_utterances(self._h, feats.ctypes.data, offs.ctypes.data, n, chunk_size, min_chunk_size,
                                            1 if pad_input else 0, out.ctypes.data, ok.ctypes.data))
         return out, ok.astype(bool)
+
+
+class Watchdog:
+    """Bounded wait for the start-up collective of a multi-rank job (the ONE broadcast of the packed weights, dist_extract.py /
+    bench.py): a rank that never joins - died while loading, a link that is down - would otherwise leave the others inside
+    the collective without a word until someone kills the job.  After `seconds` (XVEC_BCAST_TIMEOUT, default 60) the process
+    prints what it was waiting for and EXITS with status 3; the launcher then tears the other ranks down.  A plain exit of a
+    fresh-started process - nothing is re-executed (a process that has touched the GPU must never exec)."""
+
+    def __init__(self, what, seconds=None):
+        import threading
+        if seconds is None:
+            try:
+                seconds = float(os.environ.get("XVEC_BCAST_TIMEOUT", "60"))
+            except ValueError:
+                seconds = 60.0
+        self.what, self.seconds = what, seconds
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def _fire(self):
+        sys.stderr.write("ERROR (xvec_hip watchdog) rank %s: %s did not complete within %.0f s; exiting\n"
+                         % (os.environ.get("RANK", "0"), self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def cancel(self):
+        self._t.cancel()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.cancel()
+        return False
 
 
 def create_broadcast(model, devices, precision=PREC_DEFAULT):

@@ -16,9 +16,10 @@ namespace {
 
 constexpr int kDefaultFastMinPooledMx2 = 160;   // the deeper c-vector network measured 7.9e-5 at 117 pooled frames (heavy-tailed model)
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 6;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
+constexpr uint32_t kBlobVersion = 7;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
                                        // plane; 4: + the 4-bit weight image of kPrecFp16Mx2; 5: + the residual plane in the
-                                       // K-walk order of tdnn_gemm_kernel_p8; 6: + the 4-bit weight image in the order of ITS second walk
+                                       // K-walk order of tdnn_gemm_kernel_p8; 6: + the 4-bit weight image in the order of ITS second walk;
+                                       // 7: that image only for layers without time offsets (the ones the kernel runs in 1.5 passes)
 constexpr uint64_t kNone = ~0ull;
 
 struct BlobHeader {
@@ -236,9 +237,12 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           cur = Align256(cur + (uint64_t)b.n_pad * b.ldw4b);
           b.w4b_scale = cur;
           cur = Align256(cur + 2 * (uint64_t)b.n_pad * (uint64_t)nsteps);
-          bool lo64 = kP8Mx2Built && b.w4p != kNone;   // tdnn_gemm_kernel_p8's second walk: tiles of 256 columns, i.e. sources of whole multiples of 256
+          // tdnn_gemm_kernel_p8's second walk: tiles of 256 columns, i.e. sources of whole multiples of 256 - and only layers
+          // WITHOUT time offsets: on those the kernel beats tdnn_gemm_kernel_sk in this arithmetic, on the spliced ones it loses
+          // (kernels.h kP8Mx2Built).  A property of the layer: every 1.5-pass launch of the layer runs the same kernel.
+          bool lo64 = kP8Mx2Built && b.w4p != kNone;
           for (int j = 0; j < b.nsrc; ++j)
-            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256) lo64 = false;
+            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256 || b.src_offset[j] != 0) lo64 = false;
           if (lo64) {
             b.w4bp = cur;
             cur = Align256(cur + (uint64_t)b.n_pad * b.k_pad * 2);
@@ -1299,13 +1303,15 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
               rprec = kPrecFp16Mx;
               gr.out_lo4 = nullptr;
               gr.out_lo4s = nullptr;
-              if (use_p8_ && dl.w4p && (epi == kEpiAct || epi == kEpiStats)) {
-                GemmArgs g8 = gr;
-                g8.p8 = 1;
-                g8.w4 = dl.w4p;
-                g8.w4_scale = dl.w4p_scale + (epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0);
-                if (gemm_p8_applicable(g8, kPrecFp16Mx)) gr = g8;
-              }
+            }
+            // (both on the 256 x 256 kernel where the layer's shape allows: the same K walk, so the fp16 plane of a lite layer
+            // has the same bits whether or not it also writes its residual plane)
+            if (use_p8_ && dl.w4p && (epi == kEpiAct || epi == kEpiStats)) {
+              GemmArgs g8 = gr;
+              g8.p8 = 1;
+              g8.w4 = dl.w4p;
+              g8.w4_scale = dl.w4p_scale + (epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0);
+              if (gemm_p8_applicable(g8, rprec)) gr = g8;
             }
           } else if (fast_mx2_) {
             // every layer emits the 4-bit residual of its fp16 plane; a layer that cannot run the second walk reads the

@@ -292,13 +292,12 @@ const char* last_gemm_kernel();
 // with a group-max table, even tile count); otherwise the caller launches kPrecFp16x2 on the same operands.
 bool gemm_mx_applicable(const GemmArgs& a);
 bool gemm_mx2_applicable(const GemmArgs& a);   // kPrecFp16Mx2: also the 4-bit planes, sources of whole 128-column steps
-// The 1.5-pass path of tdnn_gemm_kernel_p8 is experimental and not built by default (kernels.hip, launch_one): the packer then
-// leaves its weight image out of the model blob
-#ifdef XVEC_P8_MX2
+// The 1.5-pass arithmetic on tdnn_gemm_kernel_p8 (round 5: the race of its second walk's scale staging is fixed, every launch
+// test bit-exact and bit-stable under load).  Measured against tdnn_gemm_kernel_sk<fp16mx2> on the bench workload it wins on the
+// layers WITHOUT time offsets (tdnn4 0.130 against 0.141 ms, tdnn5 0.282 against 0.288) and loses on those with (tdnn2 / tdnn3
+// 0.276 / 0.271 against 0.254 / 0.249: it recomputes its staging offsets per DMA for want of registers), so the packer gives
+// only the former its weight image (engine.cc PackModel, blob version 7) and the rule is a property of the layer, never of a launch.
 constexpr bool kP8Mx2Built = true;
-#else
-constexpr bool kP8Mx2Built = false;
-#endif
 // tdnn_gemm_kernel_p8 can run this launch in kPrecFp16 / kPrecFp16Mx (see GemmArgs::p8)
 bool gemm_p8_applicable(const GemmArgs& a, int precision);
 // Stream-K workspace (partial-tile exchange) of a stream: allocated on first use, released by the owner of the

@@ -2279,9 +2279,21 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
   }
 }
 
+#ifdef XVEC_CLOCK_PROBE
+// Measurement build only (tools/clock_probe.py; never defined in the shipped library): the shader clock the chip holds while
+// tdnn_gemm_kernel_p8 runs, from inside the kernel - s_memtime ticks (shader cycles) over s_memrealtime ticks (a constant
+// 100 MHz counter) between a workgroup's first and last instruction.  Slot = launch kind (0: act, <= 8 K tiles; 1: act, more;
+// 2: statistics epilogue), two words per workgroup.
+__device__ unsigned long long g_clock_probe[3 * 512 * 2];
+extern "C" int xvec_clock_probe_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), sizeof(g_clock_probe), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 template <int PREC, int EPI>
 __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
-  static_assert(PREC == kPrecFp16 || PREC == kPrecFp16Mx || PREC == kPrecFp16Mx2, "single-pass fp16, the 1.25- and the 1.5-pass arithmetic");
+  static_assert(PREC == kPrecFp16 || PREC == kPrecFp16Mx || PREC == kPrecFp16Mx2 || PREC == kPrecFp16MxE,
+                "single-pass fp16, the 1.25-pass arithmetic (with or without the residual plane of its output), the 1.5-pass arithmetic");
   constexpr bool MX = PrecMx(PREC);
   constexpr bool MX2 = PrecMx2(PREC);
   constexpr bool SWAP = (EPI != kEpiStats);
@@ -2324,6 +2336,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   // (the launcher sizes the grid so that every share is at least one whole tile: a head and a tail never meet in one tile)
   const int n_parts = (k_tail ? 1 : 0) + (t_end - t_first) + (k_head ? 1 : 0);
   if (s1 <= s0) return;   // an XCD block without row tiles (launches of fewer than eight of them)
+#ifdef XVEC_CLOCK_PROBE
+  const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- staging geometry: a wave stages rows wave * 16 + piece * 8 + (lane >> 3) of every 128-row unit; the lane fetches the
   // logical 16-byte chunk (lane & 7) ^ ((piece * 4 + (lane >> 4)) & 7) of its row.  The per-lane byte offsets of the units live
@@ -2693,19 +2708,25 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   // The eight phases of a tile pair (tile t in buffer 0, t + 1 in buffer 1) of the first (LL = 0) or the second walk.  n_left =
   // tiles of the part from t on: what a phase stages exists only while the part goes on - (t,0) (t,1): tile t+1's second half,
   // (t,2) (t,3): tile t+2's first half (+ its scales, second walk), and so on; a part's last pair may hold one tile only.
-  auto pair = [&](auto LL, const int n_left, const int blk) __attribute__((always_inline)) {
+  // Second-walk scales (kPrecFp16Mx2): the scales of tile u go to scale buffer u & 1 and are read in phases (u,0) and (u,2) - by
+  // wave group 1 one barrier interval after group 0.  They are therefore staged in phase (u-1,0): every wave of BOTH groups is
+  // past its last read of tile u-2's scales (LOAD(u-2,2), at least two barrier intervals earlier), and the wait at the end of
+  // LOAD(u-1,3) covers them.  (Round 4 staged them in phase (u-2,2), into the buffer the late group was still reading in ITS
+  // phase (u-2,2): the race tools/repeat_mx_case.py showed on every launch with time offsets.)  `first`: the part's first
+  // pair, whose tiles' scales open_part staged.
+  auto pair = [&](auto LL, const int n_left, const int blk, const bool first) __attribute__((always_inline)) {
     constexpr int LOW = decltype(LL)::value;
     const bool t1 = n_left > 1, t2 = n_left > 2, t3 = n_left > 3;
-    phase(I0{}, I0{}, I0{}, LL, t1 ? 2 : -1, 1, -1, -1, t3);
+    phase(I0{}, I0{}, I0{}, LL, t1 ? 2 : -1, 1, -1, (MX2 && t1 && !first && it >= S) ? 1 : -1, t3);
     phase(I1{}, I0{}, I0{}, LL, t1 ? 3 : -1, 1, (MX && !LOW) ? blk : -1, -1, t3);
     if (t2) adv();
-    phase(I2{}, I0{}, I0{}, LL, t2 ? 0 : -1, 0, -1, (MX2 && t2 && it >= S) ? 0 : -1, t3);
+    phase(I2{}, I0{}, I0{}, LL, t2 ? 0 : -1, 0, -1, -1, t3);
     phase(I3{}, I0{}, I0{}, LL, t2 ? 1 : -1, 0, -1, -1, t3);
     if (t1) {
-      phase(I0{}, I1{}, I1{}, LL, t2 ? 2 : -1, 0, -1, -1, t3);
+      phase(I0{}, I1{}, I1{}, LL, t2 ? 2 : -1, 0, -1, (MX2 && t2 && it >= S) ? 0 : -1, t3);
       phase(I1{}, I1{}, I1{}, LL, t2 ? 3 : -1, 0, -1, -1, t3);
       if (t3) adv();
-      phase(I2{}, I1{}, I1{}, LL, t3 ? 0 : -1, 1, -1, (MX2 && t3 && it >= S) ? 1 : -1, t3);
+      phase(I2{}, I1{}, I1{}, LL, t3 ? 0 : -1, 1, -1, -1, t3);
       phase(I3{}, I1{}, I1{}, LL, t3 ? 1 : -1, 1, -1, -1, t3);
     }
   };
@@ -2840,11 +2861,11 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
         }
         r_left -= 2;
       }
-      pair(I0{}, ntp - t, (kb_part + t) >> 1);
+      pair(I0{}, ntp - t, (kb_part + t) >> 1, t == 0);
     }
     if constexpr (MX2) {
 #pragma nounroll
-      for (int t = n_hi; t < ntp; t += 2) pair(I1{}, ntp - t, 0);
+      for (int t = n_hi; t < ntp; t += 2) pair(I1{}, ntp - t, 0, t == 0);
     }
     if (wn == 0) barrier();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
@@ -2878,6 +2899,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       }
     }
   }
+#ifdef XVEC_CLOCK_PROBE
+  if (tid == 0 && bid < 512) {
+    const int slot = EPI == kEpiStats ? 2 : (S > 8 ? 1 : 0);
+    g_clock_probe[(slot * 512 + bid) * 2] = __builtin_readcyclecounter() - clk_t0;
+    g_clock_probe[(slot * 512 + bid) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
 }
 
 // Workspace of the stream-K variant (one slot of raw accumulators + one flag per workgroup), per stream: launches on
@@ -3034,7 +3062,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
 // 128-column blocks for kPrecFp16Mx), an even number of K tiles, and for kPrecFp16Mx the residual plane in ITS walk order
 // (GemmArgs::p8 is the caller's statement that w4 / w4_scale are in that order)
 bool gemm_p8_applicable(const GemmArgs& a, int precision) {
-  if (precision == kPrecFp16Mx2 && !kP8Mx2Built) return false;   // experimental, not built by default (launch_one)
+  if (precision == kPrecFp16MxE) precision = kPrecFp16Mx;   // the same product; its planes epilogue also writes the residual plane
   if (precision != kPrecFp16 && precision != kPrecFp16Mx && precision != kPrecFp16Mx2) return false;
   if ((a.m_tiles & 1) || (a.n_tiles & 1) || a.ksplit > 1) return false;
   const bool mx = precision != kPrecFp16, mx2 = precision == kPrecFp16Mx2;
@@ -3135,13 +3163,8 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (a.p8) {   // the caller packed / chose this layer for the 64-column K walk: no other kernel accumulates in that order
-    // kPrecFp16Mx2: the kernel's second-walk path (tiles of 256 4-bit columns through the same phases) is written, compiles
-    // without scratch and passes 27 of its 28 kernel tests - and is NOT built by default (-DXVEC_P8_MX2 builds it): measured on
-    // the bench workload it loses to tdnn_gemm_kernel_sk where the time is (tdnn2 / tdnn3 0.279 / 0.272 ms against 0.251 / 0.247;
-    // tdnn4 0.131 against 0.144; whole step 237 k against 246 k utt/s), one statistics-epilogue case with cuts inside a
-    // time-offset group differs from the emulation, and two runs differ in the last bits (a race somewhere in the second walk's
-    // staging).  The 1.5-pass launches stay on tdnn_gemm_kernel_sk.
-    if constexpr ((PREC == kPrecFp16 || PREC == kPrecFp16Mx || (kP8Mx2Built && PREC == kPrecFp16Mx2)) && (EPI == kEpiAct || EPI == kEpiStats))
+    if constexpr (((PREC == kPrecFp16 || PREC == kPrecFp16Mx || PREC == kPrecFp16Mx2) && (EPI == kEpiAct || EPI == kEpiStats)) ||
+                  (PREC == kPrecFp16MxE && EPI == kEpiAct))
       return launch_one_p8<PREC, EPI>(a, s);
     else return hipErrorInvalidValue;
   }
@@ -3265,7 +3288,7 @@ static hipError_t launch_prec(const GemmArgs& a, int epi, hipStream_t s) {
     if (a.ksplit > 1 || epi != kEpiAct || !a.out_lo4 || !a.out_lo4s) return hipErrorInvalidValue;
     return launch_one<PREC, kEpiAct>(a, s);
   } else if constexpr (PREC == kPrecFp16MxE) {   // planes out only: the 1.25-pass product in front of a kPrecFp16Mx2 consumer
-    if (a.ksplit > 1 || epi != kEpiAct || !a.out_lo4 || !a.out_lo4s || a.p8) return hipErrorInvalidValue;
+    if (a.ksplit > 1 || epi != kEpiAct || !a.out_lo4 || !a.out_lo4s) return hipErrorInvalidValue;
     return launch_one<PREC, kEpiAct>(a, s);
   } else if constexpr (PrecMx(PREC)) {   // frame-level layers only: planes out or pooled statistics
     if (a.ksplit > 1) return hipErrorInvalidValue;

@@ -2,6 +2,7 @@
 #include "program.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <map>
@@ -226,7 +227,62 @@ TdnnProgram LowerToProgram(const RawNnet& net, const std::string& output_name) {
   for (const AffineLayer& L : p.layers)
     for (const LayerSource& s : L.src)
       if (std::abs(s.offset) > 15) throw KioError("time offsets beyond +-15 frames are not supported (layer " + L.name + ")");
+  const char* e = getenv("XVEC_BN_FOLD");   // 0: keep every BatchNorm in its producer's epilogue (A/B against round 4's planes)
+  if (!(e && *e && atoi(e) == 0)) FoldBatchNormIntoConsumers(&p);
   return p;
+}
+
+// A frame-level layer .affine -> .relu -> .batchnorm (basic_layers.py:778-816) whose value is only read by other layers need
+// not STORE y = s * relu(z) + o: with s = m * 2^e (m in [1, 2)) it stores r' = relu(z) * 2^e - a power-of-two scaling, exact in
+// every arithmetic - and each consumer computes  W . (m r' + o) + b = (W diag(m)) . r' + (b + W . o)  instead: the mantissa of the
+// scale goes into the consumer's weight columns, the offset into its bias.  Legal because nnet3 never pads in time: every frame
+// a consumer's valid row reads is a computed frame of the source (rows at chunk edges, which read neighbouring data, are never
+// consumed - DESIGN.md section 2), so "+ W . o" is the same constant for every valid row.
+// Why (CPU study tools/sim_bn_fold.py): (1) what the fp16 plane rounds is then the ReLU output itself - the
+// entries the ReLU cut are exact zeros where today they are fp16(o), and on models whose BatchNorm statistics are spread over
+// decades (what training leaves: helpers.trained_like_model) the error of the 1.25-pass arithmetic drops from 1.0 - 1.5e-4 to
+// 0.75 - 1.0e-4 (mean of 6 chunks; init-like models: 4.8e-5 either way); (2) planes that are half exact zeros cost the chip less
+// power per MFMA, which it gives back as clock.  Nothing changes for the kernels: the producer's epilogue still applies "scale,
+// offset" - they are now (2^e, 0).  The pooled layer (its statistics are the consumer) and the output layer keep their BatchNorm.
+void FoldBatchNormIntoConsumers(TdnnProgram* p) {
+  const int n = (int)p->layers.size();
+  for (int i = 0; i < n; ++i) {
+    AffineLayer& S = p->layers[i];
+    if (S.segment_level || !S.relu || !S.bn || S.log_softmax || i == p->pooled_layer || i == p->output_layer) continue;
+    bool consumed = false, ok = true;
+    for (int c = 0; c < S.out_dim && ok; ++c) ok = std::isfinite(S.bn_scale[c]) && S.bn_scale[c] > 0.f && std::isfinite(S.bn_offset[c]);
+    for (int k = i + 1; k < n; ++k)
+      for (const LayerSource& src : p->layers[k].src) consumed = consumed || src.layer == i;
+    if (!ok || !consumed) continue;
+    std::vector<double> mant(S.out_dim), off(S.out_dim);
+    for (int c = 0; c < S.out_dim; ++c) {
+      int ex = 0;
+      const double fr = frexp((double)S.bn_scale[c], &ex);   // s = fr * 2^ex, fr in [0.5, 1)
+      mant[c] = 2.0 * fr;                                    // m in [1, 2)
+      off[c] = S.bn_offset[c];
+      S.bn_scale[c] = (float)ldexp(1.0, ex - 1);
+      S.bn_offset[c] = 0.f;
+    }
+    for (int k = i + 1; k < n; ++k) {
+      AffineLayer& C = p->layers[k];
+      int k0 = 0;
+      for (const LayerSource& src : C.src) {
+        if (src.layer == i) {
+          for (int r = 0; r < C.out_dim; ++r) {
+            float* w = &C.w[(size_t)r * C.in_dim + k0];
+            double acc = 0.0;
+            for (int c = 0; c < src.dim; ++c) {
+              acc += (double)w[c] * off[c];
+              w[c] = (float)((double)w[c] * mant[c]);
+            }
+            C.bias[r] = (float)((double)C.bias[r] + acc);
+          }
+        }
+        k0 += src.dim;
+      }
+    }
+    S.bn_folded = true;
+  }
 }
 
 double TdnnProgram::Macs(int T) const {
@@ -260,7 +316,7 @@ std::string TdnnProgram::Describe() const {
   for (size_t i = 0; i < layers.size(); ++i) {
     const AffineLayer& L = layers[i];
     o << "  [" << i << "] " << L.out_node << "  " << L.in_dim << "->" << L.out_dim << (L.relu ? " relu" : "")
-      << (L.bn ? " bn" : "") << (L.log_softmax ? " log-softmax" : "") << (L.segment_level ? " (segment)" : "") << "  src:";
+      << (L.bn ? (L.bn_folded ? " bn(folded)" : " bn") : "") << (L.log_softmax ? " log-softmax" : "") << (L.segment_level ? " (segment)" : "") << "  src:";
     for (const LayerSource& s : L.src) {
       if (s.layer == kSrcInput) o << " input";
       else if (s.layer == kSrcPooled) o << " pooled";

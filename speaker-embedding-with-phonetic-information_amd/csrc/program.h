@@ -34,6 +34,7 @@ struct AffineLayer {
   std::vector<float> bias;        // [out_dim]
   bool relu = false, bn = false;
   std::vector<float> bn_scale, bn_offset;  // test-mode BatchNorm: y = x*scale + offset
+  bool bn_folded = false;         // FoldBatchNormIntoConsumers: bn_scale is a power of two, bn_offset 0; the rest is in the consumers' w / bias
   bool log_softmax = false;       // LogSoftmaxComponent after the affine (frame-level heads)
   bool segment_level = false;     // computed once per chunk (after the pooling)
   int left = 0, right = 0;        // frames not computable at the left / right edge (frame-level)
@@ -60,5 +61,8 @@ struct TdnnProgram {
 // Lowers the dependency cone of output node `output_name` ("output" in every recipe).  Throws KioError
 // with a precise message when the graph is outside the supported grammar.
 TdnnProgram LowerToProgram(const RawNnet& net, const std::string& output_name);
+// Moves the BatchNorm of every frame-level relu + batchnorm layer that only feeds other layers into those consumers (program.cc);
+// applied by LowerToProgram unless XVEC_BN_FOLD=0.
+void FoldBatchNormIntoConsumers(TdnnProgram* p);
 
 }  // namespace xv

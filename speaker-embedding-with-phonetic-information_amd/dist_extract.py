@@ -113,19 +113,21 @@ def main(argv=None):
             size = torch.tensor([-1], dtype=torch.int64, device=dev)
     else:
         size = torch.zeros(1, dtype=torch.int64, device=dev)
-    if grouped:
-        dist.broadcast(size, 0)
-    nbytes = int(size.item())
-    if nbytes < 0:
-        return finish(1)
-    if rank == 0:
-        wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    else:
-        wt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if grouped:
-        dist.broadcast(wt, 0)       # the ONE data collective of this path: the packed weights, over xGMI with RCCL
-        if use_cuda:
-            torch.cuda.synchronize()
+    # (bounded: a rank that never joins becomes an error message and exit status 3 after XVEC_BCAST_TIMEOUT seconds, not a hang)
+    with P.Watchdog("the broadcast of the packed weights (%d ranks, backend %s)" % (world, args.backend)):
+        if grouped:
+            dist.broadcast(size, 0)
+        nbytes = int(size.item())
+        if nbytes < 0:
+            return finish(1)
+        if rank == 0:
+            wt = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        else:
+            wt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if grouped:
+            dist.broadcast(wt, 0)       # the ONE data collective of this path: the packed weights, over xGMI with RCCL
+            if use_cuda:
+                torch.cuda.synchronize()
 
     # ---- this rank's contiguous slice of the utterance list -----------------------------------------------------
     lines = [l for l in open(args.feats_scp) if l.strip()]

@@ -77,3 +77,20 @@ def test_rank0_model_failure_reaches_every_rank(tmp_path):
                        env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode != 0
     assert "rank 0 could not load the model" in r.stdout
+
+
+def test_broadcast_watchdog_turns_a_stalled_collective_into_an_exit_status():
+    """the start-up broadcast of dist_extract.py / bench.py is bracketed by a watchdog - a rank that waits
+    longer than XVEC_BCAST_TIMEOUT for the others exits with status 3 and says what it waited for (a plain exit of the process,
+    nothing is re-executed); a collective that completes in time cancels it."""
+    code = ("import importlib, sys, time; sys.path.insert(0, %r); P = importlib.import_module(%r)\n"
+            "with P.Watchdog('a quick collective'):\n    pass\n"
+            "time.sleep(0.5)\n"
+            "print('survived the cancelled one', flush=True)\n"
+            "with P.Watchdog('the broadcast of the packed weights (2 ranks, backend gloo)'):\n    time.sleep(30)\n"
+            "print('not reached')\n") % (H.ROOT, H.PKG_NAME)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60,
+                       env=dict(os.environ, XVEC_BCAST_TIMEOUT="0.3", RANK="1"))
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    assert "survived the cancelled one" in r.stdout and "not reached" not in r.stdout
+    assert "rank 1: the broadcast of the packed weights (2 ranks, backend gloo) did not complete within" in r.stderr, r.stderr

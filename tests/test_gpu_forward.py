@@ -363,7 +363,12 @@ def test_full_size_batch_properties(topology, mode):
     assert ("<%s," % want) in ran, ran
     if mode == "default":
         assert ctx.precision == P.PREC_FP16MX2
-        assert "tdnn_gemm_kernel_sk<fp16mx2,stats,8>" in ran, ran
+        # 1.5 passes: the layers without time offsets on the 256 x 256 kernel (x-vector: tdnn4, tdnn5 - K = 512), the spliced
+        # ones and those whose sources are not whole 256-column tiles (c-vector tdnn5_xvec: 512 + 128) on the stream-K kernel
+        want_stats = "tdnn_gemm_kernel_p8<fp16mx2,stats>" if topology == "v2_xvector" else "tdnn_gemm_kernel_sk<fp16mx2,stats,8>"
+        assert want_stats in ran, ran
+        if topology == "v2_xvector":
+            assert "tdnn4.batchnorm tdnn_gemm_kernel_p8<fp16mx2,act>" in ran, ran
 
 
 def test_calibration_sample_covers_the_whole_table(tmp_path):

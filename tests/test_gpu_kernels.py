@@ -559,3 +559,79 @@ def test_gemm_p8_refuses_unsuitable_launch():
         _run_case(3, 0, 2 * 256, 512, P8_PLAIN, relu=True, bn=True, seed=1, p8=1)          # three-pass arithmetic
     with pytest.raises(P.XvError):
         _run_case(2, 0, 2 * 256, 512, [(0, 96, 0, 96)], relu=True, bn=True, seed=1, p8=1)  # K not in whole 64-column tiles
+
+
+# ---- the 1.5-pass arithmetic (kPrecFp16Mx2) on tdnn_gemm_kernel_p8: behind the fp16 tiles a second walk over the activations'
+# 4-bit residual planes and the 4-bit image of the weights, in tiles of 256 4-bit columns (sources of whole 256-column tiles)
+P8_AM768 = [(0, 768, -3, 768), (0, 768, 0, 768), (0, 768, 3, 768)]
+P8_TWO256 = [(0, 512, 0, 512), (1, 256, 0, 256)]
+P8_MX2_CASES = [P8_TDNN2, P8_TDNN3, P8_PLAIN, P8_AM768, P8_TWO256]
+P8_MX2_IDS = ["tdnn2", "tdnn3", "tdnn4", "am768", "two"]
+
+
+def _p8_mx2(epi, rows, n_pad, segs, seed, **kw):
+    return _run_mx_case(epi, rows, n_pad, segs, seed=seed, prec=7, p8=1, **kw)
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", P8_MX2_CASES, ids=P8_MX2_IDS)
+def test_gemm_p8_mx2_small_launch(epi, segs):
+    out, ref = _p8_mx2(epi, 3 * 256, 768 if segs is P8_AM768 else 512, segs, 27)
+    _p8_check(out, ref, epi, TOL[4] + 2.0 ** -13)
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("segs", P8_MX2_CASES, ids=P8_MX2_IDS)
+def test_gemm_p8_mx2_stream_k(epi, segs):
+    # 100 row tiles: every workgroup a head part, whole tiles and a tail part, cut inside either walk
+    out, ref = _p8_mx2(epi, 100 * 256, 768 if segs is P8_AM768 else 512, segs, 28)
+    _p8_check(out, ref, epi, TOL[4] + 2.0 ** -13)
+
+
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("rows", [100 * 256, 3 * 256], ids=["stream_k", "small"])
+def test_gemm_p8_mx2_is_bit_stable_under_load(epi, rows):
+    """The launches that differed from run to run in round 4 (every one with time offsets; tools/repeat_mx_case.py): the scales
+    of a second-walk tile were staged into the buffer the late wave group was still reading.  The same launch 40 times beside a
+    stream that keeps the CUs and the memory system busy: bit-identical."""
+    import threading
+    torch = _torch()
+    stop = []
+
+    def noise():
+        st = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+        b = torch.randn(1 << 25, device="cuda")
+        with torch.cuda.stream(st):
+            while not stop:
+                for _ in range(4):
+                    (a @ a)
+                    b.add_(1.0)
+                st.synchronize()
+    tn = threading.Thread(target=noise)
+    tn.start()
+    try:
+        ref, bad = None, 0
+        for i in range(40):
+            out = _p8_mx2(epi, rows, 512, P8_TDNN3, 29)[0]
+            if ref is None:
+                ref = out
+            elif not np.array_equal(ref, out):
+                bad += 1
+    finally:
+        stop.append(1)
+        tn.join()
+    assert bad == 0, "%d of 39 repeats differ" % bad
+
+
+@pytest.mark.parametrize("rows", [100 * 256, 3 * 256], ids=["stream_k", "small"])
+@pytest.mark.parametrize("segs", [P8_TDNN3, P8_AM768, P8_PLAIN], ids=["tdnn3", "am768", "tdnn4"])
+def test_gemm_p8_mxe_is_the_p8_mx_product_with_the_residual_plane_of_its_output(rows, segs):
+    """Precision 9 on tdnn_gemm_kernel_p8 (a lite layer of a calibrated mixture whose consumer still walks its residual plane):
+    the fp16 plane has the bits of precision 6 on the same kernel, and plane + 4-bit residual is two to three bits closer to the
+    exact result."""
+    n_pad = 768 if segs is P8_AM768 else 512
+    full, ref, hi = _run_mx_case(0, rows, n_pad, segs, seed=31, prec=9, p8=1)
+    plain, _ = _run_mx_case(0, rows, n_pad, segs, seed=31, prec=6, p8=1)
+    assert np.array_equal(hi.astype(np.float64), plain)
+    assert np.abs(full - ref).max() / np.abs(ref).max() < TOL[4] + 2.0 ** -13

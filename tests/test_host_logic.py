@@ -65,6 +65,16 @@ def test_binary_and_text_models_pack_identically():
     assert len(c) < len(a)        # single plane instead of hi+lo
 
 
+def _bn_mantissa(net, bn_name):
+    """FoldBatchNormIntoConsumers (csrc/program.cc): the BatchNorm of a relu-batchnorm layer that only feeds other layers moves
+    into its consumers - s = m * 2^e, the producer keeps 2^e, the consumer's weight columns take m in [1, 2) (and its bias W . o).
+    Returns m per column of the producing layer, as the library computes it (float scale, double arithmetic)."""
+    c = net.components[bn_name]
+    s = (np.float64(c.f.get("target_rms", 1.0)) * (np.asarray(c.f["stats_var"], np.float64) + c.f.get("epsilon", 1e-3)) ** -0.5).astype(np.float32)
+    fr, _ = np.frexp(s.astype(np.float64))
+    return 2.0 * fr
+
+
 def test_split_fp16_modes_share_one_weight_image_scaled_by_a_power_of_two():
     """fp16x3 / fp16x2 are kernel policies over the same packed weights: fp16 hi + lo planes of W * 2^S, S chosen so that
     max |w| * 2^S lies in [2^13, 2^14) (the residual plane then holds fp16 normals); the exact inverse sits in the
@@ -78,7 +88,8 @@ def test_split_fp16_modes_share_one_weight_image_scaled_by_a_power_of_two():
     diff = [i for i in range(len(blobs[0])) if blobs[0][i] != blobs[1][i]]
     assert 0 < len(diff) <= 4
     assert len(m.pack(P.PREC_AUTO)) >= len(blobs[0]) and len(m.pack(P.PRECISIONS["fp16mx2"])) >= len(blobs[0])
-    w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12 x 12
+    # tdnn4 reads tdnn3.batchnorm: its columns carry the mantissa of that BatchNorm's scale (program.cc FoldBatchNormIntoConsumers)
+    w = (np.asarray(net.components["tdnn4.affine"].f["linear"], np.float64) * _bn_mantissa(net, "tdnn3.batchnorm")[None, :]).astype(np.float32)     # 12 x 12
     scale = 2.0 ** (14 - np.frexp(np.abs(w).max())[1])
     assert 2 ** 13 <= np.abs(w).max() * scale < 2 ** 14
     u16 = np.frombuffer(blobs[0], dtype=np.uint16)
@@ -99,7 +110,7 @@ def test_packed_weights_are_the_split_of_the_fp32_weights():
     net = H.nm.synthesize(H.tiny_config(), seed=3)
     blob = P.Model(raw=net.to_bytes(True)).pack(P.PREC_BF16X3)
     # hi + lo reproduces every weight to ~2^-17 relative: find tdnn2's [12 x 24] block by value search
-    w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12x12, K padded to 32, N to 128
+    w = (np.asarray(net.components["tdnn4.affine"].f["linear"], np.float64) * _bn_mantissa(net, "tdnn3.batchnorm")[None, :]).astype(np.float32)     # 12x12, K padded to 32, N to 128
     u16 = np.frombuffer(blob, dtype=np.uint16)
     f = (u16.astype(np.uint32) << 16).view(np.float32)
     hi = (np.frombuffer(w.tobytes(), np.uint32) + 0x7FFF + ((np.frombuffer(w.tobytes(), np.uint32) >> 16) & 1)) >> 16
