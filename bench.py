@@ -485,17 +485,31 @@ def main():
             achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
             pname = re.search(r"<(\w+),", dom)
             passes = KERNEL_PASSES.get(pname.group(1) if pname else "", None)
-            traffic = None
+            # HBM-side bytes per launch of that kernel: PMC counters cannot be read by the run that is being timed, so they come
+            # from the last rocprofv3 --pmc passes over this same command (tools/profile_gpu.sh -> tools/parse_rocprof.py ->
+            # profiles/pmc_traffic.json), STAMPED with the hash of the kernel sources they were collected on: counters of another
+            # kernel build are refused (traffic = null) instead of going stale silently
+            traffic, traffic_note = None, "profiles/pmc_traffic.json not found"
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch", {}).get(dom)
-                except Exception:
-                    traffic = None
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    from parse_rocprof import kernels_sha16
+                    pj = json.load(open(pmc))
+                    have, want = pj.get("kernels_sha16"), kernels_sha16()
+                    if have == want:
+                        traffic = pj.get("hbm_bytes_per_launch", {}).get(dom)
+                        traffic_note = ("profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this kernel, "
+                                        "separate passes (MI355X_MICROARCH.md, HBM section), collected on this kernel build (kernels_sha16 %s); "
+                                        "not measured by this run" % (pj.get("source"), want))
+                    else:
+                        traffic_note = ("profiles/pmc_traffic.json is stale: collected on kernels_sha16 %s, this tree is %s - re-run "
+                                        "tools/profile_gpu.sh + tools/parse_rocprof.py" % (have, want))
+                except Exception as e:   # noqa: BLE001
+                    traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
             roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this "
-                                          "kernel, separate passes (MI355X_MICROARCH.md, HBM section); not measured by this run",
+                        "traffic_source": traffic_note,
                         "kernel": dom, "layers": g["layers"], "launches_per_step": g["launches"],
                         "avg_launch_ms": g["ms"] / g["launches"], "alg_flops_per_launch": g["flops"] / g["launches"],
                         "mfma_per_alg_mac": passes,

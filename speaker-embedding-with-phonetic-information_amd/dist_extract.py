@@ -195,6 +195,12 @@ def main(argv=None):
     except Exception as e:   # noqa: BLE001 - counted; the other ranks learn of it through the all_reduce below
         print("ERROR (dist_extract) rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
         error = 1
+    # host budget of this rank: CPU seconds (user + system, all threads) per utterance - at 8 ranks per node the readers, the
+    # packing and the writer of every rank share the node's cores (the test boxes give a job 16)
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    print("rank %d host cpu: %.2f s user + %.2f s system for %d utterances = %.1f us of CPU per utterance"
+          % (rank, ru.ru_utime, ru.ru_stime, done + failed, 1e6 * (ru.ru_utime + ru.ru_stime) / max(1, done + failed)), flush=True)
     counts = torch.tensor([done, failed, error], dtype=torch.int64, device=dev)
     if grouped:
         dist.all_reduce(counts)          # bookkeeping only (3 integers); no data-path collective exists

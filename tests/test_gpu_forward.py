@@ -511,3 +511,24 @@ def test_calibration_mixes_the_two_fast_arithmetics_on_the_cvector_network():
     c2 = P.Context(model)
     cal2 = c2.calibrate(fr, orr, tol)
     assert cal2["checked"] == 24 and cal2["checked_mx"] == 18 and cal2["chosen"] == "fp16mx2" and not cal2.get("lite_mask"), cal2
+
+
+def test_bn_fold_opt_in_is_the_same_function(monkeypatch):
+    """XVEC_BN_FOLD=1 (csrc/program.cc FoldBatchNormIntoConsumers, profiles/r05_bn_fold.md): the folded program computes the same
+    function - the parity-grade arithmetic agrees with the fp64 oracle as closely as the unfolded one, the shipped default stays
+    within the bar - on the x-vector and on the two-branch c-vector graph (a consumer with two folded sources)."""
+    P = H.pkg()
+    for topology in ("v2_xvector", "v5_cvector"):
+        net, line = H.synth_model(topology)
+        monkeypatch.setenv("XVEC_BN_FOLD", "1")
+        model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+        monkeypatch.delenv("XVEC_BN_FOLD")
+        assert "bn(folded)" in model.describe()
+        ev64 = _oracle(net, line, np.float64)
+        utts = [H.features(4400 + i, T) for i, T in enumerate([400, 21, 137, 333])]
+        feats, offs = H.pack(utts)
+        ref = np.stack([ev64.compute(u)[0] for u in utts])
+        e3 = H.rel_err(P.Context(model, precision=P.PREC_FP16X3).forward_batch(feats, offs), ref)
+        ed = H.rel_err(P.Context(model).forward_batch(feats, offs), ref)
+        print("%s folded: fp16x3 %.2e, default %.2e" % (topology, e3, ed))
+        assert e3 < 3e-6 and ed < TOL_PARITY, (topology, e3, ed)

@@ -88,8 +88,7 @@ def test_split_fp16_modes_share_one_weight_image_scaled_by_a_power_of_two():
     diff = [i for i in range(len(blobs[0])) if blobs[0][i] != blobs[1][i]]
     assert 0 < len(diff) <= 4
     assert len(m.pack(P.PREC_AUTO)) >= len(blobs[0]) and len(m.pack(P.PRECISIONS["fp16mx2"])) >= len(blobs[0])
-    # tdnn4 reads tdnn3.batchnorm: its columns carry the mantissa of that BatchNorm's scale (program.cc FoldBatchNormIntoConsumers)
-    w = (np.asarray(net.components["tdnn4.affine"].f["linear"], np.float64) * _bn_mantissa(net, "tdnn3.batchnorm")[None, :]).astype(np.float32)     # 12 x 12
+    w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12 x 12
     scale = 2.0 ** (14 - np.frexp(np.abs(w).max())[1])
     assert 2 ** 13 <= np.abs(w).max() * scale < 2 ** 14
     u16 = np.frombuffer(blobs[0], dtype=np.uint16)
@@ -110,7 +109,7 @@ def test_packed_weights_are_the_split_of_the_fp32_weights():
     net = H.nm.synthesize(H.tiny_config(), seed=3)
     blob = P.Model(raw=net.to_bytes(True)).pack(P.PREC_BF16X3)
     # hi + lo reproduces every weight to ~2^-17 relative: find tdnn2's [12 x 24] block by value search
-    w = (np.asarray(net.components["tdnn4.affine"].f["linear"], np.float64) * _bn_mantissa(net, "tdnn3.batchnorm")[None, :]).astype(np.float32)     # 12x12, K padded to 32, N to 128
+    w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12x12, K padded to 32, N to 128
     u16 = np.frombuffer(blob, dtype=np.uint16)
     f = (u16.astype(np.uint32) << 16).view(np.float32)
     hi = (np.frombuffer(w.tobytes(), np.uint32) + 0x7FFF + ((np.frombuffer(w.tobytes(), np.uint32) >> 16) & 1)) >> 16
@@ -401,3 +400,24 @@ def test_blob_layer_table_is_validated_before_anything_becomes_a_device_pointer(
         P.Context(blob=bytes(blob), device=0).close()
     except P.XvError as e:
         assert "inconsistent" not in str(e) and e.status == 3, str(e)
+
+
+def test_bn_fold_is_opt_in_and_moves_the_mantissa_into_the_consumer(monkeypatch):
+    """XVEC_BN_FOLD=1 (csrc/program.cc FoldBatchNormIntoConsumers; OFF by default - measured in round 5, it costs the fast
+    arithmetics the averaging of their weight-side errors): the packed image of tdnn4 then holds W * diag(m) with m the mantissa
+    of tdnn3.batchnorm's scale, and the describe table says which layers gave their BatchNorm away."""
+    net = H.nm.synthesize(H.tiny_config(), seed=3)
+    plain = P.Model(raw=net.to_bytes(True))
+    assert "folded" not in plain.describe()
+    monkeypatch.setenv("XVEC_BN_FOLD", "1")
+    folded = P.Model(raw=net.to_bytes(True))
+    monkeypatch.delenv("XVEC_BN_FOLD")
+    d = folded.describe()
+    assert d.count("bn(folded)") == 4 and "tdnn5.batchnorm" in d     # tdnn1-4 feed other layers; tdnn5 feeds the pooling
+    blob = folded.pack(P.PREC_BF16X3)
+    assert blob != plain.pack(P.PREC_BF16X3)
+    w = (np.asarray(net.components["tdnn4.affine"].f["linear"], np.float64) * _bn_mantissa(net, "tdnn3.batchnorm")[None, :]).astype(np.float32)
+    u16 = np.frombuffer(blob, dtype=np.uint16)
+    bits = np.frombuffer(w.tobytes(), np.uint32)
+    first_row = ((bits + 0x7FFF + ((bits >> 16) & 1)) >> 16)[:12].astype(np.uint16)      # bf16(hi) of the folded row
+    assert any(np.array_equal(u16[i:i + 12], first_row) for i in range(len(u16) - 12))

@@ -69,11 +69,16 @@ def main():
         r"finish\+write (?P<finish>[0-9.e+-]+) s", r.stdout)]
     stages = [{k: float(v) for k, v in s_.items()} for s_ in stages]
     loops = [sum(s_.values()) for s_ in stages]
+    cpu = [{"rank": int(m.group(1)), "user_s": float(m.group(2)), "system_s": float(m.group(3)), "cpu_us_per_utt": float(m.group(5))}
+           for m in re.finditer(r"rank (\d+) host cpu: ([0-9.]+) s user \+ ([0-9.]+) s system for (\d+) utterances = ([0-9.]+) us", r.stdout)]
     done = re.search(r"Done (\d+) utterances, failed for (\d+)", r.stdout)
     res = {"utterances": n, "ranks": ranks, "backend": opts.get("backend", "nccl"), "rc": r.returncode, "wall_s": wall,
            "wall_utt_per_s": n / wall, "done": int(done.group(1)) if done else None,
            "per_rank_loop_s": loops, "loop_utt_per_s": (n / max(loops)) if loops else None,
            "per_rank_stages_s": stages,
+           # CPU seconds each rank's process spent (import of torch and model load included): cores needed at R ranks =
+           # sum over ranks of cpu_us_per_utt x that rank's utt/s
+           "per_rank_host_cpu": cpu,
            "reader_wait_frac": [s_["wait"] / max(1e-9, sum(s_.values())) for s_ in stages],
            "calibration": [l for l in r.stdout.splitlines() if "calibration" in l][:3]}
     print(json.dumps(res))

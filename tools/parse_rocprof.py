@@ -19,6 +19,17 @@ import shutil
 import sys
 
 
+def kernels_sha16():
+    """First 16 hex digits of the SHA-1 of csrc/kernels.hip + kernels.h as they are in this tree (= in the snapshot the GPU box
+    profiled): stamps profiles/pmc_traffic.json, so that bench.py can tell counters of another kernel build from its own."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    for f in ("kernels.hip", "kernels.h"):
+        h.update(open(os.path.join(root, "speaker-embedding-with-phonetic-information_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     d, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -63,7 +74,9 @@ def main():
         open(os.path.join(prof, tag + "_pmc_hbm.md"), "w").write("\n".join(lines) + "\n")
         if by:
             out = {"hbm_bytes_per_launch": {k: sum(v) / len(v) for k, v in by.items()},
-                   "launches_per_step": {k: len(v) for k, v in by.items()}, "source": tag + "_pmc_hbm.md"}
+                   "launches_per_step": {k: len(v) for k, v in by.items()}, "source": tag + "_pmc_hbm.md",
+                   # which kernels these counters belong to: bench.py refuses the file when csrc/kernels.hip has changed since
+                   "kernels_sha16": kernels_sha16()}
             json.dump(out, open(os.path.join(prof, tag + "_pmc_traffic.json"), "w"), indent=1)
             if len(sys.argv) > 3 and sys.argv[3] == "main":   # what bench.py's roofline.traffic reads
                 json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)

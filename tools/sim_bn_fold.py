@@ -57,20 +57,53 @@ def load_program(path):
     return layers, pooled, out_layer, floor
 
 
-def forward(prog, feats, scheme):
+def q4_group16(x):
+    """The product's 4-bit copy of a frame fragment set: e2m1, one power-of-two scale per 16-row group (over every column of
+    the source), 2^(e - 2) with e the exponent of the group's maximum, saturating at the e2m1 maximum."""
+    n = x.shape[0]
+    pad = (-n) % 16
+    xp = np.pad(x, [(0, pad), (0, 0)])
+    g = xp.reshape(-1, 16, x.shape[1])
+    m = np.abs(g).max(axis=(1, 2), keepdims=True)
+    e = np.floor(np.log2(np.where(m > 0, m, 1.0)))
+    sc = 2.0 ** (e - 2)
+    q = (np.sign(g) * np.minimum(np.abs(_qgrid(g / sc)), 6.0)) * sc
+    return q.reshape(-1, x.shape[1])[:n]
+
+
+def _qgrid(v):
+    from sim_precision2 import qgrid
+    return qgrid(v, GRIDS["4"])
+
+
+def plane_residual4(y, yq):
+    """The 1.5-pass mode's 4-bit image of what the fp16 rounding of a plane dropped: e2m1, one scale per row and 64 columns,
+    2^(E - 13) with E the exponent of the block's largest |y|."""
+    n, c = y.shape
+    pad = (-c) % 64
+    yp = np.pad(y, [(0, 0), (0, pad)]).reshape(n, -1, 64)
+    rp = np.pad(y - yq, [(0, 0), (0, pad)]).reshape(n, -1, 64)
+    m = np.abs(yp).max(axis=2, keepdims=True)
+    E = np.floor(np.log2(np.where(m > 0, m, 1.0)))
+    sc = 2.0 ** (E - 13)
+    return (_qgrid(rp / sc) * sc).reshape(n, -1)[:, :c]
+
+
+def forward(prog, feats, scheme, tau=1e30):
     layers, pooled, out_layer, floor = prog
     T = feats.shape[0]
     fold = scheme.endswith("_fold")
     wround = scheme.startswith("mx")
-    planes = {-1: (0, T - 1, feats.astype(np.float64), None)}     # idx -> (lo, hi, stored plane, (mant, offset) when folded)
+    second = scheme.startswith("mx2")      # + q4(y - fp16(y)) . q4(W): the 1.5-pass arithmetic
+    planes = {-1: (0, T - 1, feats.astype(np.float64), None, None)}     # idx -> (lo, hi, stored plane, (mant, offset) when folded, 4-bit residual)
     stats = None
-    cache = forward.cache.setdefault((id(prog), scheme), {})
+    cache = forward.cache.setdefault((id(prog), scheme, tau), {})
     for i, L in enumerate(layers):
         if L["seg"]:
             x = np.concatenate([stats if s[0] == -2 else planes[s[0]][2] for s in L["src"]])
             z = L["w"] @ x + L["b"]
             y = (np.maximum(z, 0) if L["relu"] else z) * L["scale"] + L["offset"]
-            planes[i] = (0, 0, y, None)
+            planes[i] = (0, 0, y, None, None)
             continue
         lo = max(planes[s[0]][0] - s[1] for s in L["src"])
         hi = min(planes[s[0]][1] - s[1] for s in L["src"])
@@ -78,7 +111,7 @@ def forward(prog, feats, scheme):
         z = np.tile(L["b"], (hi - lo + 1, 1))
         k0 = 0
         for j, (si, off, dim) in enumerate(L["src"]):
-            plo, phi, P, fo = planes[si]
+            plo, phi, P, fo, R4 = planes[si]
             x = P[lo + off - plo: hi + off - plo + 1]
             W = L["w"][:, k0:k0 + dim]
             if fo is not None:      # folded source: its BatchNorm moves into this consumer
@@ -92,11 +125,14 @@ def forward(prog, feats, scheme):
                 if key not in cache:
                     wh = q16(W) if wround else W
                     wl = q_block_scaled(W - wh, GRIDS["4"], block=32, axis=1) if wround else None
-                    cache[key] = (wh, wl)
-                wh, wl = cache[key]
+                    w4 = q_block_scaled(W, GRIDS["4"], block=32, axis=1) if second else None
+                    cache[key] = (wh, wl, w4)
+                wh, wl, w4 = cache[key]
                 z += x @ wh.T
                 if wround:
-                    z += q_block_scaled(x, GRIDS["4"], block=32, axis=1) @ wl.T
+                    z += q4_group16(x) @ wl.T
+                if second and R4 is not None:
+                    z += R4[lo + off - plo: hi + off - plo + 1] @ w4.T
             k0 += dim
         r = np.maximum(z, 0) if L["relu"] else z
         if i == pooled:
@@ -105,15 +141,25 @@ def forward(prog, feats, scheme):
             mean = y.sum(0) / n
             var = np.maximum((y * y).sum(0) / n - mean * mean, floor)
             stats = np.concatenate([mean, np.sqrt(var)])
-            planes[i] = (lo, hi, y, None)
+            planes[i] = (lo, hi, y, None, None)
             continue
         if scheme == "exact":
-            planes[i] = (lo, hi, r * L["scale"] + L["offset"], None)
-        elif fold and L["relu"] and L["bn"]:
-            e = np.floor(np.log2(L["scale"]))
-            planes[i] = (lo, hi, q16(r * 2.0 ** e), (L["scale"] / 2.0 ** e, L["offset"]))
-        else:
-            planes[i] = (lo, hi, q16(r * L["scale"] + L["offset"]), None)
+            planes[i] = (lo, hi, r * L["scale"] + L["offset"], None, None)
+            continue
+        sc, of = L["scale"].copy(), L["offset"].copy()
+        fo = None
+        if fold and L["relu"] and L["bn"]:
+            # per column: fold where the offset is moderate (|o| <= tau); a column that sits far from zero relative to its spread
+            # (|o| >> 1) would put values of size |o| / m into the plane where the centred variable is of size 1
+            sel = np.abs(of) <= tau
+            e = np.floor(np.log2(sc))
+            mant = np.where(sel, sc / 2.0 ** e, 1.0)
+            fo = (mant, np.where(sel, of, 0.0))
+            sc = np.where(sel, 2.0 ** e, sc)
+            of = np.where(sel, 0.0, of)
+        y = r * sc + of
+        yq = q16(y)
+        planes[i] = (lo, hi, yq, fo, plane_residual4(y, yq) if second else None)
     return planes[out_layer][2]
 
 
@@ -128,6 +174,9 @@ def main():
               ("v5 init 123", lambda: H.synth_model("v5_cvector", 123)),
               ("v5 trained-like 11", lambda: H.trained_like_model("v5_cvector", 11))]
     d = tempfile.mkdtemp()
+    only = os.environ.get("SIM_MODELS")
+    if only:
+        models = [m for m in models if any(o in m[0] for o in only.split(","))]
     for name, mk in models:
         net, line = mk()
         n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
@@ -136,15 +185,21 @@ def main():
         prog = load_program(d + "/p.bin")
         forward.cache.clear()     # (keyed by id(prog): a new model must not find the previous one's weight images)
         ev = H.xo.GraphEvaluator(n2, np.float64)
-        errs = {k: [] for k in ("exact", "x2", "x2_fold", "mx", "mx_fold")}
+        taus = [float(a) for a in sys.argv[2:]] or [1e30]
+        keys = [("exact", 1e30), ("mx", 1e30), ("mx2", 1e30)] + [(k, t) for t in taus for k in ("mx_fold", "mx2_fold")]
+        errs = {k: [] for k in keys}
         zeros = []
         for c in range(nchunks):
-            x = H.features(31000 + c, 400)
+            x = H.features(20000 + c, 400)
             ref = ev.compute(x)[0]
             for k in errs:
-                got = forward(prog, x, k)
+                forward.cache_tag = k
+                got = forward(prog, x, k[0], k[1])
                 errs[k].append(float(np.abs(got - ref).max() / np.abs(ref).max()))
-        print("%-20s %s" % (name, "   ".join("%s worst %.2e mean %.2e" % (k, max(v), float(np.mean(v))) for k, v in errs.items())), flush=True)
+        off_all = np.concatenate([np.abs(L["offset"]) for L in prog[0] if L["bn"] and not L["seg"]])
+        print("%-20s |o| median %.2f, 90%% %.2f, max %.2f" % (name, np.median(off_all), np.quantile(off_all, 0.9), off_all.max()))
+        for k, v in errs.items():
+            print("      %-10s tau %-6s worst %.2e mean %.2e" % (k[0], "inf" if k[1] > 1e29 else "%g" % k[1], max(v), float(np.mean(v))), flush=True)
 
 
 if __name__ == "__main__":
