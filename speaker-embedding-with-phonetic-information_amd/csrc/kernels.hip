@@ -2513,7 +2513,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  constexpr bool prio_mfma = true, prio_load = false;   // issue priority of the two halves of a phase (either way: +-1 %, measured)
+  // Issue priority (XVEC_P8_PRIO, same-box A/B of round 5, profiles/r05_p8_priority.md): NONE is the default.  Raising the priority
+  // around every MFMA part (the template's s_setprio(1) / (0) pair, rounds 4's choice; knob value 2) costs 2-2.5 % on these
+  // kernels - the partner wave's LOAD part, which is what the interval waits for, loses its issue slots; a static priority for
+  // the late wave group (value 1; MI355X_MICROARCH.md, two waves per SIMD, item 4) measures the same as none.
+  constexpr bool prio_load = false;
+  const bool prio_mfma = a.p8_dbg == 2;
+  if (a.p8_dbg == 1 && wn == 1) __builtin_amdgcn_s_setprio(1);
   auto mfma = [&](auto HH, auto PP, auto QQ, const int k) __attribute__((always_inline)) {
     constexpr int H = decltype(HH)::value, pw = decltype(PP)::value, qx = decltype(QQ)::value;   // weight fragment pw, frame fragment qx
     // accumulators tied in place (inline asm): left to itself hipcc rotates the 128 accumulator registers through copies
@@ -3105,6 +3111,14 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < b.ngrp_lo; ++i) b.p8_ktiles_lo += (b.grp[b.ngrp + i].ksteps >> 1) * b.grp[b.ngrp + i].nshift;
   }
   b.p8 = 1;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("XVEC_P8_PRIO");
+      dbg = (e && *e) ? atoi(e) : 0;
+    }
+    b.p8_dbg = dbg;
+  }
   b.sk_mtiles = a.m_tiles >> 1;
   const int nt = a.n_tiles >> 1;
   int grid = device_cu_count() / 8 * 8;
