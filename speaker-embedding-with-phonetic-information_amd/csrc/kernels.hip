@@ -2513,13 +2513,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  // Issue priority (XVEC_P8_PRIO, same-box A/B of round 5, profiles/r05_p8_priority.md): NONE is the default.  Raising the priority
-  // around every MFMA part (the template's s_setprio(1) / (0) pair, rounds 4's choice; knob value 2) costs 2-2.5 % on these
-  // kernels - the partner wave's LOAD part, which is what the interval waits for, loses its issue slots; a static priority for
-  // the late wave group (value 1; MI355X_MICROARCH.md, two waves per SIMD, item 4) measures the same as none.
-  constexpr bool prio_load = false;
+  // Issue priority (XVEC_P8_PRIO; same-box A/B of round 5, profiles/r05_p8_priority.md).  A barrier interval lasts as long as the
+  // LOAD part of the wave that is NOT multiplying (two LDS-DMA instructions at 100-185 cycles of issue each + up to twelve
+  // fragment reads), so that is the part that gets the issue slots: 0 (default) = priority 1 around the LOAD part; 1 = no
+  // priority instruction (+1.7 % time on this kernel's launches); 2 = priority 1 around the MFMA part - the 8-phase template's
+  // recipe and round 4's kernel (+4 %); 3 = the late wave group at priority 1 throughout (MI355X_MICROARCH.md, two waves per
+  // SIMD, item 4: +0.3 %).
+  const bool prio_load = a.p8_dbg == 0;
   const bool prio_mfma = a.p8_dbg == 2;
-  if (a.p8_dbg == 1 && wn == 1) __builtin_amdgcn_s_setprio(1);
+  if (a.p8_dbg == 3 && wn == 1) __builtin_amdgcn_s_setprio(1);
   auto mfma = [&](auto HH, auto PP, auto QQ, const int k) __attribute__((always_inline)) {
     constexpr int H = decltype(HH)::value, pw = decltype(PP)::value, qx = decltype(QQ)::value;   // weight fragment pw, frame fragment qx
     // accumulators tied in place (inline asm): left to itself hipcc rotates the 128 accumulator registers through copies
