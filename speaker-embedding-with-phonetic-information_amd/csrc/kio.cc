@@ -12,7 +12,13 @@
 #include <string.h>
 #include <sys/wait.h>
 
+#include <poll.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace xv {
 
@@ -24,6 +30,114 @@ static std::string Trim(const std::string& s) {
 }
 
 // ------------------------------------------------------------------------------------- Input
+// One producer (this thread: read(2) on the pipe, whole blocks), one consumer (the parser).  The consumer touches the lock only
+// when it moves from one block to the next.
+class PipeDrain {
+ public:
+  static constexpr size_t kBlock = 1 << 20;
+  static constexpr long kBlocks = 8;
+  explicit PipeDrain(int fd) : fd_(fd) {
+    for (long i = 0; i < kBlocks; ++i) blk_[i].reset(new unsigned char[kBlock]);
+    th_ = std::thread([this] { Run(); });
+  }
+  ~PipeDrain() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    if (th_.joinable()) th_.join();
+  }
+  int Peek() { return (pos_ < cur_len_ || Advance()) ? cur_[pos_] : -1; }
+  int Get() { return (pos_ < cur_len_ || Advance()) ? cur_[pos_++] : -1; }
+  size_t Read(void* dst, size_t n) {   // up to n bytes, fewer only at the end of the input
+    size_t got = 0;
+    unsigned char* d = (unsigned char*)dst;
+    while (got < n) {
+      if (pos_ >= cur_len_ && !Advance()) break;
+      const size_t k = std::min(n - got, cur_len_ - pos_);
+      memcpy(d + got, cur_ + pos_, k);
+      pos_ += k;
+      got += k;
+    }
+    return got;
+  }
+
+ private:
+  bool Advance() {   // the current block is used up: release it, wait for the next
+    std::unique_lock<std::mutex> lk(mu_);
+    if (have_cur_) {
+      ++tail_;
+      have_cur_ = false;
+      cv_.notify_all();
+    }
+    cv_.wait(lk, [&] { return tail_ < head_ || eof_; });
+    if (tail_ >= head_) {
+      cur_len_ = pos_ = 0;
+      return false;
+    }
+    cur_ = blk_[tail_ % kBlocks].get();
+    cur_len_ = len_[tail_ % kBlocks];
+    pos_ = 0;
+    have_cur_ = true;
+    return true;
+  }
+  void Run() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return head_ - tail_ < kBlocks || stop_; });
+        if (stop_) return;
+      }
+      unsigned char* b = blk_[head_ % kBlocks].get();
+      size_t have = 0;
+      bool end = false;
+      // fill the block (a pipe hands over what the producer has written so far, at most its buffer); give up the wait every
+      // 50 ms to see whether the reader was closed early (a calibration sample takes only the head of a stream)
+      while (have < kBlock) {
+        struct pollfd pf = {fd_, POLLIN, 0};
+        const int pr = poll(&pf, 1, 50);
+        if (pr == 0) {
+          std::unique_lock<std::mutex> lk(mu_);
+          if (stop_) return;
+          if (have) break;   // hand over what is there rather than sit on it
+          continue;
+        }
+        if (pr < 0 && errno == EINTR) continue;
+        const ssize_t r = read(fd_, b + have, kBlock - have);
+        if (r < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+        if (r <= 0) {
+          end = true;
+          break;
+        }
+        have += (size_t)r;
+      }
+      std::unique_lock<std::mutex> lk(mu_);
+      if (have) {
+        len_[head_ % kBlocks] = have;
+        ++head_;
+      }
+      if (end) eof_ = true;
+      cv_.notify_all();
+      if (end || stop_) return;
+    }
+  }
+  int fd_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::unique_ptr<unsigned char[]> blk_[kBlocks];
+  size_t len_[kBlocks] = {};
+  long head_ = 0, tail_ = 0;   // blocks produced / released (under mu_)
+  bool eof_ = false, stop_ = false;
+  // consumer side
+  const unsigned char* cur_ = nullptr;
+  size_t cur_len_ = 0, pos_ = 0;
+  bool have_cur_ = false;
+};
+
+Input::Input() = default;
+
 Input::~Input() {
   try {
     Close();
@@ -31,7 +145,7 @@ Input::~Input() {
   }
 }
 
-void Input::Open(const std::string& rx_in) {
+void Input::Open(const std::string& rx_in, bool drain_pipe) {
   Close();
   std::string rx = Trim(rx_in);
   name_ = rx;
@@ -52,6 +166,10 @@ void Input::Open(const std::string& rx_in) {
 #endif
     // (stdio buffer left small: an fread of a whole matrix then goes from the pipe straight into its destination - one copy per
     // byte - instead of through the FILE buffer)
+    if (drain_pipe) {
+      const char* e = getenv("XVEC_PIPE_DRAIN");
+      if (!(e && *e && atoi(e) == 0)) drain_.reset(new PipeDrain(fileno(f_)));   // nothing was read through f_ yet
+    }
     return;
   }
   // "file:offset"
@@ -113,6 +231,7 @@ void Input::OpenMemory(const void* data, size_t n) {
 
 int Input::Close() {
   int status = 0;
+  drain_.reset();   // stops and joins the drain thread before the pipe is closed
   if (f_) {
     if (is_pipe_) {
       int st = pclose(f_);
@@ -129,6 +248,7 @@ int Input::Close() {
 }
 
 int Input::Peek() {
+  if (drain_) return drain_->Peek();
   if (mem_) return mem_pos_ < mem_n_ ? mem_[mem_pos_] : -1;
   if (!f_) return -1;
   int c = fgetc(f_);
@@ -138,6 +258,7 @@ int Input::Peek() {
 }
 
 int Input::Get() {
+  if (drain_) return drain_->Get();
   if (mem_) return mem_pos_ < mem_n_ ? mem_[mem_pos_++] : -1;
   if (!f_) return -1;
   int c = fgetc(f_);
@@ -146,6 +267,10 @@ int Input::Get() {
 
 void Input::Read(void* dst, size_t n) {
   if (n == 0) return;
+  if (drain_) {
+    if (drain_->Read(dst, n) != n) throw KioError("unexpected end of file in " + name_);
+    return;
+  }
   if (mem_) {
     if (mem_pos_ + n > mem_n_) throw KioError("unexpected end of data in " + name_);
     memcpy(dst, mem_ + mem_pos_, n);
@@ -156,6 +281,7 @@ void Input::Read(void* dst, size_t n) {
 }
 
 size_t Input::ReadUpTo(void* dst, size_t n) {
+  if (drain_) return drain_->Read(dst, n);
   if (mem_) {
     const size_t got = std::min(n, mem_n_ - mem_pos_);
     memcpy(dst, mem_ + mem_pos_, got);
@@ -662,7 +788,7 @@ WspecifierOptions ParseWspecifier(const std::string& wspecifier) {
 // ------------------------------------------------------------------------------------- readers
 SequentialMatrixReader::SequentialMatrixReader(const std::string& rspecifier) {
   opts_ = ParseRspecifier(rspecifier);
-  in_.Open(opts_.rxfilename);
+  in_.Open(opts_.rxfilename, /*drain_pipe=*/!opts_.is_scp);   // an archive through a pipe: the feature pipe of extract_xvectors_new.sh:79
 }
 
 SequentialMatrixReader::~SequentialMatrixReader() {}

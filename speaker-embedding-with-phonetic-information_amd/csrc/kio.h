@@ -24,14 +24,19 @@ struct KioError : public std::runtime_error {
 
 // ---------------------------------------------------------------------------------------------
 // Byte source: regular file (optionally at an offset), stdin, or the stdout of `cmd |`.
+class PipeDrain;   // kio.cc: a thread that keeps reading an input pipe into a ring of blocks
+
 class Input {
  public:
-  Input() = default;
+  Input();
   ~Input();
   Input(const Input&) = delete;
   Input& operator=(const Input&) = delete;
   // rxfilename forms: "file", "file:123", "-", "cmd args |"
-  void Open(const std::string& rxfilename);
+  // drain_pipe: for "cmd |" inputs, a second thread does the read(2) calls and the parser consumes from a ring of 1 MiB
+  // blocks (feature archives through a pipe, extract_xvectors_new.sh:79: the syscalls and the kernel's copy out of the pipe
+  // buffer then overlap the parsing and the copy into the batch; XVEC_PIPE_DRAIN=0 turns it off)
+  void Open(const std::string& rxfilename, bool drain_pipe = false);
   void OpenMemory(const void* data, size_t n);
   void Seek(long offset);           // regular files / memory only
   bool IsRegularFile() const;       // an fopen'ed regular file (seekable): not a pipe, FIFO, device or standard input
@@ -56,6 +61,7 @@ class Input {
   const unsigned char* mem_ = nullptr;
   size_t mem_n_ = 0, mem_pos_ = 0;
   std::string name_;
+  std::unique_ptr<PipeDrain> drain_;
 };
 
 // Byte sink: file, stdout ("-"), or the stdin of `| cmd`.

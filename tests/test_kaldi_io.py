@@ -147,3 +147,42 @@ def test_cpp_reader_error_behaviour(feats):
     assert r.returncode == 255 and b"unexpected end" in r.stderr
     r = _run("copy-feats", "foo:" + bad, "ark:/dev/null")
     assert r.returncode == 255
+
+
+def test_archive_through_a_pipe_is_drained_by_a_second_thread(tmp_path):
+    """`ark:cmd |` - the form extract_xvectors_new.sh:79 feeds features in: a drain thread does the read(2) calls into a ring of
+    1 MiB blocks, the parser consumes from it (kio.cc PipeDrain).  A large archive (many ring wrap-arounds, matrices that
+    straddle blocks), compressed and text objects, a slow producer and an early close must all behave exactly like the plain
+    stdio path (XVEC_PIPE_DRAIN=0) and like the file."""
+    rng = np.random.default_rng(3)
+    utts = [("u%04d" % i, rng.standard_normal((int(rng.integers(1, 900)), 23)).astype(np.float32)) for i in range(700)]   # ~29 MB
+    src = str(tmp_path / "big.ark")
+    kio.write_ark_matrices(src, utts)
+    want = open(src, "rb").read()
+    for env in ({}, {"XVEC_PIPE_DRAIN": "0"}):
+        dst = str(tmp_path / ("out%d.ark" % len(env)))
+        r = _run("copy-feats", "ark:cat %s |" % src, "ark:" + dst, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-500:]
+        assert open(dst, "rb").read() == want
+    # a producer that trickles (small writes, pauses): blocks arrive partly filled
+    trickle = "python3 -c \"import sys,time; d=open('%s','rb').read()[:3000000]\nfor i in range(0,len(d),70001):\n  sys.stdout.buffer.write(d[i:i+70001]); sys.stdout.buffer.flush(); time.sleep(0.002)\"" % src
+    head = [u for u in utts]
+    n_bytes, n_head = 0, 0
+    for k, m in head:
+        n_bytes += len(k) + 1 + 2 + 15 + m.size * 4
+        if n_bytes > 3000000:
+            break
+        n_head += 1
+    dst = str(tmp_path / "trickle.ark")
+    r = _run("copy-feats", "ark:%s |" % trickle, "ark:" + dst)
+    # the stream ends inside a matrix: everything in front of it was copied, the cut is an error like in Kaldi
+    assert r.returncode != 0 and b"unexpected end of file" in r.stderr, r.stderr.decode()[-300:]
+    got = [k for k, _ in kio.read_ark(dst, "matrix")]
+    assert got == [k for k, _ in utts[:n_head]], (len(got), n_head)
+    # text archive through the pipe (byte-wise Peek / Get across block boundaries)
+    txt = str(tmp_path / "t.ark")
+    assert _run("copy-feats", "ark:" + src, "ark,t:" + txt).returncode == 0
+    back = str(tmp_path / "back.ark")
+    assert _run("copy-feats", "ark:cat %s |" % txt, "ark:" + back).returncode == 0
+    b = dict(kio.read_ark(back, "matrix"))
+    assert len(b) == len(utts) and all(np.allclose(b[k], m, rtol=1e-5, atol=1e-6) for k, m in utts[:50])

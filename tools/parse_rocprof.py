@@ -18,6 +18,8 @@ import os
 import shutil
 import sys
 
+CLOCK_GHZ = float(os.environ.get("XVEC_CLOCK_GHZ", "2.03"))   # measured in-kernel (tools/clock_probe.py), round 5
+
 
 def kernels_sha16():
     """First 16 hex digits of the SHA-1 of csrc/kernels.hip + kernels.h as they are in this tree (= in the snapshot the GPU box
@@ -97,15 +99,20 @@ def main():
         lines = ["# SQ counters per kernel, one bench step (%s)" % tag, "",
                  "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES",
                  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, no tracing).",
-                 "clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles).", "",
-                 "| kernel | us | VGPR | LDS B | clock GHz | MFMA pipe busy | wait_any | wait_inst | active | LDS bank conflict cycles |",
+                 "MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles of the dispatch), with the cycles taken two ways:",
+                 "(a) GRBM_GUI_ACTIVE / 8 XCDs - the column rounds 1-4 quoted; GRBM counts more than the dispatch (it implies 2.3-2.5 GHz for",
+                 "the long kernels and 4-7 GHz for the short ones: not a clock, VERDICT r04), so (a) UNDERSTATES the busy fraction;",
+                 "(b) duration x %.2f GHz, the shader clock measured inside tdnn_gemm_kernel_p8 on this workload (tools/clock_probe.py:" % CLOCK_GHZ,
+                 "s_memtime over s_memrealtime per workgroup, 2.02-2.06 GHz) - meaningful for the long GEMM kernels only.", "",
+                 "| kernel | us | VGPR | GRBM_GUI_ACTIVE / 8 / us (not a clock) | MFMA busy (a) | MFMA busy (b) | wait_any | wait_inst | active | LDS bank conflict cycles |",
                  "|---|---|---|---|---|---|---|---|---|---|"]
         for e in last[idx:]:
             cyc = e.get("GRBM_GUI_ACTIVE", 0) / 8.0
             wc = max(e.get("SQ_WAVE_CYCLES", 1), 1)
-            lines.append("| %s | %.1f | %s | %s | %.2f | %.1f %% | %.2f | %.2f | %.2f | %.3g |" % (
-                e["name"], e["us"], e["vgpr"], e["lds"], cyc / e["us"] / 1e3 if e["us"] else 0,
-                100 * e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc if cyc else 0, e.get("SQ_WAIT_ANY", 0) / wc,
+            lines.append("| %s | %.1f | %s | %.2f | %.1f %% | %.1f %% | %.2f | %.2f | %.2f | %.3g |" % (
+                e["name"], e["us"], e["vgpr"], cyc / e["us"] / 1e3 if e["us"] else 0,
+                100 * e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc if cyc else 0,
+                100 * e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (e["us"] * CLOCK_GHZ * 1e3) if e["us"] else 0, e.get("SQ_WAIT_ANY", 0) / wc,
                 e.get("SQ_WAIT_INST_ANY", 0) / wc, e.get("SQ_ACTIVE_INST_ANY", 0) / wc, e.get("SQ_LDS_BANK_CONFLICT", 0)))
         open(os.path.join(prof, tag + "_pmc_sq.md"), "w").write("\n".join(lines) + "\n")
     bd = os.path.join(d, "bench_default.json")

@@ -8,7 +8,9 @@ name=${1:-main}; shift
 P=$R/gpurun_out/prof_$name
 mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-extra-modes --no-parity-sweep $*"
+# one batch in flight (--lanes 1): kernel durations then mean what they mean in bench.py's roofline, whose per-kernel HIP events
+# also come from a one-lane context (two lanes overlap one batch's tail kernels with the next batch's GEMMs)
+B="$R/bench.py --no-cpu-baseline --no-extra-modes --no-parity-sweep --lanes 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/kt" -o bench -- python3 $B --steps 20 --warmup 4 > "$P/kt_bench.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$P/pmc_$c" -o bench -- python3 $B --steps 3 --warmup 1 > "$P/pmc_$c.log" 2>&1
