@@ -367,8 +367,10 @@ def main():
         meta = torch.tensor([len(blob)], dtype=torch.int64, device=cdev)
     else:
         meta = torch.zeros(1, dtype=torch.int64, device=cdev)
-    # bounded: a rank that never joins the broadcast becomes an error and exit status 3 after XVEC_BCAST_TIMEOUT (60) seconds
-    with P.Watchdog("the broadcast of the packed weights (%d ranks, backend %s)" % (world, backend)):
+    # bounded: a rank that never joins the broadcast becomes an error and exit status 3 after XVEC_BCAST_TIMEOUT (here 300 s unless
+    # set: the other ranks wait in it while rank 0 synthesises and packs the model on a box whose page cache may be cold)
+    with P.Watchdog("the broadcast of the packed weights (%d ranks, backend %s)" % (world, backend),
+                    None if os.environ.get("XVEC_BCAST_TIMEOUT") else 300.0):
         if world > 1:
             dist.broadcast(meta, 0)
         nbytes = int(meta[0].item())

@@ -379,7 +379,8 @@ class Context:
 class Watchdog:
     """Bounded wait for the start-up collective of a multi-rank job (the ONE broadcast of the packed weights, dist_extract.py /
     bench.py): a rank that never joins - died while loading, a link that is down - would otherwise leave the others inside
-    the collective without a word until someone kills the job.  After `seconds` (XVEC_BCAST_TIMEOUT, default 60) the process
+    the collective without a word until someone kills the job.  After `seconds` (XVEC_BCAST_TIMEOUT, default 120: the other
+    ranks enter the broadcast while rank 0 still reads, lowers and packs the model - on a cold box that alone can take many seconds) the process
     prints what it was waiting for and EXITS with status 3; the launcher then tears the other ranks down.  A plain exit of a
     fresh-started process - nothing is re-executed (a process that has touched the GPU must never exec)."""
 
@@ -387,9 +388,9 @@ class Watchdog:
         import threading
         if seconds is None:
             try:
-                seconds = float(os.environ.get("XVEC_BCAST_TIMEOUT", "60"))
+                seconds = float(os.environ.get("XVEC_BCAST_TIMEOUT", "120"))
             except ValueError:
-                seconds = 60.0
+                seconds = 120.0
         self.what, self.seconds = what, seconds
         self._t = threading.Timer(seconds, self._fire)
         self._t.daemon = True

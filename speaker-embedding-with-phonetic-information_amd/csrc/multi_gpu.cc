@@ -71,7 +71,7 @@ std::vector<std::unique_ptr<Engine>> CreateEnginesBroadcast(const std::vector<ui
   if (n < 1) throw EngineError("CreateEnginesBroadcast: no device");
   if (timeout_s <= 0.0) {
     const char* e = getenv("XVEC_BCAST_TIMEOUT");
-    timeout_s = (e && *e && atof(e) > 0.0) ? atof(e) : 60.0;
+    timeout_s = (e && *e && atof(e) > 0.0) ? atof(e) : 120.0;
   }
   static Rccl rccl;   // throws when librccl cannot be bound
   std::vector<Rccl::comm_t> comms(n, nullptr);

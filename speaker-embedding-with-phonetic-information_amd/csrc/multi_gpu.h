@@ -13,7 +13,7 @@ namespace xv {
 
 // devices: distinct HIP device ordinals, devices[0] is the root.  timeout_s: how long the broadcast may take before the call
 // gives up with an EngineError (a rank that never joins would otherwise hang the job without a word); <= 0: XVEC_BCAST_TIMEOUT
-// or 60 s.  Throws EngineError on any failure; nothing is left allocated then.
+// or 120 s.  Throws EngineError on any failure; nothing is left allocated then.
 std::vector<std::unique_ptr<Engine>> CreateEnginesBroadcast(const std::vector<uint8_t>& blob, const std::vector<int>& devices,
                                                             double timeout_s = 0.0);
 
