@@ -275,7 +275,6 @@ struct GemmArgs {
   // formed in another order than the 32-column kernels') and, for kPrecFp16Mx, that w4 / w4_scale are packed in its walk order.
   int p8;
   int p8_ktiles;         // K tiles of an output tile (set by the launcher)
-  int p8_dbg;            // XVEC_P8_PRIO: 0 (default) = the LOAD part of a phase at issue priority 1, 1 = no priorities, 2 = the MFMA part (round 4), 3 = wave group 1 throughout
   int p8_ktiles_lo;      // kPrecFp16Mx2: tiles of the second walk (256 4-bit columns each); w4b / w4b_scale are then in ITS order
                          // (PlanWalkLoSteps64)
 };

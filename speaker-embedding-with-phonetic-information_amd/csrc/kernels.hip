@@ -930,6 +930,16 @@ __device__ __forceinline__ void glds16_sbase(const void* sbase, unsigned voff, u
       : "memory");
 }
 
+// The same without saving and restoring m0 around the instruction (three scalar instructions less per DMA; the LOAD part of a
+// phase of tdnn_gemm_kernel_p8 is what its barrier intervals wait for: -0.9 % on that kernel's launches, profiles/r05_p8_priority.md).
+// m0 is a reserved register to hipcc - it does not allocate it and cannot be told about the write (a clobber is refused with a
+// warning) - and it only ever reads m0 in instructions it sets it up for itself (LDS-DMA builtins, s_movrel, GWS, sendmsg), none
+// of which a kernel that uses this function may contain: tdnn_gemm_kernel_p8 issues every LDS-DMA through these asm forms, each of
+// which writes m0 first (tests/test_kernel_resources.py checks the ISA: no m0 read outside them).
+__device__ __forceinline__ void glds16_sbase_m0(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
 // 4 bytes per lane (LDS destination = base + lane * 4)
 __device__ __forceinline__ void glds4_sbase(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
@@ -2431,15 +2441,15 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       const char* src = wb + (unit == 3 ? (long)a.ldw * 128 : 0);
       unsigned woff[2] = {woff_r[0], woff_r[1]};   // (the second walk's 4-bit weight image has the row pitch of the fp16 plane: the same offsets)
       if constexpr (RECOMPUTE) unit_offsets(a.ldw, true, woff);
-      glds16_sbase(src, woff[0], dst);
-      glds16_sbase(src, woff[1], dst + 1024);
+      glds16_sbase_m0(src, woff[0], dst);
+      glds16_sbase_m0(src, woff[1], dst + 1024);
     } else {
       const char* src = xb + (unit == 2 ? (long)gi.ld * 256 : 0);
       const unsigned dst = st_lane + buf * kP8XW + (unit == 2 ? kP8Unit : 0);
       unsigned xoff[2] = {xoff_r[0], xoff_r[1]};
       if constexpr (RECOMPUTE) unit_offsets(gi.ld, false, xoff);
-      glds16_sbase(src, xoff[0], dst);
-      glds16_sbase(src, xoff[1], dst + 1024);
+      glds16_sbase_m0(src, xoff[0], dst);
+      glds16_sbase_m0(src, xoff[1], dst + 1024);
     }
   };
   // the 4-bit tile of block `blk` of the tile's walk and its scales: three DMA instructions in EVERY wave (waves 4-7 repeat
@@ -2513,15 +2523,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  // Issue priority (XVEC_P8_PRIO; same-box A/B of round 5, profiles/r05_p8_priority.md).  A barrier interval lasts as long as the
-  // LOAD part of the wave that is NOT multiplying (two LDS-DMA instructions at 100-185 cycles of issue each + up to twelve
-  // fragment reads), so that is the part that gets the issue slots: 0 (default) = priority 1 around the LOAD part; 1 = no
-  // priority instruction (+1.7 % time on this kernel's launches); 2 = priority 1 around the MFMA part - the 8-phase template's
-  // recipe and round 4's kernel (+4 %); 3 = the late wave group at priority 1 throughout (MI355X_MICROARCH.md, two waves per
-  // SIMD, item 4: +0.3 %).
-  const bool prio_load = a.p8_dbg == 0;
-  const bool prio_mfma = a.p8_dbg == 2;
-  if (a.p8_dbg == 3 && wn == 1) __builtin_amdgcn_s_setprio(1);
+  // Issue priority (same-box A/B of round 5 through a runtime knob, profiles/r05_p8_priority.md; compile-time again since).  A
+  // barrier interval lasts as long as the LOAD part of the wave that is NOT multiplying (two LDS-DMA instructions at 100-185
+  // cycles of issue each + up to twelve fragment reads), so that is the part that gets the issue slots: priority 1 around the
+  // LOAD part.  No priority instruction at all: +1.7 % time on this kernel's launches; priority around the MFMA part (the 8-phase
+  // template's recipe, round 4's kernel): +4 %; the late wave group at priority 1 throughout (MI355X_MICROARCH.md, two waves
+  // per SIMD, item 4): +0.3 %.
+  constexpr bool prio_load = true, prio_mfma = false;
   auto mfma = [&](auto HH, auto PP, auto QQ, const int k) __attribute__((always_inline)) {
     constexpr int H = decltype(HH)::value, pw = decltype(PP)::value, qx = decltype(QQ)::value;   // weight fragment pw, frame fragment qx
     // accumulators tied in place (inline asm): left to itself hipcc rotates the 128 accumulator registers through copies
@@ -2537,10 +2545,17 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   // One phase.  P = phase, B = buffer of the tile, ODD = second tile of its pair (the 4-bit conversions go to dwords 2, 3; the
   // block-scaled MFMAs follow its last phase), LO = a tile of the second walk; unit / ibuf = what the LOAD part stages (unit < 0:
   // nothing), w4_blk >= 0: also the 4-bit tile of that block, sc_buf >= 0: also the second-walk scales of the issue side's tile.
-  auto phase = [&](auto PP, auto BB, auto OO, auto LL, const int unit, const int ibuf, const int w4_blk, const int sc_buf,
+  auto phase = [&](auto PP, auto BB, auto OO, auto LL, auto FF, const int unit, const int ibuf, const int w4_blk, const int sc_buf,
                    const bool steady) __attribute__((always_inline)) {
     constexpr int P = decltype(PP)::value, B = decltype(BB)::value, ODD = decltype(OO)::value;
     constexpr bool LO = decltype(LL)::value != 0;
+    // FAST: a phase of the part's steady state (at least two more tiles behind this pair; first walk) - what it stages and what it
+    // waits for are compile-time constants: unit {2, 3, 0, 1}[P] into buffer (P < 2 ? 1 - B : B), the block's 4-bit tile in phase 1
+    // of its first tile, vmcnt(8 / 6 [+ 3]).  The LOAD part is what a barrier interval waits for (profiles/r05_p8_priority.md),
+    // and the runtime form of these decisions (is there a unit? a 4-bit tile? which wait?) cost it a dozen scalar and two vector
+    // instructions per phase.
+    constexpr bool FAST = decltype(FF)::value != 0;
+    // (only ever CALLED for the first walk of the 1- and 1.25-pass arithmetic: pair_fast)
     // LDS: [frames, buffer 0 | frames, buffer 1 | weights, buffer 0 | weights, buffer 1], 32 KiB each: every fragment read is one of
     // four per-lane bases + a 16-bit immediate
     const char* xs0 = smem + xrd0 + B * kP8XW;
@@ -2590,33 +2605,42 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       ws_lo[0] = *(const int*)(wsl);
       ws_lo[1] = *(const int*)(wsl + 1024);
     }
-    c3 = c2;
-    c2 = c1;
-    c1 = c0;
-    c0 = 0;
-    if (unit >= 0) {
-      issue(unit, ibuf);
-      c0 += 2;
-    }
-    if (w4_blk >= 0) {
-      issue_w4(w4_blk);
-      c0 += 3;
-    }
-    if (sc_buf >= 0) {
-      issue_scales(sc_buf);
-      c0 += 2;
-    }
-    __builtin_amdgcn_sched_barrier(0);
     // steady state (every phase of this pair and of the one before it staged its unit): the counts are constants - 2 per phase,
     // + 3 in phase 1 of a block's first tile (4-bit tile and scales); the tail of a part and the second walk count as they go
     constexpr int E1 = (MX && !LO && !ODD) ? 3 : 0;
-    if constexpr (P == 1) {
-      if (!MX2 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + E1) : "memory");
-      else wait_vmcnt_n(c0 + c1 + c2 + c3);
-    }
-    if constexpr (P == 3) {
-      if (!MX2 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + E1) : "memory");
-      else wait_vmcnt_n(c0 + c1 + c2);
+    if constexpr (FAST) {
+      constexpr int UNIT = P == 0 ? 2 : P == 1 ? 3 : P == 2 ? 0 : 1;
+      issue(UNIT, P < 2 ? 1 - B : B);
+      if constexpr (MX && P == 1 && !ODD) issue_w4(w4_blk);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (P == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + E1) : "memory");
+      if constexpr (P == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + E1) : "memory");
+    } else {
+      c3 = c2;
+      c2 = c1;
+      c1 = c0;
+      c0 = 0;
+      if (unit >= 0) {
+        issue(unit, ibuf);
+        c0 += 2;
+      }
+      if (w4_blk >= 0) {
+        issue_w4(w4_blk);
+        c0 += 3;
+      }
+      if (sc_buf >= 0) {
+        issue_scales(sc_buf);
+        c0 += 2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (P == 1) {
+        if (!MX2 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + E1) : "memory");
+        else wait_vmcnt_n(c0 + c1 + c2 + c3);
+      }
+      if constexpr (P == 3) {
+        if (!MX2 && steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + E1) : "memory");
+        else wait_vmcnt_n(c0 + c1 + c2);
+      }
     }
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the fragments are in (the MFMAs are inline asm: their waits are ours)
@@ -2725,18 +2749,35 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   auto pair = [&](auto LL, const int n_left, const int blk, const bool first) __attribute__((always_inline)) {
     constexpr int LOW = decltype(LL)::value;
     const bool t1 = n_left > 1, t2 = n_left > 2, t3 = n_left > 3;
-    phase(I0{}, I0{}, I0{}, LL, t1 ? 2 : -1, 1, -1, (MX2 && t1 && !first && it >= S) ? 1 : -1, t3);
-    phase(I1{}, I0{}, I0{}, LL, t1 ? 3 : -1, 1, (MX && !LOW) ? blk : -1, -1, t3);
+    phase(I0{}, I0{}, I0{}, LL, I0{}, t1 ? 2 : -1, 1, -1, (MX2 && t1 && !first && it >= S) ? 1 : -1, t3);
+    phase(I1{}, I0{}, I0{}, LL, I0{}, t1 ? 3 : -1, 1, (MX && !LOW) ? blk : -1, -1, t3);
     if (t2) adv();
-    phase(I2{}, I0{}, I0{}, LL, t2 ? 0 : -1, 0, -1, -1, t3);
-    phase(I3{}, I0{}, I0{}, LL, t2 ? 1 : -1, 0, -1, -1, t3);
+    phase(I2{}, I0{}, I0{}, LL, I0{}, t2 ? 0 : -1, 0, -1, -1, t3);
+    phase(I3{}, I0{}, I0{}, LL, I0{}, t2 ? 1 : -1, 0, -1, -1, t3);
     if (t1) {
-      phase(I0{}, I1{}, I1{}, LL, t2 ? 2 : -1, 0, -1, (MX2 && t2 && it >= S) ? 0 : -1, t3);
-      phase(I1{}, I1{}, I1{}, LL, t2 ? 3 : -1, 0, -1, -1, t3);
+      phase(I0{}, I1{}, I1{}, LL, I0{}, t2 ? 2 : -1, 0, -1, (MX2 && t2 && it >= S) ? 0 : -1, t3);
+      phase(I1{}, I1{}, I1{}, LL, I0{}, t2 ? 3 : -1, 0, -1, -1, t3);
       if (t3) adv();
-      phase(I2{}, I1{}, I1{}, LL, t3 ? 0 : -1, 1, -1, -1, t3);
-      phase(I3{}, I1{}, I1{}, LL, t3 ? 1 : -1, 1, -1, -1, t3);
+      phase(I2{}, I1{}, I1{}, LL, I0{}, t3 ? 0 : -1, 1, -1, -1, t3);
+      phase(I3{}, I1{}, I1{}, LL, I0{}, t3 ? 1 : -1, 1, -1, -1, t3);
     }
+  };
+
+  // The same eight phases in the steady state of the first walk (at least two more tiles of the part behind this pair): every
+  // phase stages its unit, the block's 4-bit tile goes out in phase (t, 1), the waits are constants.  Leaves the issue counters in
+  // the state the generic pair behind it expects (two instructions in each of the last four phases).
+  auto pair_fast = [&](const int blk) __attribute__((always_inline)) {
+    phase(I0{}, I0{}, I0{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    phase(I1{}, I0{}, I0{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    adv();
+    phase(I2{}, I0{}, I0{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    phase(I3{}, I0{}, I0{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    phase(I0{}, I1{}, I1{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    phase(I1{}, I1{}, I1{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    adv();
+    phase(I2{}, I1{}, I1{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    phase(I3{}, I1{}, I1{}, I0{}, I1{}, 0, 0, blk, -1, true);
+    c0 = c1 = c2 = c3 = 2;
   };
 
   // position of K tile k in the walk (first-walk groups, then the second walk's)
@@ -2857,10 +2898,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     // fragments in scratch between them: 660 bytes per lane.)
     const int ntp = n_tiles_part;
     const int n_hi = MX2 ? (kb_part >= S ? 0 : (kb_part + ntp <= S ? ntp : S - kb_part)) : ntp;   // tiles of the first walk in this part
-#pragma nounroll
-    for (int t = 0; t < n_hi; t += 2) {
+    // entering another source of the walk: its group maxima (a pair never straddles two groups)
+    auto enter_pair = [&]() __attribute__((always_inline)) {
       if constexpr (MX) {
-        if (r_left == 0) {   // the walk enters another source: its group maxima (a pair never straddles two groups)
+        if (r_left == 0) {
           ++rg;
           r_left = (a.grp[rg].ksteps >> 1) * a.grp[rg].nshift;
           xs_uvec xg;
@@ -2869,11 +2910,28 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
         }
         r_left -= 2;
       }
+    };
+    // Two loops one behind the other, never two bodies in one loop (hipcc then splits the accumulator tuples between the bodies
+    // and spills ~100 registers - seen again in round 5): first the pairs of the steady state, whose staging and waits are
+    // compile-time constants (pair_fast), then the part's last two pairs in the general form.
+    int t = 0;
+    // (not the kernels at the register limit: the 1.5-pass one - it recomputes its staging offsets as it is - and fp16mxe,
+    // which spills one register with the second loop body)
+    if constexpr (!MX2 && PREC != kPrecFp16MxE) {
+#pragma nounroll
+      for (; ntp - t > 3; t += 2) {
+        enter_pair();
+        pair_fast((kb_part + t) >> 1);
+      }
+    }
+#pragma nounroll
+    for (; t < n_hi; t += 2) {
+      enter_pair();
       pair(I0{}, ntp - t, (kb_part + t) >> 1, t == 0);
     }
     if constexpr (MX2) {
 #pragma nounroll
-      for (int t = n_hi; t < ntp; t += 2) pair(I1{}, ntp - t, 0, t == 0);
+      for (t = n_hi; t < ntp; t += 2) pair(I1{}, ntp - t, 0, t == 0);
     }
     if (wn == 0) barrier();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
@@ -3113,14 +3171,6 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < b.ngrp_lo; ++i) b.p8_ktiles_lo += (b.grp[b.ngrp + i].ksteps >> 1) * b.grp[b.ngrp + i].nshift;
   }
   b.p8 = 1;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("XVEC_P8_PRIO");
-      dbg = (e && *e) ? atoi(e) : 0;
-    }
-    b.p8_dbg = dbg;
-  }
   b.sk_mtiles = a.m_tiles >> 1;
   const int nt = a.n_tiles >> 1;
   int grid = device_cu_count() / 8 * 8;
