@@ -615,6 +615,28 @@ def main():
                                 "rel_err_vs_oracle_fp32": H.rel_err(o2[:nchk].cpu().numpy(), ref), "parity_chunks_vs_oracle": nchk}
                 del c2
             res["other_modes"] = extra
+            # the same arithmetic with tdnn_gemm_kernel_p8 dealing out WHOLE output tiles (XVEC_P8_WHOLE=1, read per context): every
+            # launch is longer on its own (no even split of the K tiles), but there is no exchange of partial tiles, and with two
+            # batches in flight the other lane's kernels fill the CUs that finish early (profiles/r05_p8_whole_tiles.md)
+            try:
+                os.environ["XVEC_P8_WHOLE"] = "1"
+                cw = P.Context(model, device=local_rank, precision=prec)
+                os.environ.pop("XVEC_P8_WHOLE", None)
+                if calibration:
+                    cw.set_fast_mode(calibration["chosen"])
+                    if calibration.get("lite_mask"):
+                        cw.set_lite_mask(calibration["lite_mask"])
+                ow = torch.empty_like(out)
+                fw = lambda: cw.forward_batch_device(feats.data_ptr(), offs, ow.data_ptr(), ow.shape[1], None)  # noqa: E731
+                prewarm(torch, fw, 0.3)
+                dw = time_steps(torch, fw, args.steps)
+                res["whole_tiles"] = {"value": B * args.steps / dw, "unit": "utt/s", "lanes": args.lanes, "ms_per_step": dw / args.steps * 1e3,
+                                      "bit_identical_to_the_timed_run": bool(torch.equal(ow, out)),
+                                      "note": "XVEC_P8_WHOLE=1: not the default - the dominant kernel's own launch is ~13 % longer this way"}
+                del cw
+            except Exception as e:   # noqa: BLE001
+                os.environ.pop("XVEC_P8_WHOLE", None)
+                res["whole_tiles"] = {"error": str(e)}
             # the fast modes on a model closer to a trained one (heavy-tailed weights, calibrated BatchNorm): see docstring
             try:
                 tnet, tline = H.trained_like_model(args.topology, 11)

@@ -698,6 +698,14 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
   {
     const char* e = getenv("XVEC_P8");   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
     use_p8_ = !(e && *e && atoi(e) == 0);
+    // XVEC_P8_WHOLE (read per context): how tdnn_gemm_kernel_p8 deals its work out.  0 (default): K tiles evenly, partial tiles
+    // exchanged through the workspace - the shortest launch when a launch has the GPU to itself.  1: whole output tiles only -
+    // every launch is LONGER on its own (800 tiles on 256 workgroups: a quarter of them gets a fourth tile) but needs no exchange,
+    // and with two batches in flight the other lane's kernels fill the CUs that finish early: +3 % throughput at two lanes,
+    // -10 % on the dominant kernel's own roofline fraction (profiles/r05_p8_whole_tiles.md).  2: whole tiles for the K <= 512 layers.
+    // Same bits either way: every output element is accumulated in one fixed order.
+    const char* w = getenv("XVEC_P8_WHOLE");
+    p8_whole_ = (w && *w) ? atoi(w) : 0;
   }
   in_ld_ = RoundUp(info_.input_dim, kBK);
   stats_ld_ = RoundUp(2 * info_.pool_dim, kBK);
@@ -1258,6 +1266,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
         // single-pass fp16: the layers tdnn_gemm_kernel_p8 can run, run it - for every launch (see the fast region below)
         GemmArgs g8 = ga;
         g8.p8 = 1;
+        g8.p8_whole = p8_whole_;
         if (gemm_p8_applicable(g8, kPrecFp16)) ga = g8;
       }
       Check(launch_tdnn_gemm(ga, prec, epi, s), "tdnn_gemm launch");
@@ -1309,6 +1318,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
             if (use_p8_ && dl.w4p && (epi == kEpiAct || epi == kEpiStats)) {
               GemmArgs g8 = gr;
               g8.p8 = 1;
+              g8.p8_whole = p8_whole_;
               g8.w4 = dl.w4p;
               g8.w4_scale = dl.w4p_scale + (epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0);
               if (gemm_p8_applicable(g8, rprec)) gr = g8;
@@ -1323,6 +1333,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
               const size_t so = epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0;
               GemmArgs g8 = gr;
               g8.p8 = 1;
+              g8.p8_whole = p8_whole_;
               g8.w4 = dl.w4p;
               g8.w4_scale = dl.w4p_scale + so;
               g8.w4b = dl.w4bp;
@@ -1337,6 +1348,7 @@ void Engine::ForwardOnLane(size_t lane, const Plan& plan, const float* feats_dev
               // formed in another order than the 32-column kernels', and a chunk's embedding must not depend on its batch
               GemmArgs g8 = gr;
               g8.p8 = 1;
+              g8.p8_whole = p8_whole_;
               g8.w4 = dl.w4p;
               g8.w4_scale = dl.w4p_scale + (epi == kEpiStats ? (size_t)li.n_pad * (li.k_pad / kBK) : 0);
               if (gemm_p8_applicable(g8, kPrecFp16Mx)) gr = g8;

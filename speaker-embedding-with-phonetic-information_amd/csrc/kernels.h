@@ -275,6 +275,8 @@ struct GemmArgs {
   // formed in another order than the 32-column kernels') and, for kPrecFp16Mx, that w4 / w4_scale are packed in its walk order.
   int p8;
   int p8_ktiles;         // K tiles of an output tile (set by the launcher)
+  int p8_whole;          // partition policy (caller): 0 = K tiles dealt out evenly (stream-K exchange), 1 = whole output tiles only, 2 = whole
+                         // tiles for layers of <= 8 K tiles; the launcher resolves it to 0 / 1 for the kernel
   int p8_ktiles_lo;      // kPrecFp16Mx2: tiles of the second walk (256 4-bit columns each); w4b / w4b_scale are then in ITS order
                          // (PlanWalkLoSteps64)
 };

@@ -393,6 +393,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
     // lane owns frames q*16 + fr_i (q = 0..3) x two groups of 8 contiguous columns: nbase + h*32 + fr_g*8 + (0..7),
     // h = p>>1, position inside the group (p&1)*4 + r
     const int ncol = nbase + fr_g * 8;
+    // Plane stores as (wave-uniform base in SGPRs) + (32-bit byte offset per lane): base and row step are read from the kernel
+    // arguments ONCE.  Written as `a.out_hi + (long)row * a.ldo + col` per store, hipcc re-loaded a.out_hi from the kernarg
+    // segment in front of every one of the 32 stores of a wave tile (s_load_dwordx2 + s_waitcnt lgkmcnt(0): a scalar-cache round
+    // trip with the matrix pipe idle) and formed every address with a 64-bit multiply-add and two 64-bit adds (round 5, from the ISA).
+    // A plane is far below 4 GB (131072 rows x 4096 columns x 2 bytes at most).
+    XV_AS1 char* hi_base = (XV_AS1 char*)a.out_hi;   // (global address space: a generic pointer would make these flat stores)
+    XV_AS1 char* lo_base = (XV_AS1 char*)a.out_lo;
+    XV_AS1 char* lo4_base = (XV_AS1 char*)a.out_lo4;
+    unsigned row_step_b = (unsigned)a.ldo * 32u;                                   // 16 rows, bytes
+    unsigned off0_b = (unsigned)(((mbase + fr_i) * a.ldo + ncol) * 2);             // this lane's first row, first column group
+    asm volatile("" : "+s"(hi_base), "+s"(lo_base), "+s"(lo4_base), "+s"(row_step_b));   // values, not re-loadable expressions
     if constexpr (LAZY && !PrecEmitsLo4(PREC)) {
       // Parameters from LDS, column pair outermost: the 24 parameter words of a lane's 8 contiguous columns are read once
       // and serve the four 16-row groups (with the rows outermost they were read again for every group: 96 LDS reads and
@@ -442,8 +453,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
               for (int v = 0; v < 4; ++v) ymax = fmaxf(fmaxf(ymax, fabsf(y2[v][0])), fabsf(y2[v][1]));
               gm[q] = ymax;
             }
-            *(u32x4*)(a.out_hi + (long)row * a.ldo + ncol + pp * 32) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-            if constexpr (SPLIT) *(u32x4*)(a.out_lo + (long)row * a.ldo + ncol + pp * 32) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+            const unsigned ob = off0_b + (unsigned)q * row_step_b + (unsigned)pp * 64u;
+            *(XV_AS1 u32x4*)(hi_base + ob) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+            if constexpr (SPLIT) *(XV_AS1 u32x4*)(lo_base + ob) = u32x4{lw[0], lw[1], lw[2], lw[3]};
           }
         }
       }
@@ -545,10 +557,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
         // y[0..7] = columns ncol..ncol+7, y[8..15] = columns ncol+32..ncol+39
         // (the run-time tests of out_hi / out_lo4 are always true; as branches they keep hipcc from interleaving the stores,
         // the group-maximum code and the residual block, which spilled 9-16 registers in the 512 x 128 stream-K kernel)
-        uint16_t* dh = a.out_hi + (long)row * a.ldo + ncol;
+        const unsigned ob = off0_b + (unsigned)q * row_step_b;   // (base + 32-bit offset: see the top of this branch)
         if (!PrecEmitsLo4(PREC) || a.out_hi) {
-          *(u32x4*)(dh) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-          *(u32x4*)(dh + 32) = u32x4{hw[4], hw[5], hw[6], hw[7]};
+          *(XV_AS1 u32x4*)(hi_base + ob) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+          *(XV_AS1 u32x4*)(hi_base + ob + 64u) = u32x4{hw[4], hw[5], hw[6], hw[7]};
         }
         if (PrecEmitsLo4(PREC) && a.out_lo4) {
           // what the fp16 rounding dropped, y - fp16(y), as e2m1 with one power-of-two scale per row and 64-column block
@@ -581,14 +593,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[4]
             c0 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c0, r0, r1, sc4, v);
             c1 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(c1, r2, r3, sc4, v);
           });
-          uint8_t* d4 = a.out_lo4 + (long)row * (a.ldo >> 1) + (ncol >> 1);
-          *(unsigned*)d4 = c0;
-          *(unsigned*)(d4 + 16) = c1;
+          // (4 bits per value: a quarter of the fp16 plane's byte offsets)
+          *(XV_AS1 unsigned*)(lo4_base + (ob >> 2)) = c0;
+          *(XV_AS1 unsigned*)(lo4_base + (ob >> 2) + 16u) = c1;
           e4 |= e << (8 * q);
         } else if constexpr (SPLIT) {
-          uint16_t* dl = a.out_lo + (long)row * a.ldo + ncol;
-          *(u32x4*)(dl) = u32x4{lw[0], lw[1], lw[2], lw[3]};
-          *(u32x4*)(dl + 32) = u32x4{lw[4], lw[5], lw[6], lw[7]};
+          *(XV_AS1 u32x4*)(lo_base + ob) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+          *(XV_AS1 u32x4*)(lo_base + ob + 64u) = u32x4{lw[4], lw[5], lw[6], lw[7]};
         }
       }
     }
@@ -2334,6 +2345,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     const long all = (long)(tb1 - tb0) * cpl * ST;
     auto cut = [&](long g) __attribute__((always_inline)) {
       const long s = all * g / Ng;
+      // whole tiles only (GemmArgs::p8_whole): no partial tile, no exchange through the workspace - the shares then differ by one tile
+      if (a.p8_whole) return (s + ST / 2) / ST * ST;
       int k = (int)(s % ST);
       if (k < S) k &= ~1;
       return s - s % ST + k;
@@ -3171,6 +3184,9 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < b.ngrp_lo; ++i) b.p8_ktiles_lo += (b.grp[b.ngrp + i].ksteps >> 1) * b.grp[b.ngrp + i].nshift;
   }
   b.p8 = 1;
+  // GemmArgs::p8_whole as the caller's policy (Engine: XVEC_P8_WHOLE): 0 = K tiles dealt out evenly over the workgroups (stream-K
+  // exchange; the default), 1 = whole tiles for every launch, 2 = whole tiles for layers of at most 8 K tiles per output tile
+  b.p8_whole = (a.p8_whole == 1 || (a.p8_whole == 2 && b.p8_ktiles + b.p8_ktiles_lo <= 8)) ? 1 : 0;
   b.sk_mtiles = a.m_tiles >> 1;
   const int nt = a.n_tiles >> 1;
   int grid = device_cu_count() / 8 * 8;
