@@ -2198,6 +2198,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     }
     if (part + 1 < n_parts) open_part(part + 1);
 
+#ifdef XVEC_CLOCK_PROBE
+    const unsigned long long xp_e0 = __builtin_readcyclecounter();
+#endif
     if (e_kind == 1) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(a.sk_ws + (long)bid * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
@@ -2306,8 +2309,14 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 // 100 MHz counter) between a workgroup's first and last instruction.  Slot = launch kind (0: act, <= 8 K tiles; 1: act, more;
 // 2: statistics epilogue), two words per workgroup.
 __device__ unsigned long long g_clock_probe[3 * 512 * 2];
+// [slot][workgroup][0: exchange store (issue -> vmcnt(0) + barrier), 1: flag wait + exchange loads issued, 2: drain at the start of the
+// head part (the loads landing), 3: the epilogue of the workgroup's last whole-tile part] in shader cycles, wave 0
+__device__ unsigned long long g_exchange_probe[3 * 512 * 4];
 extern "C" int xvec_clock_probe_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), sizeof(g_clock_probe), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int xvec_exchange_probe_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exchange_probe), sizeof(g_exchange_probe), 0, hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -2868,6 +2877,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   open_part(0);
 #pragma nounroll
   for (int part = 0; part < n_parts; ++part) {
+#ifdef XVEC_CLOCK_PROBE
+    unsigned long long xp_t0 = __builtin_readcyclecounter(), xp_t1 = xp_t0;
+#endif
     if (kind == 2) {
       const int prev = bid - 8 * L;   // same lane, previous group: its first action was the store waited for here
       if (tid == 0) {
@@ -2899,11 +2911,21 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[h][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#ifdef XVEC_CLOCK_PROBE
+    xp_t1 = __builtin_readcyclecounter();
+#endif
     // everything open_part issued has landed (and the previous epilogue's stores are out: the counter does not tell them apart)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#ifdef XVEC_CLOCK_PROBE
+    if (tid == 0 && bid < 512 && kind == 2) {
+      const int slot = EPI == kEpiStats ? 2 : (S > 8 ? 1 : 0);
+      g_exchange_probe[(slot * 512 + bid) * 4 + 1] = xp_t1 - xp_t0;
+      g_exchange_probe[(slot * 512 + bid) * 4 + 2] = __builtin_readcyclecounter() - xp_t1;
+    }
+#endif
     c0 = c1 = c2 = c3 = 0;
     if (wn == 1) barrier();
     // the pairs of the first walk, then - kPrecFp16Mx2 - those of the second: two loops one behind the other.  (As the two arms
@@ -2952,6 +2974,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     const int e_kind = kind, e_m0 = m0, e_n0 = n0;
     const float* e_par = (const float*)(smem + kP8PB + (part & 1) * 3072 + wn * 1536);
     if (part + 1 < n_parts) open_part(part + 1);
+#ifdef XVEC_CLOCK_PROBE
+    const unsigned long long xp_e0 = __builtin_readcyclecounter();
+#endif
     if (e_kind == 1) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(a.sk_ws + (long)bid * kPartialFloats), 0, (int)(kPartialFloats * 4), 0x00020000);
@@ -2967,6 +2992,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(a.sk_flags + bid, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef XVEC_CLOCK_PROBE
+      if (tid == 0 && bid < 512) g_exchange_probe[((EPI == kEpiStats ? 2 : (S > 8 ? 1 : 0)) * 512 + bid) * 4 + 0] = __builtin_readcyclecounter() - xp_e0;
+#endif
     } else {
       float gm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2976,6 +3004,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
         epilogue_prefetch_lds<EPI, LAZY>(a, e_par, e_m0 + wm * 64, h * 64, lane, er);
         gemm_epilogue<PREC, EPI, LAZY>(a, acc[h], e_m0 + wm * 64, e_n0 + wn * 128 + h * 64, lane, er, gm, h == 0 ? 1 : 2, e_par, h * 64);
       }
+#ifdef XVEC_CLOCK_PROBE
+      if (tid == 0 && bid < 512 && e_kind == 0) g_exchange_probe[((EPI == kEpiStats ? 2 : (S > 8 ? 1 : 0)) * 512 + bid) * 4 + 3] = __builtin_readcyclecounter() - xp_e0;
+#endif
     }
   }
 #ifdef XVEC_CLOCK_PROBE

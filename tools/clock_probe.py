@@ -61,3 +61,20 @@ for slot, name in enumerate(("act epilogue, <= 8 K tiles (tdnn4)", "act epilogue
     ghz = cyc[ok] / rt[ok] * 0.1
     print("  %-42s %3d workgroups: clock %.3f GHz (min %.3f, max %.3f); workgroup lifetime %.1f us = %.0f k cycles"
           % (name, int(ok.sum()), ghz.mean(), ghz.min(), ghz.max(), rt[ok].mean() / 100.0, cyc[ok].mean() / 1e3))
+
+if hasattr(L, "xvec_exchange_probe_read"):
+    xb = (ctypes.c_ulonglong * (3 * 512 * 4))()
+    assert L.xvec_exchange_probe_read(xb) == 0
+    x = np.frombuffer(xb, dtype=np.uint64).reshape(3, 512, 4).astype(np.float64)
+    print("stream-K exchange and epilogue, wave 0 of each workgroup, shader cycles (us at the clock above):")
+    for slot, name in enumerate(("tdnn4", "tdnn2 / tdnn3", "tdnn5 (statistics)")):
+        ghz = (a[slot, :, 0] / np.maximum(a[slot, :, 1], 1) * 0.1)
+        ghz = float(ghz[a[slot, :, 1] > 0].mean()) if (a[slot, :, 1] > 0).any() else 2.0
+        parts = []
+        for j, what in enumerate(("tail part: store of the partial tile until it is out", "head part: flag wait + loads issued",
+                                  "head part: drain until the partial tile is in", "epilogue of a whole tile")):
+            v = x[slot, :, j]
+            v = v[v > 0]
+            if v.size:
+                parts.append("%s %.0f k = %.1f us (%d wgs)" % (what, v.mean() / 1e3, v.mean() / ghz / 1e3, v.size))
+        print("  %-20s %s" % (name, "; ".join(parts)))
