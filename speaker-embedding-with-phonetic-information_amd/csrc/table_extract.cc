@@ -236,7 +236,11 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
   std::string reader_error;
   long num_fail_read = 0;
   bool stop = false;   // under mu: the consumer is gone, the reader must not block on a full queue
-  auto warn = [&](const std::string& m) { log("WARNING", m); };
+  std::mutex warn_mu;   // readers and (with several engines) consumers warn from their own threads
+  auto warn = [&](const std::string& m) {
+    std::unique_lock<std::mutex> lk(warn_mu);
+    log("WARNING", m);
+  };
 
   // ---- feature ingestion --------------------------------------------------------------------------------------------
   // Tables whose objects can be addressed (binary archive in a regular file, script file of path:offset entries) are read by
@@ -497,18 +501,24 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
 
   const auto t0 = std::chrono::steady_clock::now();
   const bool has_backend = !opt.backend_mean.empty() || !opt.backend_transform.empty() || opt.backend_normalize;
-  std::vector<int32_t> sel_row, sel_utt, poffs;
-  std::vector<float> processed, emb, post;
-  std::vector<int32_t> ok;
-  std::vector<std::string> why;
   std::string fatal;
+  std::mutex fatal_mu;
+  auto set_fatal = [&](const std::string& m) {
+    std::unique_lock<std::mutex> lk(fatal_mu);
+    if (fatal.empty()) fatal = m;
+  };
+  auto is_fatal = [&] {
+    std::unique_lock<std::mutex> lk(fatal_mu);
+    return !fatal.empty();
+  };
 
-  // Up to kNumHostSlots batches queued on the device (ExtractJob::Start returns at once): after submitting batch i the
-  // thread finalises batch i-2 (average, back-end, write) and packs batch i+1 while i-1 and i keep the GPU busy - with
+  // Up to kNumHostSlots batches queued on a device (ExtractJob::Start returns at once): after submitting batch i a consumer
+  // finalises batch i-2 (average, back-end, hand over to the writer) and packs batch i+1 while i-1 and i keep the GPU busy - with
   // only two, both lanes ran their batches side by side, finished together, and the GPU idled while the host caught up
   // (measured: 20 % idle).  Output order = input order.
   struct Work {
     Batch b;
+    long g = 0;                  // number of the batch in table order
     std::vector<int> idx;        // utterances of b that entered the device batch
     std::vector<float> packed;   // front-end path only: the processed rows, back to back
     std::vector<int32_t> offs;
@@ -516,27 +526,79 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     std::vector<int32_t> urows;
     ExtractJob job;
   };
-  // slot s of this ring = host slot s / NE of engine s % NE: consecutive batches go to consecutive engines, and the ring order
-  // is the submission order, which is the table order
-  const int NS = Engine::kNumHostSlots * NE;
-  std::vector<Work> work(NS);
-  int cur = 0;
-  std::vector<long> eseq(NE, 0);   // running batch number per engine (selects its lane)
-  // stage timing of the consumer thread (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
+  // What a finalised batch hands to the writer: one record per utterance that reached the device, in table order.
+  struct OutBatch {
+    std::vector<std::string> keys;
+    std::vector<float> vecs;   // [keys.size()][VE]
+    int VE = 0;
+    std::vector<char> okv;
+    std::vector<std::string> whys;
+    std::vector<int> rows;
+  };
+  // One consumer per engine (= per GPU): its own ring of host slots, scratch and counters.  With ONE engine the consumer runs on the
+  // calling thread and writes as it goes (rounds 2-4's loop).  With several (nnet3-xvector-compute --devices) each consumer is a
+  // thread of its own - the packing of a batch (one host copy per byte) and the wait for its device are what a single thread could
+  // not do for more than one GPU - batches are dealt to them round-robin in table order, and the calling thread writes the
+  // finalised batches in that order: the archive is byte-identical to the one-GPU job's.
+  constexpr int NS = Engine::kNumHostSlots;
+  struct Consumer {
+    Engine* eng = nullptr;
+    std::vector<Work> work;
+    int cur = 0;
+    long seq = 0;   // running batch number on this engine (selects its lane)
+    std::vector<int32_t> sel_row, sel_utt, poffs;
+    std::vector<float> processed, emb, post;
+    std::vector<int32_t> ok;
+    std::vector<std::string> why;
+    long num_fail = 0;   // utterances rejected before they reached the device
+    double t_pack = 0, t_start = 0, t_fin = 0;
+  };
+  std::vector<Consumer> cons(NE);
+  for (int e = 0; e < NE; ++e) {
+    cons[e].eng = engines[e];
+    cons[e].work.resize(NS);
+  }
+  std::mutex vad_mu, out_mu;
+  std::condition_variable out_cv;
+  std::map<long, OutBatch> done;   // NE > 1: finalised batches waiting for their turn at the writer
+  // stage timing (XVEC_TIMING=1 logs it): waiting for the reader, packing, submitting, finishing
   const bool timing = getenv("XVEC_TIMING") != nullptr;
-  double t_wait = 0, t_pack = 0, t_start = 0, t_fin = 0;
+  double t_wait = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
 
-  auto finalize = [&](Work& w) {
+  // the writer (calling thread only)
+  auto write_out = [&](const OutBatch& ob) {
+    for (size_t k = 0; k < ob.keys.size(); ++k) {
+      if (!ob.okv[k]) {
+        warn(ob.whys[k] + ": " + ob.keys[k]);
+        ++res.num_fail;
+        continue;
+      }
+      writer.WriteVec(ob.keys[k], ob.vecs.data() + k * (size_t)ob.VE, ob.VE);
+      res.frames += ob.rows[k];
+      ++res.num_success;
+    }
+  };
+  auto deliver = [&](long g, OutBatch&& ob) {
+    if (NE == 1) {
+      write_out(ob);   // same thread, already in table order
+      return;
+    }
+    std::unique_lock<std::mutex> lk(out_mu);
+    done.emplace(g, std::move(ob));
+    out_cv.notify_all();
+  };
+
+  auto finalize = [&](Consumer& C, Work& w) {
     const int n = (int)w.idx.size();
-    emb.resize((size_t)n * E);
-    ok.assign(n, 0);
-    why.assign(n, std::string());
-    w.job.Finish(emb.data(), ok.data(), &why);
-    const float* vec = emb.data();
+    C.emb.resize((size_t)n * E);
+    C.ok.assign(n, 0);
+    C.why.assign(n, std::string());
+    w.job.Finish(C.emb.data(), C.ok.data(), &C.why);
+    const float* vec = C.emb.data();
     int VE = E;
     if (n && has_backend) {
       BackendOptions bo;
@@ -547,22 +609,25 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
       bo.normalize = opt.backend_normalize;
       bo.scaleup = opt.backend_scaleup;
       VE = bo.transform ? bo.t_rows : E;
-      post.resize((size_t)n * VE);
+      C.post.resize((size_t)n * VE);
       for (int k = 0; k < n; ++k)
-        if (!ok[k]) std::fill(emb.begin() + (size_t)k * E, emb.begin() + (size_t)(k + 1) * E, 0.f);
-      BackendApply(engine->device(), emb.data(), n, E, bo, post.data(), nullptr);
-      vec = post.data();
+        if (!C.ok[k]) std::fill(C.emb.begin() + (size_t)k * E, C.emb.begin() + (size_t)(k + 1) * E, 0.f);
+      BackendApply(C.eng->device(), C.emb.data(), n, E, bo, C.post.data(), nullptr);
+      vec = C.post.data();
     }
+    OutBatch ob;
+    ob.VE = VE;
+    ob.keys.reserve(n);
+    ob.vecs.assign(vec, vec + (size_t)n * VE);
+    ob.okv.resize(n);
+    ob.whys.resize(n);
+    ob.rows.resize(n);
     for (int k = 0; k < n; ++k) {
-      const Utt& u = w.b.utts[w.idx[k]];
-      if (!ok[k]) {
-        warn(why[k] + ": " + u.key);
-        ++res.num_fail;
-        continue;
-      }
-      writer.WriteVec(u.key, vec + (size_t)k * VE, VE);
-      res.frames += u.feats.rows;
-      ++res.num_success;
+      Utt& u = w.b.utts[w.idx[k]];
+      ob.keys.push_back(std::move(u.key));   // (the batch is dropped below)
+      ob.okv[k] = C.ok[k] ? 1 : 0;
+      if (!C.ok[k]) ob.whys[k] = C.why[k];
+      ob.rows[k] = u.feats.rows;
     }
     if (!indexer) {   // stream reader: the batch's feature buffers go back to it
       std::unique_lock<std::mutex> lk(mu);
@@ -570,14 +635,24 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
         if (buf_pool.size() < 4096 && u.feats.data.capacity()) buf_pool.push_back(std::move(u.feats.data));
     }
     w.b = Batch();
+    deliver(w.g, std::move(ob));
   };
 
-  auto process = [&](Batch&& b) {
-    if (!b.utts.empty() && fatal.empty()) {
+  // One batch through one consumer: reject what cannot run, pack, submit; then finalise the consumer's oldest batch in flight.
+  // Every batch number g is delivered exactly once (an empty record when nothing of the batch reaches the writer), so the ordered
+  // writer never waits for a number that does not come.
+  auto process = [&](Consumer& C, Batch&& b, long g) {
+    bool submitted_batch = false;
+    if (!b.utts.empty() && !is_fatal()) {
       try {
         const auto tp0 = now();
-        Work& w = work[cur];
+        Work& w = C.work[C.cur];
         w.b = std::move(b);
+        w.g = g;
+        std::vector<int32_t>& sel_row = C.sel_row;
+        std::vector<int32_t>& sel_utt = C.sel_utt;
+        std::vector<int32_t>& poffs = C.poffs;
+        std::vector<float>& processed = C.processed;
         std::vector<float>& packed = w.packed;
         std::vector<int32_t>& offs = w.offs;
         std::vector<int>& idx = w.idx;
@@ -595,7 +670,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
             std::ostringstream m;
             m << "feature dimension " << u.feats.cols << " of utterance " << u.key << " does not match the model's " << D;
             warn(m.str());
-            ++res.num_fail;
+            ++C.num_fail;
             continue;
           }
           uptr.push_back(u.feats.data.data());
@@ -614,24 +689,26 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
             const int T = u.feats.rows;
             const std::vector<float>* v = nullptr;
             if (vad) {
+              std::unique_lock<std::mutex> vlk(vad_mu);   // (the reader caches what it loads: one consumer at a time)
               if (!vad->HasKey(u.key)) {
                 warn("No VAD input found for utterance " + u.key);
-                ++res.num_fail;
+                ++C.num_fail;
                 continue;
               }
               v = &vad->Value(u.key);
+              vlk.unlock();
               if ((int)v->size() != T) {
                 std::ostringstream m;
                 m << "Mismatch in number of frames " << T << " for features and VAD " << v->size() << ", for utterance " << u.key;
                 warn(m.str());
-                ++res.num_fail;
+                ++C.num_fail;
                 continue;
               }
               bool any = false;
               for (int t = 0; t < T && !any; ++t) any = (*v)[t] != 0.f;
               if (T > 0 && !any) {
                 warn("No features were judged as voiced for utterance " + u.key);
-                ++res.num_fail;
+                ++C.num_fail;
                 continue;
               }
             }
@@ -643,8 +720,8 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
           idx.swap(keep_idx);
           n = (int)idx.size();
           // device path: raw rows in, CMN + selection + network on the lane's stream, nothing comes back but embeddings
-          if (n) submitted = w.job.StartFrontEnd(engines[cur % NE], opt, cur / NE, eseq[cur % NE], n, rawp.data(), rrows.data(), vadp.data());
-          if (submitted) ++eseq[cur % NE];
+          if (n) submitted = w.job.StartFrontEnd(C.eng, opt, C.cur, C.seq, n, rawp.data(), rrows.data(), vadp.data());
+          if (submitted) ++C.seq;
           if (n && !submitted) {
             // utterances that are cut into several chunks or padded: front-end result back to the host, then Start()
             sel_row.clear();
@@ -665,33 +742,126 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
               poffs.push_back((int32_t)sel_row.size());
             }
             processed.resize(sel_row.size() * (size_t)D);
-            engine->FrontEndHost(raw2.data(), raw_off2.data(), n, sel_row.data(), sel_utt.data(), (int)sel_row.size(),
+            C.eng->FrontEndHost(raw2.data(), raw_off2.data(), n, sel_row.data(), sel_utt.data(), (int)sel_row.size(),
                                  opt.cmn_window, opt.cmn_center, opt.cmn_min_window, processed.data());
             packed.swap(processed);
             offs = poffs;
           }
         }
         const auto tp1 = now();
-        t_pack += secs(tp0, tp1);
+        C.t_pack += secs(tp0, tp1);
         if (n) {
           if (!submitted) {
-            Engine* const eng = engines[cur % NE];
-            if (use_frontend) w.job.Start(eng, opt, cur / NE, eseq[cur % NE]++, packed.data(), offs.data(), n);   // front-end result (host)
-            else w.job.StartPtrs(eng, opt, cur / NE, eseq[cur % NE]++, uptr.data(), urows.data(), n);
+            if (use_frontend) w.job.Start(C.eng, opt, C.cur, C.seq++, packed.data(), offs.data(), n);   // front-end result (host)
+            else w.job.StartPtrs(C.eng, opt, C.cur, C.seq++, uptr.data(), urows.data(), n);
           }
           const auto tp2 = now();
-          t_start += secs(tp1, tp2);
-          cur = (cur + 1) % NS;
-          Work& oldest = work[cur];   // the slot the next batch will use
-          if (oldest.job.active()) finalize(oldest);
-          t_fin += secs(tp2, now());
+          C.t_start += secs(tp1, tp2);
+          submitted_batch = true;
+          C.cur = (C.cur + 1) % NS;
+          Work& oldest = C.work[C.cur];   // the slot the next batch will use
+          if (oldest.job.active()) finalize(C, oldest);
+          C.t_fin += secs(tp2, now());
         } else {
           w.b = Batch();
         }
       } catch (const std::exception& ex) {
-        fatal = ex.what();  // keep draining the queue so the reader can finish
+        set_fatal(ex.what());  // keep draining the queue so the reader can finish
       }
     }
+    if (!submitted_batch) deliver(g, OutBatch());
+  };
+  // the batches a consumer still has in flight, oldest first
+  auto drain_consumer = [&](Consumer& C) {
+    for (int k = 1; k <= NS; ++k) {
+      Work& w = C.work[(C.cur + k) % NS];
+      if (!w.job.active()) continue;
+      if (is_fatal()) {   // still owed to the ordered writer
+        deliver(w.g, OutBatch());
+        continue;
+      }
+      try {
+        finalize(C, w);
+      } catch (const std::exception& ex) {
+        set_fatal(ex.what());
+        deliver(w.g, OutBatch());
+      }
+    }
+  };
+
+  // ---- several engines: one consumer thread each, the calling thread deals the batches out and writes ------------------------
+  std::vector<std::deque<std::pair<long, Batch>>> inbox(NE);
+  std::mutex in_mu;
+  std::condition_variable in_cv;
+  bool in_end = false;
+  std::vector<std::thread> workers;
+  struct WorkerGuard {   // an exception on the calling thread must not leave joinable threads behind
+    std::vector<std::thread>& ts;
+    std::mutex& m;
+    std::condition_variable& c;
+    bool& end;
+    ~WorkerGuard() {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        end = true;
+        c.notify_all();
+      }
+      for (std::thread& t : ts)
+        if (t.joinable()) t.join();
+    }
+  } worker_guard{workers, in_mu, in_cv, in_end};
+  if (NE > 1) {
+    for (int e = 0; e < NE; ++e)
+      workers.emplace_back([&, e] {
+        Consumer& C = cons[e];
+        for (;;) {
+          std::pair<long, Batch> item;
+          {
+            std::unique_lock<std::mutex> lk(in_mu);
+            in_cv.wait(lk, [&] { return !inbox[e].empty() || in_end; });
+            if (inbox[e].empty()) break;
+            item = std::move(inbox[e].front());
+            inbox[e].pop_front();
+            in_cv.notify_all();
+          }
+          try {
+            process(C, std::move(item.second), item.first);
+          } catch (const std::exception& ex) {   // (process catches what the extraction throws; this is for the unexpected)
+            set_fatal(ex.what());
+          }
+        }
+        drain_consumer(C);
+      });
+  }
+  long next_g = 0, next_write = 0;
+  auto write_ready = [&](bool all) {   // calling thread: whatever is next in table order (all: whatever is there, gaps included)
+    for (;;) {
+      OutBatch ob;
+      {
+        std::unique_lock<std::mutex> lk(out_mu);
+        auto it = done.begin();
+        if (it == done.end() || (!all && it->first != next_write)) return;
+        next_write = it->first + 1;
+        ob = std::move(it->second);
+        done.erase(it);
+      }
+      write_out(ob);
+    }
+  };
+  auto dispatch = [&](Batch&& b) {
+    const long g = next_g++;
+    if (NE == 1) {
+      process(cons[0], std::move(b), g);
+      return;
+    }
+    const int e = (int)(g % NE);
+    {
+      std::unique_lock<std::mutex> lk(in_mu);
+      in_cv.wait(lk, [&] { return inbox[e].size() < 2; });
+      inbox[e].emplace_back(g, std::move(b));
+      in_cv.notify_all();
+    }
+    write_ready(false);
   };
   // With calibration the arithmetic of the whole job is chosen before anything is submitted.  Addressable tables were sampled
   // over their whole list above; a stream is calibrated on its first calibrate_utts utterances: batches are held back until
@@ -717,7 +887,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
       held.push_back(std::move(b));
       if (held_utts >= (size_t)opt.calibrate_utts || last) {
         calibrated = true;
-        if (fatal.empty()) {
+        if (!is_fatal()) {
           try {
             std::vector<CalibUtt> cu;
             for (const Batch& hb : held)
@@ -729,31 +899,47 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
               share_choice();
             }
           } catch (const std::exception& ex) {
-            fatal = ex.what();
+            set_fatal(ex.what());
           }
         }
-        for (Batch& hb : held) process(std::move(hb));
+        for (Batch& hb : held) dispatch(std::move(hb));
         held.clear();
       }
     } else {
-      process(std::move(b));
+      dispatch(std::move(b));
     }
     if (last) break;
   }
-  // the batches still in flight, oldest first
-  for (int k = 0; k < NS && fatal.empty(); ++k) {
-    Work& w = work[(cur + k) % NS];
-    if (!w.job.active()) continue;
-    try {
-      finalize(w);
-    } catch (const std::exception& ex) {
-      fatal = ex.what();
+  if (NE == 1) {
+    drain_consumer(cons[0]);
+  } else {
+    {
+      std::unique_lock<std::mutex> lk(in_mu);
+      in_end = true;
+      in_cv.notify_all();
     }
+    // write while the consumers finish; then whatever is left (gaps only after a fatal error)
+    for (;;) {
+      write_ready(false);
+      std::unique_lock<std::mutex> lk(out_mu);
+      if (next_write >= next_g) break;
+      if (out_cv.wait_for(lk, std::chrono::milliseconds(50)) == std::cv_status::timeout && is_fatal()) break;
+    }
+    for (std::thread& t : workers) t.join();
+    workers.clear();
+    write_ready(true);
   }
+  for (const Consumer& C : cons) res.num_fail += C.num_fail;
   if (timing) {
+    double t_pack = 0, t_start = 0, t_fin = 0;
+    for (const Consumer& C : cons) {
+      t_pack += C.t_pack;
+      t_start += C.t_start;
+      t_fin += C.t_fin;
+    }
     std::ostringstream m;
-    m << "consumer stages: wait for reader " << t_wait << " s, pack " << t_pack << " s, plan+submit " << t_start
-      << " s, finish+write " << t_fin << " s";
+    m << "consumer stages" << (NE > 1 ? " (summed over the engines' threads)" : "") << ": wait for reader " << t_wait << " s, pack "
+      << t_pack << " s, plan+submit " << t_start << " s, finish+write " << t_fin << " s";
     log("LOG", m.str());
   }
   {

@@ -318,3 +318,39 @@ def test_cli_devices_all_on_a_multi_gpu_node_equals_one_gpu(tmp_path):
     r2 = _cli(tmp_path, "all", ["--devices=all"])
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert (tmp_path / "all.ark").read_bytes() == (tmp_path / "plain.ark").read_bytes()
+
+
+def test_cli_several_engines_threaded_consumers_write_the_one_engine_archive(tmp_path):
+    """The several-engine table loop (a consumer thread per engine, batches dealt round-robin, the calling thread writes in
+    table order) on a ONE-GPU box: XVEC_ENGINES_ON_ONE_DEVICE=3 builds three engines on device 0 (test knob, no RCCL).  Archive
+    and script file are those of the one-engine job byte for byte - with calibration on (the choice of engine 0 is shared), with
+    utterances that fail in different places (empty, too short, wrong dimension), for two batch sizes."""
+    utts = _cli_job(tmp_path, 400)
+    # a wrong-dimension utterance and an empty one in the middle of the table: rejected by the consumer, the rest unaffected
+    bad = [("bad_dim", np.ones((300, 24), np.float32)), ("zero_len", np.zeros((0, 23), np.float32))]
+    allu = utts[:200] + bad + utts[200:]
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), allu, scp_path=str(tmp_path / "feats.scp"))
+    for bf in ("4096", "20000"):
+        r0 = _cli(tmp_path, "one" + bf, ["--batch-frames=" + bf])
+        assert r0.returncode == 0, r0.stderr[-2000:]
+        r1 = _cli(tmp_path, "three" + bf, ["--batch-frames=" + bf], env={"XVEC_ENGINES_ON_ONE_DEVICE": "3", "XVEC_TIMING": "1"})
+        assert r1.returncode == 0 and "3 engines on device" in r1.stderr, r1.stderr[-2000:]
+        assert "summed over the engines' threads" in r1.stderr
+        assert (tmp_path / ("three%s.ark" % bf)).read_bytes() == (tmp_path / ("one%s.ark" % bf)).read_bytes()
+        assert (tmp_path / ("three%s.scp" % bf)).read_text().replace("three", "one") == (tmp_path / ("one%s.scp" % bf)).read_text()
+        done = lambda r: [l for l in r.stderr.splitlines() if "Done " in l][-1]   # noqa: E731
+        assert done(r0).split("Done")[-1] == done(r1).split("Done")[-1], (done(r0), done(r1))
+        assert "bad_dim" in r1.stderr
+    # a damaged archive is fatal in the threaded path too: non-zero exit, no hang, what was written before is intact vectors
+    blob = (tmp_path / "feats.ark").read_bytes()
+    (tmp_path / "cut.ark").write_bytes(blob[:len(blob) // 2 + 7])
+    exe = os.path.join(H.ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
+    r = subprocess.run([exe, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine",
+                        "--batch-frames=4096", str(tmp_path / "final.raw"), "ark:%s/cut.ark" % tmp_path, "ark:%s/cut_out.ark" % tmp_path],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=dict(os.environ, XVEC_ENGINES_ON_ONE_DEVICE="2"))
+    assert r.returncode != 0, r.stderr[-1500:]
+    got = list(kio.read_ark(str(tmp_path / "cut_out.ark"), "vector")) if os.path.getsize(tmp_path / "cut_out.ark") else []
+    ref = dict(kio.read_ark(str(tmp_path / "one4096.ark"), "vector"))
+    for k, v in got:
+        np.testing.assert_array_equal(v, ref[k])
