@@ -119,6 +119,36 @@ __device__ __forceinline__ float from16(uint16_t u) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Schedule fuzzing (verification build only: `make fuzz` -> -DXVEC_SCHED_FUZZ, a second library next to the product one;
+// tools/fuzz_schedule.sh).  The GEMM kernels order their LDS traffic with counted waits and one barrier per phase, and their two
+// wave groups run a barrier interval apart: a missing wait shows only when one wave gets far enough ahead of another, which
+// under load happens once in thousands of launches (both races of rounds 4 / 5 were found that way).  The fuzz build makes
+// it happen all the time: every XV_FUZZ() point sleeps the WAVE for a pseudo-random time - mostly 0-3 x 64 cycles, one time in
+// four up to 63 x 64 cycles (a whole K tile) - from a per-wave generator seeded with the clock at kernel start, so the waves
+// of a workgroup drift against each other and against the DMA engine differently in every launch.  Every output element is
+// summed in one fixed order, so ANY result that differs from the emulation / from the previous launch is a hazard, not noise.
+// Scalar instructions only (s_sleep, s_mul, s_add): no wait counter is touched, no vector register used.
+#ifdef XVEC_SCHED_FUZZ
+__device__ __forceinline__ unsigned sched_fuzz_seed() {
+  const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+  return __builtin_amdgcn_readfirstlane((t * 2654435761u) ^ ((threadIdx.x >> 6) * 0x9E3779B9u) ^ (blockIdx.x * 0x85EBCA6Bu));
+}
+__device__ __forceinline__ void sched_fuzz(unsigned& st) {
+  st = __builtin_amdgcn_readfirstlane(st * 1664525u + 1013904223u);
+  const unsigned r = st >> 24;
+  unsigned n = r < 192u ? (r & 3u) : (r - 192u);
+  __builtin_amdgcn_sched_barrier(0);
+  for (; n; --n) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define XV_FUZZ_INIT() unsigned xv_fuzz_state = sched_fuzz_seed()
+#define XV_FUZZ() sched_fuzz(xv_fuzz_state)
+#else
+#define XV_FUZZ_INIT() do { } while (0)
+#define XV_FUZZ() do { } while (0)
+#endif
+
 // Kaldi's ApplyFloor: x < floor ? floor : x, i.e. a NaN stays a NaN (fmaxf / v_max_f32 would return the floor).  gfx950's
 // v_maximum3_f32 is the IEEE-754-2019 maximum - NaN-propagating - in one instruction instead of compare + select; the only
 // difference to the comparison is the sign of an exact zero (maximum(-0, +0) = +0), which no later sum or product can see.
@@ -721,6 +751,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   if (mt >= a.m_tiles) return;
   const int m0 = mt * kBM;
   const int n0 = nt * kBN;
+  XV_FUZZ_INIT();
 
   // ---- per-lane staging geometry -------------------------------------------------------
   // one global_load_lds_dwordx4 per wave = 16 LDS rows x 64 B; lane l -> row l>>2, phys chunk l&3
@@ -833,6 +864,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     for (int s = 0; s < S; ++s) {
       // stage s has landed once at most the stages issued after it are outstanding; everyone is past its reads of stage
       // s - 1, whose slot the loads issued below overwrite
+      XV_FUZZ();
       const int later = min(S - 1 - s, NST - 2);
       if (later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PER) : "memory");
       else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PER) : "memory");
@@ -846,6 +878,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
         if constexpr (SPLIT) xl[f] = *(const s16x8*)(st + x_rd + kTileBytes + f * 1024);
         if constexpr (WSPLIT) wl[f] = *(const s16x8*)(st + w_rd + kTileBytes + f * 1024);
       }
+      XV_FUZZ();
       if (s + NST - 1 < S) stage_loads_asm((s + NST - 1) % NST);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -867,6 +900,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
   __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and orders the LDS writes
 
   for (int s = 0; s < S; ++s) {
+    XV_FUZZ();
     const char* st = smem + (s & 1) * STAGE;
     s16x8 xh[4], xl[4], wh[4], wl[4];
 #pragma unroll
@@ -878,6 +912,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_gemm_kernel(const GemmArgs a) {
     }
     // stage the next K step into the other buffer: every wave finished reading it before the
     // barrier that ended the previous iteration.
+    XV_FUZZ();
     if (s + 1 < S) stage_loads((s + 1) & 1);
 
 #pragma unroll
@@ -1045,6 +1080,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   if (mt >= m_tiles) return;
   const int m0 = mt * 256;
   const int n0 = nt * kBN;
+  XV_FUZZ_INIT();
   // Start stagger: the first workgroup of every CU waits a different fraction of one tile time.  All tiles take the
   // same time, so without it every CU reaches its epilogue in the same microsecond and the 32 MB store burst of a
   // round (128 KiB per CU) runs at the HBM write rate with nothing to overlap; staggered, the stores of one CU drain
@@ -1362,10 +1398,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
     for (int j = 0; j < SH; j += 4, ++rblk) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        XV_FUZZ();
         read_step(f);
         if (s == 3) ws_v = read_scales(rblk % 3);
+        XV_FUZZ();
         const int n = (j + s + 2 < S) ? issue_step() : 0;
         wait_and_barrier(n);
+        XV_FUZZ();
         __builtin_amdgcn_s_setprio(1);
         mfmas(f);
         convert(f, s);
@@ -1379,10 +1418,13 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
       for (int j = SH; j < S; ++j) {   // the second walk (see the stream-K kernel)
         const int lg = rg, lkk = rkk, lj = rj;
         if (lj == 0 && (lkk & 1) == 0) ++rslab;
+        XV_FUZZ();
         read_step(f);
         const int ws_lo = read_scales((j - SH + (SH >> 2)) % 3);
+        XV_FUZZ();
         const int n = (j + 2 < S) ? issue_step() : 0;
         wait_and_barrier(n);
+        XV_FUZZ();
         __builtin_amdgcn_s_setprio(1);
         lo_mfmas(f, ws_lo, lg, lkk, lj, (rslab - 1) % 3);
         __builtin_amdgcn_s_setprio(0);
@@ -1393,9 +1435,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
   } else {
     for (int j = 0; j < S; ++j) {
       // ---- LOAD segment of step j
+      XV_FUZZ();
       read_step(f);
+      XV_FUZZ();
       const int n = (j + 2 < S) ? issue_step() : 0;
       wait_and_barrier(n);
+      XV_FUZZ();
       // ---- COMPUTE segment of step j
       __builtin_amdgcn_s_setprio(1);
       mfmas(f);
@@ -1610,6 +1655,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
   const int col_w = WIDE ? 0 : (wave >> 2) * 64;                 // workgroup tile
   const int group = wave >> 2;
   const int bid = blockIdx.x;
+  XV_FUZZ_INIT();
 
   // ---- this workgroup's share of the K steps ---------------------------------------------------------------------
   // XCD block `xcd` owns a contiguous range of whole ROW tiles.  Its G/8 workgroups form G/8/L groups of L "column
@@ -2139,11 +2185,14 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           // with 1.25 passes per product the LOAD segment (12 fragment reads, 3-6 LDS-DMA instructions) is as long as
           // the COMPUTE segment of the partner wave (s_memtime stamps: ~870 vs ~890 cycles): it gets the issue
           // priority (measured -4.5 % on tdnn2 against the opposite assignment the two-pass kernels use)
+          XV_FUZZ();
           __builtin_amdgcn_s_setprio(1);
           read_step(f);
           if (s == 3) read_scales(rblk % 3);
+          XV_FUZZ();
           const int n = (j + s + 2 < ns) ? issue_step() : 0;
           wait_and_barrier(n);
+          XV_FUZZ();
           __builtin_amdgcn_s_setprio(0);
           mfmas(f);
           convert(f, s);
@@ -2160,8 +2209,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
           if ((lj == 0 && (lkk & 1) == 0) || (j == ns_hi && ns_hi == 0)) ++rslab;   // the rule of issue_step
           read_step(f);
           read_scales((rstep - SH + (SH >> 2)) % 3);
+          XV_FUZZ();
           const int n = (j + 2 < ns) ? issue_step() : 0;
           wait_and_barrier(n);
+          XV_FUZZ();
           __builtin_amdgcn_s_setprio(0);
           lo_mfmas(f, lg, lkk, lj, (rslab - 1) % 3);
           plain_barrier();
@@ -2171,9 +2222,12 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
     } else {
 #pragma nounroll
       for (int j = 0; j < ns; ++j) {
+        XV_FUZZ();
         read_step(f);
+        XV_FUZZ();
         const int n = (j + 2 < ns) ? issue_step() : 0;
         wait_and_barrier(n);
+        XV_FUZZ();
         __builtin_amdgcn_s_setprio(1);
         mfmas(f);
         __builtin_amdgcn_s_setprio(0);
@@ -2181,6 +2235,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
       }
     }
     if (group == 0) plain_barrier();
+    XV_FUZZ();
     // every wave is past its last LDS read: the rings may be refilled for the next part while this one's results go out
     const int e_kind = kind, e_m0 = m0, e_n0 = n0;
     const float* e_par = (const float*)(smem + PB + (part & 1) * 1536);
@@ -2213,6 +2268,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_sk(const GemmArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[h][p][q]), rs, tid * 16,
                                                    ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent);
       // every store of this workgroup has been performed (acknowledged) before the flag goes out
+      XV_FUZZ();
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), through the builtin so that hipcc's scoreboard knows
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -2335,6 +2391,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   const int fr_i = lane & 15, fr_g = lane >> 4;
   const int bid = blockIdx.x;
   const unsigned lds_base = (unsigned)(size_t)(XV_AS3 char*)smem;
+  XV_FUZZ_INIT();
 
   // ---- this workgroup's share of the K tiles (the partition of tdnn_gemm_kernel_sk) ----------------------------------------
   // kPrecFp16Mx2: behind the S tiles of 64 fp16 columns an output tile's walk goes on with S_lo tiles of 256 4-bit columns
@@ -2584,6 +2641,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     const char* xs1 = smem + xrd1 + B * kP8XW;
     const char* ws0 = smem + wrd0 + B * kP8XW;
     const char* ws1 = smem + wrd1 + B * kP8XW;
+    XV_FUZZ();
     if (prio_load) __builtin_amdgcn_s_setprio(1);
     if constexpr (P == 0) {
 #pragma unroll
@@ -2630,6 +2688,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     // steady state (every phase of this pair and of the one before it staged its unit): the counts are constants - 2 per phase,
     // + 3 in phase 1 of a block's first tile (4-bit tile and scales); the tail of a part and the second walk count as they go
     constexpr int E1 = (MX && !LO && !ODD) ? 3 : 0;
+    XV_FUZZ();
     if constexpr (FAST) {
       constexpr int UNIT = P == 0 ? 2 : P == 1 ? 3 : P == 2 ? 0 : 1;
       issue(UNIT, P < 2 ? 1 - B : B);
@@ -2665,6 +2724,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       }
     }
     asm volatile("s_barrier" ::: "memory");
+    XV_FUZZ();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the fragments are in (the MFMAs are inline asm: their waits are ours)
     __builtin_amdgcn_sched_barrier(0);
     constexpr int H = P >> 1;
@@ -2771,6 +2831,24 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   auto pair = [&](auto LL, const int n_left, const int blk, const bool first) __attribute__((always_inline)) {
     constexpr int LOW = decltype(LL)::value;
     const bool t1 = n_left > 1, t2 = n_left > 2, t3 = n_left > 3;
+#ifdef XVEC_FUZZ_INJECT_HAZARD
+    // Self-test of the fuzzing method (`make fuzz-inject`, never the product): round 4's race put back - the scales of tile u are
+    // staged in phase (u-2, 2), into the buffer the late wave group still reads in its own phase (u-2, 2).  tools/fuzz_schedule.py
+    // must report the 1.5-pass cases of this build as differing.
+    (void)first;
+    phase(I0{}, I0{}, I0{}, LL, I0{}, t1 ? 2 : -1, 1, -1, -1, t3);
+    phase(I1{}, I0{}, I0{}, LL, I0{}, t1 ? 3 : -1, 1, (MX && !LOW) ? blk : -1, -1, t3);
+    if (t2) adv();
+    phase(I2{}, I0{}, I0{}, LL, I0{}, t2 ? 0 : -1, 0, -1, (MX2 && t2 && it >= S) ? 0 : -1, t3);
+    phase(I3{}, I0{}, I0{}, LL, I0{}, t2 ? 1 : -1, 0, -1, -1, t3);
+    if (t1) {
+      phase(I0{}, I1{}, I1{}, LL, I0{}, t2 ? 2 : -1, 0, -1, -1, t3);
+      phase(I1{}, I1{}, I1{}, LL, I0{}, t2 ? 3 : -1, 0, -1, -1, t3);
+      if (t3) adv();
+      phase(I2{}, I1{}, I1{}, LL, I0{}, t3 ? 0 : -1, 1, -1, (MX2 && t3 && it >= S) ? 1 : -1, t3);
+      phase(I3{}, I1{}, I1{}, LL, I0{}, t3 ? 1 : -1, 1, -1, -1, t3);
+    }
+#else
     phase(I0{}, I0{}, I0{}, LL, I0{}, t1 ? 2 : -1, 1, -1, (MX2 && t1 && !first && it >= S) ? 1 : -1, t3);
     phase(I1{}, I0{}, I0{}, LL, I0{}, t1 ? 3 : -1, 1, (MX && !LOW) ? blk : -1, -1, t3);
     if (t2) adv();
@@ -2783,6 +2861,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       phase(I2{}, I1{}, I1{}, LL, I0{}, t3 ? 0 : -1, 1, -1, -1, t3);
       phase(I3{}, I1{}, I1{}, LL, I0{}, t3 ? 1 : -1, 1, -1, -1, t3);
     }
+#endif
   };
 
   // The same eight phases in the steady state of the first walk (at least two more tiles of the part behind this pair): every
@@ -2880,6 +2959,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
 #ifdef XVEC_CLOCK_PROBE
     unsigned long long xp_t0 = __builtin_readcyclecounter(), xp_t1 = xp_t0;
 #endif
+    XV_FUZZ();
     if (kind == 2) {
       const int prev = bid - 8 * L;   // same lane, previous group: its first action was the store waited for here
       if (tid == 0) {
@@ -2915,6 +2995,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
     xp_t1 = __builtin_readcyclecounter();
 #endif
     // everything open_part issued has landed (and the previous epilogue's stores are out: the counter does not tell them apart)
+    XV_FUZZ();
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2969,6 +3050,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       for (t = n_hi; t < ntp; t += 2) pair(I1{}, ntp - t, 0, t == 0);
     }
     if (wn == 0) barrier();
+    XV_FUZZ();
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> the epilogue's VALU reads
     // every wave is past its last LDS read: the buffers may be refilled for the next part while this one's results go out
     const int e_kind = kind, e_m0 = m0, e_n0 = n0;
@@ -2988,6 +3070,7 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
           for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[h][p][q]), rs, tid * 16,
                                                    ((h * 4 + p) * 4 + q) * 8192, kAuxCoherent);
+      XV_FUZZ();
       __builtin_amdgcn_s_waitcnt(0x0f70);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -3486,6 +3569,7 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
   if (rb0 >= rb1 || wg >= nwg) return;
   const int n0w = cg * 512 + wave * 64;
   const bool cols_valid = n0w < n_pad;
+  XV_FUZZ_INIT();
 
   // this lane's fragment chunk of K step s: columns k' = 32 s + 8 g .. + 7  ->  frame offset off[j], element d0 (bytes from
   // the unit's first staged frame, this lane's frame fr_i included).  Beyond noff * dp the weights are zero: any finite
@@ -3644,9 +3728,11 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
       build_table(rb + 1);
     }
     __syncthreads();   // this unit's frames are in LDS; the other buffer is free
+    XV_FUZZ();
     if (rb + 1 < rb1) prefetch(rb + 1);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
+      XV_FUZZ();
       if (pending && (half == 0 || group == 0)) {
         pending = false;
         const float* par = par_all + (wave >> 1) * 384;
@@ -3726,6 +3812,7 @@ __global__ __launch_bounds__(512) void tdnn_first_kernel(const FirstArgs fa) {
           pending = true;
           pend_mbase = fa.row0 + rb * kFirstRows;
         }
+        XV_FUZZ();
         if (rb + 1 < rb1) commit(buf ^ 1);
       }
     }
