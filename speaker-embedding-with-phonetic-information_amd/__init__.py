@@ -69,11 +69,11 @@ class Calibration(ctypes.Structure):
     _fields_ = [("chosen", ctypes.c_int32), ("checked", ctypes.c_int32), ("err_mx", ctypes.c_float), ("err_mx2", ctypes.c_float),
                 ("checked_mx", ctypes.c_int32), ("err_lite", ctypes.c_float), ("lite_mask", ctypes.c_uint64),
                 ("err_holdout", ctypes.c_float), ("checked_holdout", ctypes.c_int32), ("lite_dropped", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("tail", ctypes.c_float)]
 
     def as_dict(self):
         d = {"chosen": PRECISION_NAMES.get(self.chosen, str(self.chosen)), "checked": self.checked, "checked_mx": self.checked_mx,
-             "err_mx": self.err_mx, "err_mx2": self.err_mx2}
+             "err_mx": self.err_mx, "err_mx2": self.err_mx2, "tail": self.tail}
         if self.lite_mask:
             d["lite_mask"] = int(self.lite_mask)
             d["err_lite"] = self.err_lite

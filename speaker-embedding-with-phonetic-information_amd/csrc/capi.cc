@@ -235,7 +235,7 @@ static void FillCalibration(const xv::Engine::Calibration& c, xv_calibration* ou
   out->err_holdout = c.err_holdout;
   out->checked_holdout = c.checked_holdout;
   out->lite_dropped = c.lite_dropped;
-  out->reserved = 0;
+  out->tail = c.tail;
 }
 
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out) {

@@ -1514,9 +1514,25 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     if (before == kPrecFp16Mx2 && lite_before) SetLiteMask(lite_before);
     throw;
   }
-  // half: -1 = every chunk, 0 / 1 = the chunks at even / odd positions of the sample (selection / held-out half of the mixture)
-  auto worst = [&](const std::vector<float>& got, bool only_mx, int half) {
-    float w = 0.f;
+  // Per-chunk errors of one arithmetic over a set of sample chunks.  half: -1 = every chunk, 0 / 1 = the chunks at even / odd
+  // positions of the sample (selection / held-out half of the mixture).
+  // A configuration is ACCEPTED on a set when (a) its worst chunk there is within the tolerance and (b) the tail its error
+  // distribution projects - mean + kTailSigmas (6) standard deviations over the set - is within tol x kTailOverTol (1.15: the
+  // tools' 7.5e-5 -> 8.6e-5).  (b) is there because a job is not 64 chunks.  Measured over 32 768 distinct chunks per model
+  // (tools/tail_error.py, profiles/r05_tail_error.md): the worst chunk lies 4.6-5.9 standard deviations above the mean; the
+  // projection from the 64-chunk sample landed 1-7 % above that worst chunk for fp16mx / plain fp16mx2 and 6-10 %
+  // BELOW it for mixtures (32 confirming chunks, a selected configuration) - and a mixture of the c-vector network that sat at
+  // 6.9e-5 on its sample (mean 5.7e-5, projection 9.0e-5) reached 1.0008e-4 against the fp64 oracle on one chunk of 32 768.
+  // Hence the limit of 8.6e-5 for the projection rather than the bar itself: the 10 % it has been seen to fall short, and a
+  // job thirty times that size.  A candidate whose errors are spread too wide for its mean is turned down even when none of
+  // the sampled chunks is above the tolerance.  Sets of fewer than eight chunks: (a) only.
+  struct ErrStat {
+    float worst = 0.f, tail = 0.f;
+    int n = 0;
+  };
+  auto stat = [&](const std::vector<float>& got, bool only_mx, int half) {
+    ErrStat st;
+    double sum = 0.0, sum2 = 0.0;
     for (int i = 0; i < n; ++i) {
       if (only_mx && !runs_mx[i]) continue;
       if (half >= 0 && (i & 1) != half) continue;
@@ -1526,10 +1542,19 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
         m = std::max(m, std::fabs(ref[(size_t)i * E + k]));
       }
       const float r = m > 0.f ? d / m : (d > 0.f ? INFINITY : 0.f);
-      w = std::isnan(r) ? INFINITY : std::max(w, r);
+      st.worst = std::isnan(r) ? INFINITY : std::max(st.worst, r);
+      sum += r;
+      sum2 += (double)r * r;
+      ++st.n;
     }
-    return w;
+    st.tail = st.worst;
+    if (st.n >= 8 && std::isfinite(st.worst)) {
+      const double mean = sum / st.n, var = std::max(0.0, (sum2 - st.n * mean * mean) / (st.n - 1));
+      st.tail = std::max(st.worst, (float)(mean + kTailSigmas * std::sqrt(var)));
+    }
+    return st;
   };
+  auto accepted = [&](const ErrStat& st) { return st.worst <= tol && st.tail <= tol * kTailOverTol; };
   int n_mx = 0, n_mx_hold = 0;
   for (int i = 0; i < n; ++i) {
     n_mx += runs_mx[i] ? 1 : 0;
@@ -1537,20 +1562,23 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   }
   c.checked = n;
   c.checked_mx = n_mx;
-  c.err_mx = worst(mx, true, -1);
-  c.err_mx2 = worst(mx2, false, -1);
+  const ErrStat st_mx = stat(mx, true, -1), st_mx2 = stat(mx2, false, -1);
+  c.err_mx = st_mx.worst;
+  c.err_mx2 = st_mx2.worst;
+  c.tail_mx = st_mx.tail;
   // The lighter mode governs a whole job: it is taken only on the evidence of at least kCalibMinChunks chunks it would run
   // (the margin between the tolerance and the bar is argued for a sample of that order; one or two
   // qualifying chunks are not a measurement).  Fewer: the packed mode stays.  This is ONE hypothesis fixed in advance,
   // tested once on the whole sample - nothing is selected, so nothing has to be held out.
-  const bool mx_ok = n_mx >= kCalibMinChunks && c.err_mx <= tol;
+  const bool mx_ok = n_mx >= kCalibMinChunks && accepted(st_mx);
   c.chosen = mx_ok ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
+  c.tail = mx_ok ? st_mx.tail : (c.chosen == kPrecFp16Mx2 ? st_mx2.tail : 0.f);
   SetFastMode(c.chosen);
   // (the mixture runs fast what fp16mx runs fast - chunks of >= 300 pooled frames - and sends the shorter ones, which plain
   // fp16mx2 runs fast from 160, to the three-pass arithmetic: on a job with many of those it would lose more than it saves,
   // so it is considered only where they are at most an eighth of the sample)
   const int n_mx_fit = n_mx - n_mx_hold;
-  if (c.chosen == kPrecFp16Mx2 && n_mx_fit >= kCalibMinChunks / 2 && n_mx_hold >= kCalibMinChunks / 2 && c.err_mx2 <= tol &&
+  if (c.chosen == kPrecFp16Mx2 && n_mx_fit >= kCalibMinChunks / 2 && n_mx_hold >= kCalibMinChunks / 2 && accepted(st_mx2) &&
       (n - n_mx) * 8 <= n) {
     // Between the two: the 1.5-pass context with some of its layers in 1.25 passes - as much of the second walk taken off as the
     // tolerance allows.  What the second walk corrects (the activations' fp16 rounding) matters less the further a layer is
@@ -1571,18 +1599,19 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
       if (ok) order.push_back((int)i);
     }
     std::vector<float> got((size_t)n * E);
-    float err_all = 0.f, err_hold = 0.f;
+    float err_all = 0.f, err_hold = 0.f, tail_hold = 0.f;
     int dropped = 0;
     try {
       std::vector<double> gain(layers_.size(), 0.0);
-      const double fit_mx2 = worst(mx2, true, 0);
+      const double fit_mx2 = stat(mx2, true, 0).worst;
       const double base2 = fit_mx2 * fit_mx2;
       for (int i : order) {
         SetLiteMask(1ull << i);
         if (!lite_mask_) continue;
         ForwardHost(f.data(), offs.data(), n, got.data());
-        const double e = worst(got, true, 0);
-        if (e > tol) continue;   // not even alone
+        const ErrStat sa = stat(got, true, 0);
+        const double e = sa.worst;
+        if (!accepted(sa)) continue;   // not even alone
         const double v = std::max(e * e - base2, 1e-4 * base2 + 1e-30);
         gain[i] = (double)info_.layers[i].k_pad * info_.layers[i].n_pad / v;
       }
@@ -1597,7 +1626,7 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
         SetLiteMask(mask | (1ull << i));
         if (lite_mask_ == mask) continue;
         ForwardHost(f.data(), offs.data(), n, got.data());
-        if (worst(got, true, 0) <= tol) {
+        if (accepted(stat(got, true, 0))) {
           mask = lite_mask_;
           added.push_back(i);
         }
@@ -1606,13 +1635,15 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
       while (mask) {
         SetLiteMask(mask);
         ForwardHost(f.data(), offs.data(), n, got.data());
-        err_hold = worst(got, true, 1);
-        err_all = std::max(err_hold, worst(got, true, 0));
-        if (err_hold <= tol) break;
+        const ErrStat sh = stat(got, true, 1);
+        err_hold = sh.worst;
+        tail_hold = sh.tail;
+        err_all = std::max(err_hold, stat(got, true, 0).worst);
+        if (accepted(sh)) break;
         mask &= ~(1ull << added.back());
         added.pop_back();
         ++dropped;
-        err_hold = err_all = 0.f;
+        err_hold = err_all = tail_hold = 0.f;
       }
       SetLiteMask(mask);
     } catch (...) {
@@ -1625,6 +1656,7 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     c.err_holdout = lite_mask_ ? err_hold : 0.f;
     c.checked_holdout = n_mx_hold;
     c.lite_dropped = dropped;
+    if (lite_mask_) c.tail = tail_hold;
   }
   return c;
 }

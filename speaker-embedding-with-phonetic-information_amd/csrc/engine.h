@@ -146,8 +146,14 @@ class Engine {
     int checked_holdout = 0;  // chunks of the held-out half that kPrecFp16Mx would run fast
     float err_holdout = 0.f;  // worst error of the adopted mixture over them (0 when lite_mask == 0)
     int lite_dropped = 0;     // layers the selection half had admitted and the held-out half threw out again
+    // Projected tail of the per-chunk error: mean + kTailSigmas standard deviations over the chunks that confirmed a configuration
+    // (never below the worst of them).  A configuration is accepted only while this is within tol x kTailOverTol (Calibrate).
+    float tail = 0.f;         // of what was adopted: fp16mx / plain fp16mx2 on the whole sample, a mixture on its held-out half
+    float tail_mx = 0.f;      // of fp16mx on the chunks it runs fast, adopted or not
   };
   static constexpr int kCalibMinChunks = 16;
+  static constexpr double kTailSigmas = 6.0;
+  static constexpr float kTailOverTol = 1.15f;
   static constexpr int kMaxLanes = 4;       // XVEC_LANES is clamped to this
   static constexpr int kMaxLiteLayers = 64; // lite_mask is a uint64: only layers with index < 64 can be "lite" (SetLiteMask drops the rest)
   bool can_switch_fast_mode() const { return info_.precision == kPrecFp16Mx2 && !frame_mode_; }

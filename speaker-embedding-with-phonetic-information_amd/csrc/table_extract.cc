@@ -101,6 +101,9 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
         << " held-out chunks)";
     }
     if (c.lite_dropped) m << "; " << c.lite_dropped << " layer(s) admitted by the selection half failed the held-out half and were taken out again";
+    if (c.tail > 0.f) m << "; projected tail of what runs (mean + 6 sd of the per-chunk error) " << c.tail;
+    if (c.chosen != kPrecFp16Mx && c.err_mx <= opt.calibrate_tol && c.checked_mx >= Engine::kCalibMinChunks)
+      m << "; fp16mx was within the tolerance on every sampled chunk but projects a tail of " << c.tail_mx << " and was turned down";
   }
   log("LOG", m.str());
   return c;

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""How far out does the error of the calibrated default go on MANY chunks?  (GPU box.)
+
+The default arithmetic is chosen on 64 chunks (32 choose, 32 confirm) at a tolerance of 7.5e-5 against the three-pass
+arithmetic; the full-batch parity tests assert the worst of 256 chunks against the fp64 oracle below 1e-4.  BASELINE config 4
+is a million utterances: this tool measures the distribution of the per-chunk error over N distinct chunks (default 32768)
+so that the tail is a measurement instead of an extrapolation.  Reference = the fp16x3 context of the same model on the same
+chunks (its own error against the fp64 oracle is 5-7e-6 - tests/test_gpu_full_batch_parity.py - i.e. the figures below are good
+to about a tenth of the tolerance; the oracle itself takes ~0.15 s per chunk and is used for a spot check of the worst chunks).
+
+usage: tail_error.py [N] [--models v2,v2t11,v2t12,v5,v5t11] [--oracle K]   (K worst chunks re-checked against the fp64 oracle)
+One JSON line per model: what the calibration chose, mean / percentiles / worst of the per-chunk relative error (max |d| over
+max |ref| of the embedding, the measure of every parity test), how many chunks lie above 9e-5 and above 1e-4."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+
+MODELS = {"v2": ("v2_xvector", None), "v2t11": ("v2_xvector", 11), "v2t12": ("v2_xvector", 12), "v5": ("v5_cvector", None),
+          "v5t11": ("v5_cvector", 11)}
+
+
+def main():
+    args = sys.argv[1:]
+    N = int(args[0]) if args and not args[0].startswith("--") else 32768
+    names = args[args.index("--models") + 1].split(",") if "--models" in args else list(MODELS)
+    n_oracle = int(args[args.index("--oracle") + 1]) if "--oracle" in args else 4
+    tol = float(args[args.index("--tol") + 1]) if "--tol" in args else 7.5e-5
+    P = H.pkg()
+    T, B = 400, 256
+    for name in names:
+        topo, seed = MODELS[name]
+        net, line = H.synth_model(topo) if seed is None else H.trained_like_model(topo, seed)
+        model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+        ctx = P.Context(model)                                   # XV_PREC_DEFAULT
+        ref_ctx = P.Context(model, precision=P.PRECISIONS["fp16x3"])
+        # the tools' sample: 64 chunks spread evenly over the whole list
+        picks = sorted({((2 * i + 1) * N) // 128 for i in range(64)})
+        sub = [H.features(700000 + k, T) for k in picks]
+        f, o = H.pack(sub)
+        cal = ctx.calibrate(f, o, tol)
+        errs = np.empty(N)
+        for b0 in range(0, N, B):
+            utts = [H.features(700000 + k, T) for k in range(b0, min(N, b0 + B))]
+            f, o = H.pack(utts)
+            got = np.asarray(ctx.forward_batch(f, o), np.float64)
+            ref = np.asarray(ref_ctx.forward_batch(f, o), np.float64)
+            errs[b0:b0 + len(utts)] = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+        worst = np.argsort(errs)[::-1][:n_oracle]
+        spot = []
+        if n_oracle:
+            n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+            n2.apply_nnet_config(line)
+            ev64 = H.xo.GraphEvaluator(n2, np.float64)
+            for k in worst:
+                u = H.features(700000 + int(k), T)
+                f, o = H.pack([u])
+                r64 = ev64.compute(u)[0]
+                g = np.asarray(ctx.forward_batch(f, o), np.float64)[0]
+                spot.append({"chunk": int(k), "vs_fp16x3": float(errs[k]), "vs_fp64_oracle": float(np.abs(g - r64).max() / np.abs(r64).max())})
+        q = lambda p: float(np.quantile(errs, p))   # noqa: E731
+        print(json.dumps({"model": name, "chunks": N, "calibration_tol": tol, "chosen": cal["chosen"], "lite_mask": cal.get("lite_mask", 0),
+                          "lite_dropped": cal.get("lite_dropped", 0), "err_sample": {k: cal[k] for k in ("err_mx", "err_mx2", "err_lite", "err_holdout", "tail") if k in cal},
+                          "mean": float(errs.mean()), "p50": q(0.5), "p99": q(0.99), "p99.9": q(0.999), "p99.99": q(0.9999),
+                          "worst": float(errs.max()), "above_9e-5": int((errs > 9e-5).sum()), "above_1e-4": int((errs > 1e-4).sum()),
+                          "worst_chunks_against_the_fp64_oracle": spot}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
