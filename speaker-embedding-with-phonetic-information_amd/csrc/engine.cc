@@ -1571,7 +1571,10 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   // qualifying chunks are not a measurement).  Fewer: the packed mode stays.  This is ONE hypothesis fixed in advance,
   // tested once on the whole sample - nothing is selected, so nothing has to be held out.
   const bool mx_ok = n_mx >= kCalibMinChunks && accepted(st_mx);
-  c.chosen = mx_ok ? (int)kPrecFp16Mx : (c.err_mx2 <= 1e-4f ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
+  // (the packed 1.5-pass mode is left only for the three-pass one, at half the speed: it goes when a sampled chunk or the projected
+  // tail is over the BAR itself - on the heavy-tailed c-vector model with chunks of 175-600 frames it projects 8.9e-5 and its worst
+  // of 32 768 chunks is 8.8e-5)
+  c.chosen = mx_ok ? (int)kPrecFp16Mx : ((c.err_mx2 <= 1e-4f && st_mx2.tail <= 1e-4f) ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
   c.tail = mx_ok ? st_mx.tail : (c.chosen == kPrecFp16Mx2 ? st_mx2.tail : 0.f);
   SetFastMode(c.chosen);
   // (the mixture runs fast what fp16mx runs fast - chunks of >= 300 pooled frames - and sends the shorter ones, which plain

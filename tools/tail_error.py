@@ -8,7 +8,9 @@ so that the tail is a measurement instead of an extrapolation.  Reference = the 
 chunks (its own error against the fp64 oracle is 5-7e-6 - tests/test_gpu_full_batch_parity.py - i.e. the figures below are good
 to about a tenth of the tolerance; the oracle itself takes ~0.15 s per chunk and is used for a spot check of the worst chunks).
 
-usage: tail_error.py [N] [--models v2,v2t11,v2t12,v5,v5t11] [--oracle K]   (K worst chunks re-checked against the fp64 oracle)
+usage: tail_error.py [N] [--models v2,v2t11,v2t12,v5,v5t11] [--oracle K] [--frames LO-HI] [--tol T]
+       (K worst chunks re-checked against the fp64 oracle; --frames: chunk lengths uniform over LO..HI instead of 400 - the fast
+       arithmetics take chunks from 160 (fp16mx2) / 300 (fp16mx, mixtures) pooled frames, shorter ones run three-pass)
 One JSON line per model: what the calibration chose, mean / percentiles / worst of the per-chunk relative error (max |d| over
 max |ref| of the embedding, the measure of every parity test), how many chunks lie above 9e-5 and above 1e-4."""
 import json
@@ -33,7 +35,9 @@ def main():
     n_oracle = int(args[args.index("--oracle") + 1]) if "--oracle" in args else 4
     tol = float(args[args.index("--tol") + 1]) if "--tol" in args else 7.5e-5
     P = H.pkg()
-    T, B = 400, 256
+    B = 256
+    lo, hi = (int(v) for v in args[args.index("--frames") + 1].split("-")) if "--frames" in args else (400, 400)
+    lens = np.random.default_rng(99).integers(lo, hi + 1, N)
     for name in names:
         topo, seed = MODELS[name]
         net, line = H.synth_model(topo) if seed is None else H.trained_like_model(topo, seed)
@@ -42,12 +46,12 @@ def main():
         ref_ctx = P.Context(model, precision=P.PRECISIONS["fp16x3"])
         # the tools' sample: 64 chunks spread evenly over the whole list
         picks = sorted({((2 * i + 1) * N) // 128 for i in range(64)})
-        sub = [H.features(700000 + k, T) for k in picks]
+        sub = [H.features(700000 + k, int(lens[k])) for k in picks]
         f, o = H.pack(sub)
         cal = ctx.calibrate(f, o, tol)
         errs = np.empty(N)
         for b0 in range(0, N, B):
-            utts = [H.features(700000 + k, T) for k in range(b0, min(N, b0 + B))]
+            utts = [H.features(700000 + k, int(lens[k])) for k in range(b0, min(N, b0 + B))]
             f, o = H.pack(utts)
             got = np.asarray(ctx.forward_batch(f, o), np.float64)
             ref = np.asarray(ref_ctx.forward_batch(f, o), np.float64)
@@ -59,13 +63,13 @@ def main():
             n2.apply_nnet_config(line)
             ev64 = H.xo.GraphEvaluator(n2, np.float64)
             for k in worst:
-                u = H.features(700000 + int(k), T)
+                u = H.features(700000 + int(k), int(lens[k]))
                 f, o = H.pack([u])
                 r64 = ev64.compute(u)[0]
                 g = np.asarray(ctx.forward_batch(f, o), np.float64)[0]
-                spot.append({"chunk": int(k), "vs_fp16x3": float(errs[k]), "vs_fp64_oracle": float(np.abs(g - r64).max() / np.abs(r64).max())})
+                spot.append({"chunk": int(k), "frames": int(lens[k]), "vs_fp16x3": float(errs[k]), "vs_fp64_oracle": float(np.abs(g - r64).max() / np.abs(r64).max())})
         q = lambda p: float(np.quantile(errs, p))   # noqa: E731
-        print(json.dumps({"model": name, "chunks": N, "calibration_tol": tol, "chosen": cal["chosen"], "lite_mask": cal.get("lite_mask", 0),
+        print(json.dumps({"model": name, "chunks": N, "frames": [lo, hi], "calibration_tol": tol, "chosen": cal["chosen"], "lite_mask": cal.get("lite_mask", 0),
                           "lite_dropped": cal.get("lite_dropped", 0), "err_sample": {k: cal[k] for k in ("err_mx", "err_mx2", "err_lite", "err_holdout", "tail") if k in cal},
                           "mean": float(errs.mean()), "p50": q(0.5), "p99": q(0.99), "p99.9": q(0.999), "p99.99": q(0.9999),
                           "worst": float(errs.max()), "above_9e-5": int((errs > 9e-5).sum()), "above_1e-4": int((errs > 1e-4).sum()),
