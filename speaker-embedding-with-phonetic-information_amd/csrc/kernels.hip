@@ -2368,6 +2368,12 @@ __device__ unsigned long long g_clock_probe[3 * 512 * 2];
 // [slot][workgroup][0: exchange store (issue -> vmcnt(0) + barrier), 1: flag wait + exchange loads issued, 2: drain at the start of the
 // head part (the loads landing), 3: the epilogue of the workgroup's last whole-tile part] in shader cycles, wave 0
 __device__ unsigned long long g_exchange_probe[3 * 512 * 4];
+// [slot][workgroup][0: cycles wave 0 spent in the wait + barrier that opens its whole-tile parts (the DMA of the part's first tiles
+// landing AND the previous epilogue's stores draining: the counter does not tell them apart), summed over the launch, 1: such parts]
+__device__ unsigned long long g_part_probe[3 * 512 * 2];
+extern "C" int xvec_part_probe_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_part_probe), sizeof(g_part_probe), 0, hipMemcpyDeviceToHost);
+}
 extern "C" int xvec_clock_probe_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), sizeof(g_clock_probe), 0, hipMemcpyDeviceToHost);
 }
@@ -2954,6 +2960,9 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
   };
 
   open_part(0);
+#ifdef XVEC_CLOCK_PROBE
+  unsigned long long pp_sum = 0, pp_n = 0;
+#endif
 #pragma nounroll
   for (int part = 0; part < n_parts; ++part) {
 #ifdef XVEC_CLOCK_PROBE
@@ -3005,6 +3014,10 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
       const int slot = EPI == kEpiStats ? 2 : (S > 8 ? 1 : 0);
       g_exchange_probe[(slot * 512 + bid) * 4 + 1] = xp_t1 - xp_t0;
       g_exchange_probe[(slot * 512 + bid) * 4 + 2] = __builtin_readcyclecounter() - xp_t1;
+    }
+    if (kind == 0 && part > 0) {   // (part 0 has no epilogue in front of it)
+      pp_sum += __builtin_readcyclecounter() - xp_t1;
+      ++pp_n;
     }
 #endif
     c0 = c1 = c2 = c3 = 0;
@@ -3095,6 +3108,8 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_p8(const GemmArgs a) {
 #ifdef XVEC_CLOCK_PROBE
   if (tid == 0 && bid < 512) {
     const int slot = EPI == kEpiStats ? 2 : (S > 8 ? 1 : 0);
+    g_part_probe[(slot * 512 + bid) * 2] = pp_sum;
+    g_part_probe[(slot * 512 + bid) * 2 + 1] = pp_n;
     g_clock_probe[(slot * 512 + bid) * 2] = __builtin_readcyclecounter() - clk_t0;
     g_clock_probe[(slot * 512 + bid) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
   }

@@ -78,3 +78,17 @@ if hasattr(L, "xvec_exchange_probe_read"):
             if v.size:
                 parts.append("%s %.0f k = %.1f us (%d wgs)" % (what, v.mean() / 1e3, v.mean() / ghz / 1e3, v.size))
         print("  %-20s %s" % (name, "; ".join(parts)))
+
+if hasattr(L, "xvec_part_probe_read"):
+    pb = (ctypes.c_ulonglong * (3 * 512 * 2))()
+    assert L.xvec_part_probe_read(pb) == 0
+    pp = np.frombuffer(pb, dtype=np.uint64).reshape(3, 512, 2).astype(np.float64)
+    print("wait + barrier that opens a whole-tile part behind an epilogue (DMA of its first tiles landing + the epilogue's stores draining), wave 0:")
+    for slot, name in enumerate(("tdnn4", "tdnn2 / tdnn3", "tdnn5 (statistics)")):
+        ghz = (a[slot, :, 0] / np.maximum(a[slot, :, 1], 1) * 0.1)
+        ghz = float(ghz[a[slot, :, 1] > 0].mean()) if (a[slot, :, 1] > 0).any() else 2.0
+        ok = pp[slot, :, 1] > 0
+        if ok.any():
+            per = pp[slot, ok, 0] / pp[slot, ok, 1]
+            print("  %-20s %.0f cycles = %.2f us per part (%.1f such parts per workgroup; %.1f us per workgroup and launch)"
+                  % (name, per.mean(), per.mean() / ghz / 1e3, pp[slot, ok, 1].mean(), pp[slot, ok, 0].mean() / ghz / 1e3))
