@@ -38,7 +38,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def child(out, topo, prec, lite, n, T, ragged, repeats):
     import helpers as H
     P = H.pkg()
-    net, line = H.synth_model(topo)
+    if ":" in topo:   # "config:node" - a frame-level output (nnet3-compute: senone log-posteriors, bottleneck features)
+        cfg, node = topo.split(":")
+        net = H.nm.synthesize([H.config_text(cfg)], seed=11, head_stddev=1.0)
+        line = "output-node name=output input=%s" % node
+    else:
+        net, line = H.synth_model(topo)
     model = P.Model(raw=net.to_bytes(True), nnet_config=line)
     ctx = P.Context(model, precision=P.PRECISIONS[prec])
     if lite:
@@ -128,6 +133,24 @@ def main():
                     cases += 1
                     report.append(row)
                     print(json.dumps(row), flush=True)
+    # frame-level outputs (config 5's senone head, the phonetic bottleneck): three-pass and single-pass fp16, fewer and shorter chunks
+    # (one output row per frame: 3856 log-posteriors each)
+    if "--no-forward" not in args and "--smoke" not in args:
+        for topo in (["v3_multitask:output_am.log-softmax"] if quick else ["v3_multitask:output_am.log-softmax", "am:tdnn5.batchnorm"]):
+            for prec in ("fp16x3", "fp16"):
+                for fam, env in families:
+                    for n, T, ragged in ((48, 400, 1), (3, 137, 0)):
+                        a = [topo, prec, 0, n, T, ragged]
+                        ref = run_child(None, env, a + [1], os.path.join(tmp, "ref.npy"))[0]
+                        got = run_child(lib, env, a + [repeats], os.path.join(tmp, "fuzz.npy"))
+                        diff = [int(np.sum(g.view(np.uint32) != ref.view(np.uint32))) for g in got]
+                        row = {"topology": topo, "mode": prec, "kernels": fam, "shape": [n, T, ragged],
+                               "fuzz_differing_launches": sum(1 for d in diff if d), "fuzz_differing_values_max": max(diff)}
+                        launches += repeats
+                        bad += row["fuzz_differing_launches"]
+                        cases += 1
+                        report.append(row)
+                        print(json.dumps(row), flush=True)
     print(json.dumps({"cases": cases, "fuzzed_forward_passes": launches, "passes_that_differ_from_the_product_build": bad,
                       "kernel_launch_tests_on_the_fuzz_build": kt.get("fuzz", {}).get("summary"),
                       "kernel_launch_tests_with_the_race_put_back": kt.get("inject", {}).get("summary")}))
