@@ -341,6 +341,26 @@ def test_cli_several_engines_threaded_consumers_write_the_one_engine_archive(tmp
         done = lambda r: [l for l in r.stderr.splitlines() if "Done " in l][-1]   # noqa: E731
         assert done(r0).split("Done")[-1] == done(r1).split("Done")[-1], (done(r0), done(r1))
         assert "bad_dim" in r1.stderr
+    # the device front-end (sliding CMN + voiced-frame selection, the two pipe stages of extract_xvectors_new.sh:79) and the speaker-
+    # level back-end under the consumer threads: the VAD table is shared by them (one reader, locked), an utterance without voiced
+    # frames and one without a VAD entry fail in the consumer that meets them
+    from oracle import frontend as fe
+    vads = [(k, fe.synthetic_vad(i, x.shape[0])) for i, (k, x) in enumerate(allu) if x.shape[0] > 0 and k not in ("bad_dim", "utt007")]
+    vads[3] = (vads[3][0], np.zeros_like(vads[3][1]))
+    kio.write_ark_vectors(str(tmp_path / "vad.ark"), vads, scp_path=str(tmp_path / "vad.scp"))
+    rng = np.random.default_rng(3)
+    with open(tmp_path / "mean.vec", "wb") as f:
+        f.write(b"\0B")
+        kio.write_vector(f, rng.standard_normal(512).astype(np.float32) * 0.1)
+    fe_args = ["--cmn-window=300", "--vad-rspecifier=scp:%s/vad.scp" % tmp_path, "--backend-mean=%s/mean.vec" % tmp_path,
+               "--backend-normalize-length=true"]
+    q0 = _cli(tmp_path, "fe_one", fe_args)
+    assert q0.returncode == 0, q0.stderr[-2000:]
+    q1 = _cli(tmp_path, "fe_three", fe_args, env={"XVEC_ENGINES_ON_ONE_DEVICE": "3"})
+    assert q1.returncode == 0 and "3 engines on device" in q1.stderr, q1.stderr[-2000:]
+    assert (tmp_path / "fe_three.ark").read_bytes() == (tmp_path / "fe_one.ark").read_bytes()
+    assert done(q0).split("Done")[-1] == done(q1).split("Done")[-1], (done(q0), done(q1))
+    assert "No VAD input found for utterance utt007" in q1.stderr and "voiced" in q1.stderr
     # a damaged archive is fatal in the threaded path too: non-zero exit, no hang, what was written before is intact vectors
     blob = (tmp_path / "feats.ark").read_bytes()
     (tmp_path / "cut.ark").write_bytes(blob[:len(blob) // 2 + 7])
