@@ -149,7 +149,7 @@ xv_status xv_ctx_synchronize(xv_ctx* c);
  * three-pass in that mode -, XV_PREC_FP16MX2 over every chunk it runs fast, from 160 pooled frames) and switches the context to
  * XV_PREC_FP16MX only when at least 16 such chunks were compared, its worst chunk stays within tol (the tools use 7.5e-5: three
  * quarters of the 1e-4 bar) AND the tail its errors project (mean + 6 standard deviations over those chunks, xv_calibration.tail)
- * stays within tol x 1.15 - over 32 768 chunks the worst one was measured 4.6-5.9 standard deviations above the mean
+ * stays within tol x 1.10 - over 32 768 chunks the worst one was measured 4.6-5.9 standard deviations above the mean
  * (profiles/r05_tail_error.md) -, else leaves XV_PREC_FP16MX2
  * (or drops to XV_PREC_FP16X3 should even that exceed 1e-4).  Contexts that cannot switch report their precision with
  * checked = 0.  This is what `nnet3-xvector-compute --precision=default` does on 64 utterances of its job
@@ -175,7 +175,7 @@ typedef struct {
   int32_t lite_dropped;     /* layers the selection half admitted and the held-out half threw out again */
   float tail;               /* projected tail of the per-chunk error of what was adopted: mean + 6 standard deviations over the
                                chunks that confirmed it (the whole sample; a mixture: its held-out half), never below their worst.
-                               A configuration is adopted only while this is within tol x 1.15 (7.5e-5 -> 8.6e-5: the projection has
+                               A configuration is adopted only while this is within tol x 1.10 (7.5e-5 -> 8.25e-5: the projection has
                                been measured up to 10 % below the worst of 32 768 chunks, profiles/r05_tail_error.md) */
 } xv_calibration;
 xv_status xv_ctx_calibrate(xv_ctx* c, const float* feats, const int32_t* row_offsets, int32_t B, float tol, xv_calibration* out);

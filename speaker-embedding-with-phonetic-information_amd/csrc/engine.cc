@@ -1517,14 +1517,15 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   // Per-chunk errors of one arithmetic over a set of sample chunks.  half: -1 = every chunk, 0 / 1 = the chunks at even / odd
   // positions of the sample (selection / held-out half of the mixture).
   // A configuration is ACCEPTED on a set when (a) its worst chunk there is within the tolerance and (b) the tail its error
-  // distribution projects - mean + kTailSigmas (6) standard deviations over the set - is within tol x kTailOverTol (1.15: the
-  // tools' 7.5e-5 -> 8.6e-5).  (b) is there because a job is not 64 chunks.  Measured over 32 768 distinct chunks per model
+  // distribution projects - mean + kTailSigmas (6) standard deviations over the set - is within tol x kTailOverTol (1.10: the
+  // tools' 7.5e-5 -> 8.25e-5).  (b) is there because a job is not 64 chunks.  Measured over 32 768 distinct chunks per model
   // (tools/tail_error.py, profiles/r05_tail_error.md): the worst chunk lies 4.6-5.9 standard deviations above the mean; the
   // projection from the 64-chunk sample landed 1-7 % above that worst chunk for fp16mx / plain fp16mx2 and 6-10 %
   // BELOW it for mixtures (32 confirming chunks, a selected configuration) - and a mixture of the c-vector network that sat at
   // 6.9e-5 on its sample (mean 5.7e-5, projection 9.0e-5) reached 1.0008e-4 against the fp64 oracle on one chunk of 32 768.
-  // Hence the limit of 8.6e-5 for the projection rather than the bar itself: the 10 % it has been seen to fall short, and a
-  // job thirty times that size.  A candidate whose errors are spread too wide for its mean is turned down even when none of
+  // Hence a limit of 8.25e-5 for the projection rather than the bar itself: the 10 % it has been seen to fall short, and a
+  // job thirty times that size.  (At 1.15 x one of twenty-one models - fp16mx accepted with a projection of 8.62e-5 - reached
+  // 9.4e-5 in 8192 chunks; at 1.10 x the worst chunk of all of them is 8.5e-5.)  A candidate whose errors are spread too wide for its mean is turned down even when none of
   // the sampled chunks is above the tolerance.  Sets of fewer than eight chunks: (a) only.
   struct ErrStat {
     float worst = 0.f, tail = 0.f;
@@ -1554,7 +1555,11 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     }
     return st;
   };
-  auto accepted = [&](const ErrStat& st) { return st.worst <= tol && st.tail <= tol * kTailOverTol; };
+  // (XVEC_TAIL_OVER_TOL: diagnostic override of the factor, for studies like tools/tail_error.py)
+  float tail_over_tol = kTailOverTol;
+  if (const char* e = getenv("XVEC_TAIL_OVER_TOL"))
+    if (*e && atof(e) >= 1.0) tail_over_tol = (float)atof(e);
+  auto accepted = [&](const ErrStat& st) { return st.worst <= tol && st.tail <= tol * tail_over_tol; };
   int n_mx = 0, n_mx_hold = 0;
   for (int i = 0; i < n; ++i) {
     n_mx += runs_mx[i] ? 1 : 0;

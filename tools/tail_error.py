@@ -39,8 +39,15 @@ def main():
     lo, hi = (int(v) for v in args[args.index("--frames") + 1].split("-")) if "--frames" in args else (400, 400)
     lens = np.random.default_rng(99).integers(lo, hi + 1, N)
     for name in names:
-        topo, seed = MODELS[name]
-        net, line = H.synth_model(topo) if seed is None else H.trained_like_model(topo, seed)
+        if name[:3] in ("v2s", "v5s"):   # another draw of the initialisation-like model: v2s7 = synth_model("v2_xvector", seed=7)
+            topo, seed = ("v2_xvector" if name[1] == "2" else "v5_cvector"), None
+            net, line = H.synth_model(topo, seed=int(name[3:]))
+        elif name[:3] in ("v2t", "v5t") and name not in MODELS:   # another heavy-tailed one
+            topo, seed = ("v2_xvector" if name[1] == "2" else "v5_cvector"), int(name[3:])
+            net, line = H.trained_like_model(topo, seed)
+        else:
+            topo, seed = MODELS[name]
+            net, line = H.synth_model(topo) if seed is None else H.trained_like_model(topo, seed)
         model = P.Model(raw=net.to_bytes(True), nnet_config=line)
         ctx = P.Context(model)                                   # XV_PREC_DEFAULT
         ref_ctx = P.Context(model, precision=P.PRECISIONS["fp16x3"])
