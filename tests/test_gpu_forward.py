@@ -387,14 +387,20 @@ def test_calibration_sample_covers_the_whole_table(tmp_path):
     kio.write_ark_matrices(str(ark), head + tail)
     ctx = P.Context(model)
     fh, oh = H.pack([x for _, x in head])
-    e_head = ctx.calibrate(fh, oh, tol=1.0)["err_mx"]            # what a head-of-list sample measures
+    cal_head = ctx.calibrate(fh, oh, tol=1.0)                    # what a head-of-list sample measures
+    e_head = cal_head["err_mx"]
+    assert cal_head["chosen"] == "fp16mx" and cal_head["tail"] >= e_head
     ctx.set_fast_mode("fp16mx2")
     cal_all = ctx.calibrate_table("ark:%s" % ark, tol=1.0)       # 64 utterances spread over all 256: 16 of A, 48 of B
     e_all = cal_all["err_mx"]
     print("head %.3g  whole list %.3g" % (e_head, e_all), cal_all)
     assert cal_all["checked_mx"] == 64
     assert e_all > 1.2 * e_head, (e_head, e_all)
-    tol = float(np.sqrt(e_head * e_all))                         # a tolerance the head passes and the job does not
+    # a tolerance the head passes - on its worst chunk and on the tail its errors project (mean + 6 sd within 1.10 x the tolerance) -
+    # and the job does not
+    lo = max(e_head, cal_head["tail"] / 1.10)
+    assert lo < e_all, (lo, e_all)
+    tol = float(np.sqrt(lo * e_all))
     ctx.set_fast_mode("fp16mx2")
     assert ctx.calibrate(fh, oh, tol=tol)["chosen"] == "fp16mx"
     ctx.set_fast_mode("fp16mx2")
