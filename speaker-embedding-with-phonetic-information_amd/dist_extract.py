@@ -36,6 +36,57 @@ def shard_bounds(n, world):
     return bounds
 
 
+def shard_by_speaker(lines, utt2spk, world):
+    """The split `utils/data/split_data.sh` makes by default (`split_scp.pl --utt2spk=...`, utils/split_scp.pl:84-191; the
+    extraction script takes its per-job lists from it, extract_xvectors_new.sh:72): no speaker is cut in two.
+      * speakers in order of first appearance; speaker i of S starts in job floor(i * world / S);
+      * then, until nothing moves: for every job in turn, its LAST speaker goes to the next job, and after that its FIRST
+        speaker to the previous job, whenever that strictly reduces the difference between the two jobs' utterance counts;
+      * a job's list is its speakers in that order, each with its lines in the order of the input.
+    Returns one list of lines per job.  Errors like the reference: an utterance without a speaker, fewer speakers than jobs,
+    a job left without speakers."""
+    order, by_spk = [], {}
+    for ln in lines:
+        utt = ln.split()[0]
+        if utt not in utt2spk:
+            raise ValueError("No such utterance %s in the utt2spk file" % utt)
+        spk = utt2spk[utt]
+        if spk not in by_spk:
+            by_spk[spk] = []
+            order.append(spk)
+        by_spk[spk].append(ln)
+    n_spk = len(order)
+    if n_spk < world:
+        raise ValueError("Refusing to split data because number of speakers %d is less than the number of jobs %d" % (n_spk, world))
+    jobs = [[] for _ in range(world)]
+    count = [0] * world
+    for i, spk in enumerate(order):
+        j = (i * world) // n_spk
+        jobs[j].append(spk)
+        count[j] += len(by_spk[spk])
+    moved = True
+    while moved:
+        moved = False
+        for j in range(world):
+            if j + 1 < world and jobs[j]:
+                c = len(by_spk[jobs[j][-1]])
+                if abs((count[j + 1] + c) - (count[j] - c)) < abs(count[j + 1] - count[j]):
+                    jobs[j + 1].insert(0, jobs[j].pop())
+                    count[j + 1] += c
+                    count[j] -= c
+                    moved = True
+            if j > 0 and jobs[j]:
+                c = len(by_spk[jobs[j][0]])
+                if abs((count[j] - c) - (count[j - 1] + c)) < abs(count[j] - count[j - 1]):
+                    jobs[j - 1].append(jobs[j].pop(0))
+                    count[j - 1] += c
+                    count[j] -= c
+                    moved = True
+    if any(not spks for spks in jobs):
+        raise ValueError("a job is left without speakers (too many jobs for too few speakers)")
+    return [[ln for spk in spks for ln in by_spk[spk]] for spks in jobs]
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--nnet", required=True, help="raw nnet3 model rxfilename (file or 'command |')")
@@ -44,6 +95,9 @@ def main(argv=None):
     ap.add_argument("--feats-scp", required=True)
     ap.add_argument("--feat-pipe", default=None,
                     help="feature pipeline with the literal SCP standing for this rank's scp slice; default: scp:SCP")
+    ap.add_argument("--utt2spk", default=None,
+                    help="utt2spk file: shard like utils/data/split_data.sh does by default (split_scp.pl --utt2spk: no speaker is "
+                         "cut in two, extract_xvectors_new.sh:72) instead of into equal contiguous slices")
     ap.add_argument("--out-dir", required=True)
     ap.add_argument("--name", default="xvector")
     ap.add_argument("--chunk-size", type=int, default=-1)
@@ -131,12 +185,19 @@ def main(argv=None):
 
     # ---- this rank's contiguous slice of the utterance list -----------------------------------------------------
     lines = [l for l in open(args.feats_scp) if l.strip()]
-    lo, hi = shard_bounds(len(lines), world)[rank]
+    if args.utt2spk:
+        # every rank computes the same split from the same two files (deterministic; a bad file fails every rank alike)
+        u2s = dict(l.split()[:2] for l in open(args.utt2spk) if l.strip())
+        mine = shard_by_speaker(lines, u2s, world)[rank]
+        lo, hi = 0, len(mine)   # (positions inside `mine`: the slice is not contiguous in the list in general)
+    else:
+        lo, hi = shard_bounds(len(lines), world)[rank]
+        mine = lines[lo:hi]
     os.makedirs(args.out_dir, exist_ok=True)
     job = rank + 1
     my_scp = os.path.join(args.out_dir, "feats_%s.%d.scp" % (args.name, job))
     with open(my_scp, "w") as f:
-        f.writelines(lines[lo:hi])
+        f.writelines(mine)
     rspec = ("ark:" + args.feat_pipe.replace("SCP", my_scp)) if args.feat_pipe else ("scp:" + my_scp)
     ark = os.path.join(args.out_dir, "xvector_%s.%d.ark" % (args.name, job))
     scp = os.path.join(args.out_dir, "xvector_%s.%d.scp" % (args.name, job))
@@ -186,7 +247,7 @@ def main(argv=None):
             host = wt.cpu().numpy().tobytes()
             print("rank %d/%d: blob %d bytes sha1 %s, utterances [%d, %d)" % (rank, world, len(host),
                                                                           hashlib.sha1(host).hexdigest(), lo, hi), flush=True)
-            open(scp, "w").writelines("%s DRYRUN\n" % l.split()[0] for l in lines[lo:hi])
+            open(scp, "w").writelines("%s DRYRUN\n" % l.split()[0] for l in mine)
         elif hi > lo:
             done, failed = ctx.extract_table(rspec, "ark,scp:%s,%s" % (ark, scp), args.chunk_size, args.min_chunk_size,
                                              args.pad_input.lower() in ("true", "t", "1"))

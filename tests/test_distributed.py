@@ -94,3 +94,74 @@ def test_broadcast_watchdog_turns_a_stalled_collective_into_an_exit_status():
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
     assert "survived the cancelled one" in r.stdout and "not reached" not in r.stdout
     assert "rank 1: the broadcast of the packed weights (2 ranks, backend gloo) did not complete within" in r.stderr, r.stderr
+
+
+def _split_cases():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "split_scp", "cases.json")))
+
+
+def test_sharding_rules_against_the_reference_split_scp_goldens():
+    """tests/golden/split_scp/cases.json holds what the reference's utils/split_scp.pl did (run in the build container by
+    tests/golden/make_split_scp_goldens.py) with seeded lists: plain (:193-221 -> shard_bounds) and --utt2spk (:84-191 ->
+    shard_by_speaker, the split utils/data/split_data.sh makes by default and extract_xvectors_new.sh:72 uses), including
+    speakers that are not contiguous in the list, as many jobs as speakers, and more jobs than speakers (an error in both)."""
+    n_cases = n_err = 0
+    for c in _split_cases():
+        if "counts" in c:
+            utts = ["spk%03d-utt%03d" % (s, k) for s, n in enumerate(c["counts"]) for k in range(n)]
+            spks = ["spk%03d" % s for s, n in enumerate(c["counts"]) for k in range(n)]
+        else:
+            utts, spks = c["utts"], c["spks"]
+        lines = ["%s /feats/%s.ark:%d\n" % (u, u, 17 * i) for i, u in enumerate(utts)]
+        n_cases += 1
+        if c["by_speaker"]:
+            if c.get("error"):
+                n_err += 1
+                with pytest.raises(ValueError):
+                    D.shard_by_speaker(lines, dict(zip(utts, spks)), c["nj"])
+                continue
+            got = D.shard_by_speaker(lines, dict(zip(utts, spks)), c["nj"])
+            assert [[lines.index(l) for l in sh] for sh in got] == c["shards"], (c["nj"], c.get("counts"))
+            # no speaker in two jobs
+            owner = {}
+            for j, sh in enumerate(got):
+                for l in sh:
+                    assert owner.setdefault(spks[lines.index(l)], j) == j
+        elif not c.get("error"):
+            b = D.shard_bounds(len(lines), c["nj"])
+            assert [list(range(lo, hi)) for lo, hi in b] == c["shards"], (c["nj"], len(lines))
+    assert n_cases >= 19 and n_err >= 1
+
+
+def test_shard_by_speaker_rejects_an_utterance_without_a_speaker():
+    with pytest.raises(ValueError, match="No such utterance"):
+        D.shard_by_speaker(["a x\n", "b y\n"], {"a": "s1"}, 1)
+
+
+def test_world_size_2_gloo_dry_run_sharded_by_speaker(tmp_path):
+    """--utt2spk: the two ranks take the lists split_scp.pl --utt2spk would give jobs 1 and 2 (no speaker cut in two), and the
+    merged output list is the input list again (speakers contiguous, as in the reference's sorted data directories)."""
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    counts = [4, 1, 3, 2, 5]                      # 15 utterances: plain halves would be 8 + 7 and cut speaker 2
+    keys = ["spk%d-utt%d" % (s, k) for s, n in enumerate(counts) for k in range(n)]
+    (tmp_path / "feats.scp").write_text("".join("%s /data/feats.ark:%d\n" % (k, 100 * i) for i, k in enumerate(keys)))
+    (tmp_path / "utt2spk").write_text("".join("%s %s\n" % (k, k.split("-")[0]) for k in keys))
+    out = tmp_path / "out"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(H.ROOT, H.PKG_NAME, "dist_extract.py"),
+           "--nnet", str(tmp_path / "final.raw"), "--output-node", "tdnn6.affine", "--utt2spk", str(tmp_path / "utt2spk"),
+           "--feats-scp", str(tmp_path / "feats.scp"), "--out-dir", str(out), "--name", "t",
+           "--backend", "gloo", "--dry-run"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout
+    lines = ["%s x\n" % k for k in keys]
+    want = D.shard_by_speaker(lines, {k: k.split("-")[0] for k in keys}, 2)
+    one = [l.split()[0] for l in open(out / "feats_t.1.scp")]
+    two = [l.split()[0] for l in open(out / "feats_t.2.scp")]
+    assert one == [l.split()[0] for l in want[0]] and two == [l.split()[0] for l in want[1]]
+    assert {k.split("-")[0] for k in one}.isdisjoint({k.split("-")[0] for k in two})
+    assert (len(one), len(two)) == (8, 7) or abs(len(one) - len(two)) <= 3
+    assert [l.split()[0] for l in open(out / "xvector_t.scp")] == keys
