@@ -206,3 +206,20 @@ def test_fused_backend_options_of_the_extractor(tmp_path):
         kio.write_vector(f, mean[:100])
     r = _run(common + ["--backend-mean=%s/bad.vec" % tmp_path, str(tmp_path / "final.raw"), "ark:%s/f.ark" % tmp_path, "ark:/dev/null"])
     assert r.returncode == 255 and b"--backend-mean has dimension 100" in r.stderr
+
+
+def test_transform_vec_reads_the_text_matrix_the_reference_helpers_write(tmp_path):
+    """tests/golden/text_matrix/cases.json `object_by_reference`: what steps/libs/common.py:333-352 write_kaldi_matrix wrote for a
+    2 x 3 integer matrix ("[ 1 -2 3\\n40 5 -600 ]") is read as the transform of transform-vec: y = M x."""
+    import base64
+    import json
+    c = json.load(open(os.path.join(H.ROOT, "tests", "golden", "text_matrix", "cases.json")))
+    (tmp_path / "m.txt").write_bytes(base64.b64decode(c["object_by_reference"]))
+    M = np.array(c["matrices"][1][1], np.float32)
+    vecs = [("v%d" % i, H.features(i, 1, 3)[0]) for i in range(5)]
+    kio.write_ark_vectors(str(tmp_path / "v.ark"), vecs)
+    r = _run([os.path.join(BIN, "transform-vec"), str(tmp_path / "m.txt"), "ark:%s/v.ark" % tmp_path, "ark:%s/y.ark" % tmp_path])
+    assert r.returncode == 0, r.stderr
+    y = dict(kio.read_ark(str(tmp_path / "y.ark"), "vector"))
+    for k, v in vecs:
+        assert np.allclose(y[k], M @ v, rtol=1e-6), k

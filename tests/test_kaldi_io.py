@@ -186,3 +186,57 @@ def test_archive_through_a_pipe_is_drained_by_a_second_thread(tmp_path):
     assert _run("copy-feats", "ark:cat %s |" % txt, "ark:" + back).returncode == 0
     b = dict(kio.read_ark(back, "matrix"))
     assert len(b) == len(utts) and all(np.allclose(b[k], m, rtol=1e-5, atol=1e-6) for k, m in utts[:50])
+
+
+def _text_cases():
+    import base64
+    import json
+    c = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_matrix", "cases.json")))
+    for k in ("written_by_reference", "object_by_reference", "ours_oracle", "ours_cpp"):
+        c[k] = base64.b64decode(c[k])
+    c["matrices"] = [(k, np.array(m, np.float32)) for k, m in c["matrices"]]
+    return c
+
+
+def test_text_matrices_written_by_the_reference_helpers_are_read(tmp_path):
+    """tests/golden/text_matrix/cases.json (made by tests/golden/make_text_matrix_goldens.py from the reference's own
+    steps/libs/common.py:333-470, the one place in its tree that writes a Kaldi table): the archive text its write_matrix_ascii
+    produced ("key [" + rows of "%f" + " ]" - one space, no indentation, where Kaldi's tools write "key  [" and two-space rows)
+    is read by the oracle's reader and by the C++ one to the six decimals it carries; its write_kaldi_matrix object
+    ("[ 1 -2 3\\n40 5 -600 ]") is read as a whole-file matrix by both."""
+    c = _text_cases()
+    got = dict(kio.read_ark(io.BytesIO(c["written_by_reference"])))
+    assert list(got) == [k for k, _ in c["matrices"]]
+    for k, m in c["matrices"]:
+        assert got[k].shape == m.shape and np.abs(got[k] - m).max() <= 5.1e-7 * max(1.0, np.abs(m).max()), k
+    (tmp_path / "ref.txt").write_bytes(c["written_by_reference"])
+    r = _run("copy-feats", "ark:%s/ref.txt" % tmp_path, "ark:%s/ref.ark" % tmp_path)
+    assert r.returncode == 0, r.stderr
+    got_cpp = dict(kio.read_ark(str(tmp_path / "ref.ark")))
+    for k, m in c["matrices"]:
+        assert np.array_equal(got_cpp[k], got[k]), k          # both readers parse the same decimal strings to the same floats
+    # the whole-file object
+    M = kio.read_matrix(io.BytesIO(c["object_by_reference"]), binary=False)
+    assert np.array_equal(M, c["matrices"][1][1])
+    # (the C++ reader of whole-file objects sits behind the back-end tools, which need the GPU: tests/test_gpu_backend.py)
+
+
+def test_text_matrices_we_write_are_what_the_reference_helpers_read(tmp_path):
+    """The other direction, pinned at generation time: the bytes our two writers emit for the fixture's matrices (oracle/kaldi_io.py,
+    bin/copy-feats ark,t:) are still the recorded ones, and what the reference's read_mat_ark parsed from those bytes equals the
+    matrices (to float print precision)."""
+    c = _text_cases()
+    o = io.BytesIO()
+    for k, m in c["matrices"]:
+        o.write(k.encode() + b" ")
+        kio.write_matrix(o, m, binary=False)
+    assert o.getvalue() == c["ours_oracle"]
+    kio.write_ark_matrices(str(tmp_path / "in.ark"), c["matrices"])
+    r = _run("copy-feats", "ark:%s/in.ark" % tmp_path, "ark,t:%s/out.txt" % tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "out.txt").read_bytes() == c["ours_cpp"]
+    for name in ("reference_read_ours_oracle", "reference_read_ours_cpp"):
+        parsed = c[name]
+        assert [k for k, _ in parsed] == [k for k, _ in c["matrices"]]
+        for (k, rows), (_, m) in zip(parsed, c["matrices"]):
+            assert np.allclose(np.array(rows, np.float64), m.astype(np.float64), rtol=3e-7, atol=0), (name, k)
