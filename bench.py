@@ -571,7 +571,10 @@ def main():
                        "frames_per_chunk": T if not ragged else None, "precision": args.precision,
                        "arithmetic": arithmetic_name(ctx), "calibration": calibration, "kernel_precisions": kernel_precs,
                        "lanes": args.lanes, "alg_gflop_per_utt": 2.0 * macs / 1e9, "output_node": args.output_node or "embedding",
-                       "chunk_lengths": args.ragged or str(T), "frames_per_step": total_rows},
+                       "chunk_lengths": args.ragged or str(T), "frames_per_step": total_rows,
+                       # which build of the library ran (it names the kernel sources it was compiled from: the hash profiles/pmc_traffic.json
+                       # is stamped with)
+                       "library": P.lib().xv_version().decode()},
             "frames_per_sec": world * total_rows * args.steps / dt,
             "roofline": roofline,
             "parity_rel_err_vs_oracle_fp32": parity,          # worst chunk

@@ -82,7 +82,18 @@ xv_status LoadCommon(xv::RawNnet& net, const char* nnet_config, const char* outp
 extern "C" {
 
 const char* xv_last_error(void) { return g_err.c_str(); }
-const char* xv_version(void) { return "xvec_hip 0.4 (gfx950)"; }
+// XVEC_KERNELS_SHA: first 16 hex digits of the SHA-1 of kernels.hip + kernels.h this library was built from (Makefile; the stamp
+// tools/parse_rocprof.py puts on profiles/pmc_traffic.json): tells a stale or a differently configured build of the library from
+// the tree's (tests/test_gpu_fuzz.py compares the product and the schedule-fuzzing build with it).
+#ifndef XVEC_KERNELS_SHA
+#define XVEC_KERNELS_SHA "unknown"
+#endif
+#ifdef XVEC_SCHED_FUZZ
+#define XVEC_BUILD_KIND "; schedule-fuzzing build"
+#else
+#define XVEC_BUILD_KIND ""
+#endif
+const char* xv_version(void) { return "xvec_hip 0.4 (gfx950; kernels " XVEC_KERNELS_SHA XVEC_BUILD_KIND ")"; }
 
 xv_status xv_model_load(const void* raw, size_t n, const char* nnet_config, const char* output_node, xv_model** out) {
   if (!raw || !out) return Fail(XV_ERR_ARG, "xv_model_load: null argument");

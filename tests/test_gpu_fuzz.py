@@ -18,6 +18,17 @@ FUZZ_LIB = os.path.join(H.ROOT, H.PKG_NAME, "fuzz", "libxvec_hip.so")
 def _need_fuzz_build():
     if not os.path.exists(FUZZ_LIB):
         pytest.skip("no fuzz build (make -C %s/csrc fuzz; __graft_entry__.build() makes it)" % H.PKG_NAME)
+    # both libraries name the kernel sources they were built from (xv_version): a fuzz build of OTHER sources would compare two
+    # different kernels
+    import ctypes
+    vers = []
+    for path in (H.pkg().LIB_PATH, FUZZ_LIB):
+        L = ctypes.CDLL(path)
+        L.xv_version.restype = ctypes.c_char_p
+        vers.append(L.xv_version().decode())
+    assert "schedule-fuzzing build" in vers[1] and "schedule-fuzzing build" not in vers[0], vers
+    sha = [v.split("kernels ")[1][:16] for v in vers]
+    assert sha[0] == sha[1], "the fuzz library was built from other kernel sources than the product library: %s (make fuzz)" % vers
 
 
 def test_forward_passes_of_the_fuzz_build_are_bit_identical():
