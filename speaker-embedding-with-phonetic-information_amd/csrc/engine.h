@@ -153,7 +153,8 @@ class Engine {
   };
   static constexpr int kCalibMinChunks = 16;
   static constexpr double kTailSigmas = 6.0;
-  static constexpr float kTailOverTol = 1.10f;
+  static constexpr float kTailOverTol = 1.10f;        // fp16mx outright, mixtures
+  static constexpr float kTailOverTolPacked = 1.20f;  // plain fp16mx2 (else the three-pass arithmetic)
   static constexpr int kMaxLanes = 4;       // XVEC_LANES is clamped to this
   static constexpr int kMaxLiteLayers = 64; // lite_mask is a uint64: only layers with index < 64 can be "lite" (SetLiteMask drops the rest)
   bool can_switch_fast_mode() const { return info_.precision == kPrecFp16Mx2 && !frame_mode_; }

@@ -56,6 +56,21 @@ def main():
         sub = [H.features(700000 + k, int(lens[k])) for k in picks]
         f, o = H.pack(sub)
         cal = ctx.calibrate(f, o, tol)
+        # --project: the two plain arithmetics next to what was adopted, each with two projections of its tail from the SAMPLE's
+        # per-chunk errors - linear (mean + 6 sd, the rule of Engine::Calibrate) and log-normal (exp(mean + 6 sd of the logarithms)) -
+        # to be held against the worst of the N chunks
+        extra = {}
+        if "--project" in args:
+            ref_s = np.asarray(ref_ctx.forward_batch(f, o), np.float64)
+            modes = {"adopted": ctx}
+            for m in ("fp16mx", "fp16mx2"):
+                modes[m] = P.Context(model, precision=P.PRECISIONS[m])
+            for m, c2 in modes.items():
+                g = np.asarray(c2.forward_batch(f, o), np.float64)
+                e = np.abs(g - ref_s).max(axis=1) / np.abs(ref_s).max(axis=1)
+                le = np.log(np.maximum(e, 1e-12))
+                extra[m] = {"ctx": c2, "sample_worst": float(e.max()), "lin6": float(e.mean() + 6 * e.std(ddof=1)),
+                            "log6": float(np.exp(le.mean() + 6 * le.std(ddof=1))), "errs": np.empty(N)}
         errs = np.empty(N)
         for b0 in range(0, N, B):
             utts = [H.features(700000 + k, int(lens[k])) for k in range(b0, min(N, b0 + B))]
@@ -63,6 +78,10 @@ def main():
             got = np.asarray(ctx.forward_batch(f, o), np.float64)
             ref = np.asarray(ref_ctx.forward_batch(f, o), np.float64)
             errs[b0:b0 + len(utts)] = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+            for m, x in extra.items():
+                if m != "adopted":
+                    g = np.asarray(x["ctx"].forward_batch(f, o), np.float64)
+                    x["errs"][b0:b0 + len(utts)] = np.abs(g - ref).max(axis=1) / np.abs(ref).max(axis=1)
         worst = np.argsort(errs)[::-1][:n_oracle]
         spot = []
         if n_oracle:
@@ -75,12 +94,17 @@ def main():
                 r64 = ev64.compute(u)[0]
                 g = np.asarray(ctx.forward_batch(f, o), np.float64)[0]
                 spot.append({"chunk": int(k), "frames": int(lens[k]), "vs_fp16x3": float(errs[k]), "vs_fp64_oracle": float(np.abs(g - r64).max() / np.abs(r64).max())})
+        proj = {}
+        for m, x in extra.items():
+            e = errs if m == "adopted" else x["errs"]
+            proj[m] = {"sample_worst": x["sample_worst"], "lin6": x["lin6"], "log6": x["log6"], "worst": float(e.max()), "mean": float(e.mean()),
+                       "p99.9": float(np.quantile(e, 0.999))}
         q = lambda p: float(np.quantile(errs, p))   # noqa: E731
         print(json.dumps({"model": name, "chunks": N, "frames": [lo, hi], "calibration_tol": tol, "chosen": cal["chosen"], "lite_mask": cal.get("lite_mask", 0),
                           "lite_dropped": cal.get("lite_dropped", 0), "err_sample": {k: cal[k] for k in ("err_mx", "err_mx2", "err_lite", "err_holdout", "tail") if k in cal},
                           "mean": float(errs.mean()), "p50": q(0.5), "p99": q(0.99), "p99.9": q(0.999), "p99.99": q(0.9999),
                           "worst": float(errs.max()), "above_9e-5": int((errs > 9e-5).sum()), "above_1e-4": int((errs > 1e-4).sum()),
-                          "worst_chunks_against_the_fp64_oracle": spot}), flush=True)
+                          "worst_chunks_against_the_fp64_oracle": spot, **({"projections": proj} if proj else {})}), flush=True)
 
 
 if __name__ == "__main__":
