@@ -1579,7 +1579,7 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   // (the packed 1.5-pass mode is left only for the three-pass one, at half the speed: it goes when a sampled chunk or the projected
   // tail is too close to the BAR - on the heavy-tailed c-vector model with chunks of 175-600 frames it projects 8.9e-5 and its worst
   // of 32 768 chunks is 8.8e-5)
-  // (the projection has been seen up to 16 % below the worst of 32 768 chunks - profiles/r05_tail_error.md, 42 configurations - so
+  // (the projection has been seen up to 16 % below the worst of 32 768 chunks - profiles/r05_tail_error.md, 33 configurations - so
   // the limit for staying in the packed mode is tol x kTailOverTolPacked = 9e-5, not the bar)
   c.chosen = mx_ok ? (int)kPrecFp16Mx
                    : ((c.err_mx2 <= 1e-4f && st_mx2.tail <= tol * kTailOverTolPacked) ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3);
