@@ -151,7 +151,7 @@ xv_status xv_ctx_synchronize(xv_ctx* c);
  * quarters of the 1e-4 bar) AND the tail its errors project (mean + 6 standard deviations over those chunks, xv_calibration.tail)
  * stays within tol x 1.10 - over 32 768 chunks the worst one was measured 4.6-5.9 standard deviations above the mean
  * (profiles/r05_tail_error.md) -, else leaves XV_PREC_FP16MX2
- * (or drops to XV_PREC_FP16X3 should even that exceed 1e-4).  Contexts that cannot switch report their precision with
+ * (or drops to XV_PREC_FP16X3 should even that exceed 1e-4 on a sampled chunk, or project a tail beyond tol x 1.20).  Contexts that cannot switch report their precision with
  * checked = 0.  This is what `nnet3-xvector-compute --precision=default` does on 64 utterances of its job
  * (no reference counterpart: Kaldi computes in fp32 throughout).  xv_ctx_set_fast_mode applies a choice made elsewhere
  * (the other ranks of a multi-GPU job); xv_calibrate_table calibrates on max_utts utterances of a table: spread evenly
