@@ -241,8 +241,10 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           // WITHOUT time offsets: on those the kernel beats tdnn_gemm_kernel_sk in this arithmetic, on the spliced ones it loses
           // (kernels.h kP8Mx2Built).  A property of the layer: every 1.5-pass launch of the layer runs the same kernel.
           bool lo64 = kP8Mx2Built && b.w4p != kNone;
+          // (XVEC_P8_MX2_SPLICED=1: measurement knob - the spliced layers on that kernel as well)
+          static const bool spliced_too = getenv("XVEC_P8_MX2_SPLICED") && atoi(getenv("XVEC_P8_MX2_SPLICED")) == 1;
           for (int j = 0; j < b.nsrc; ++j)
-            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256 || b.src_offset[j] != 0) lo64 = false;
+            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256 || (b.src_offset[j] != 0 && !spliced_too)) lo64 = false;
           if (lo64) {
             b.w4bp = cur;
             cur = Align256(cur + (uint64_t)b.n_pad * b.k_pad * 2);
