@@ -152,8 +152,10 @@ xv_status xv_ctx_synchronize(xv_ctx* c);
  * stays within tol x 1.10 - over 32 768 chunks the worst one was measured 4.6-5.9 standard deviations above the mean
  * (profiles/r05_tail_error.md) -, else leaves XV_PREC_FP16MX2
  * (or drops to XV_PREC_FP16X3 should even that exceed 1e-4 on a sampled chunk, or project a tail beyond tol x 1.20).  Contexts that cannot switch report their precision with
- * checked = 0.  This is what `nnet3-xvector-compute --precision=default` does on 64 utterances of its job
- * (no reference counterpart: Kaldi computes in fp32 throughout).  xv_ctx_set_fast_mode applies a choice made elsewhere
+ * checked = 0.  (No reference counterpart: Kaldi computes in fp32 throughout.)  A measured choice depends on the sample it was
+ * measured on, so the command-line tools never make one per job by default - `--precision=default` is plain XV_PREC_FP16MX2, a
+ * function of the model alone - and use a measured choice only when it is SHARED between the jobs of a recipe through a
+ * calibration file (xv_ctx_share_calibration below; `--calibration=<file>` / $XVEC_CALIBRATION).  xv_ctx_set_fast_mode applies a choice made elsewhere
  * (the other ranks of a multi-GPU job); xv_calibrate_table calibrates on max_utts utterances of a table: spread evenly
  * over the whole list where its objects can be addressed (archive file, script file - the reference's lists are sorted
  * by speaker, utils/data/split_data.sh:18-21, so the head of a list is one or two speakers), the head of a stream. */
@@ -191,6 +193,28 @@ xv_status xv_calibrate_table(xv_ctx* c, const char* feature_rspecifier, int32_t 
                              int32_t pad_input, int32_t max_utts, float tol, xv_calibration* out);
 /* xv_extract_table calibrates on a sample of its own table first (as xv_calibrate_table) when this is enabled (default: off) */
 xv_status xv_ctx_set_calibration(xv_ctx* c, int32_t enable, float tol);
+/* ---- the shared choice of a recipe (csrc/calib_file.h) -------------------------------------------------------------------
+ * The reference splits a list over `nj` independent processes and concatenates their outputs
+ * (egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:72,91-99); an utterance gets the same vector in whatever shard it lands.
+ * For that to hold here, a MEASURED choice of arithmetic must be one choice for all jobs: a small text file beside the model
+ * ("xvec-calibration 1", the fingerprint of the packed model image, the arithmetic, the mask of lite layers, provenance).
+ * xv_ctx_model_fingerprint: the fingerprint of the context's packed image (part of the image header, so a context built from a
+ * broadcast image knows it too).  xv_ctx_share_calibration: the file exists -> its choice is applied to the context
+ * (*outcome = 0; XV_ERR_IO when it names another model image or cannot be parsed); it does not -> the context's CURRENT choice
+ * (after xv_ctx_calibrate / xv_calibrate_table, or the packed default) is published atomically (temporary file + link(2): the
+ * first of several concurrent publishers wins) and what the file then holds is applied: *outcome = 1 when this context's
+ * choice was published, 2 when another job's was adopted.  note: one line of provenance written into the file (may be NULL).
+ * xv_ctx_set_calibration_file: xv_extract_table does the same before its first batch (file present: applied, nothing measured;
+ * absent: measured on the job's own sample, published, adopted).  NULL / "" turns it off.
+ * xv_calibration_file_read / _publish: the file itself, without a context (no device call): read reports *found = 0 for a
+ * missing file; publish writes (model, precision, lite_mask) unless the file exists and reports what the file then holds. */
+xv_status xv_calibration_file_read(const char* path, int32_t* found, uint64_t* model, int32_t* precision, uint64_t* lite_mask);
+xv_status xv_calibration_file_publish(const char* path, uint64_t model, int32_t precision, uint64_t lite_mask, float tol,
+                                      const char* note, int32_t* published, uint64_t* adopted_model, int32_t* adopted_precision,
+                                      uint64_t* adopted_lite_mask);
+xv_status xv_ctx_model_fingerprint(const xv_ctx* c, uint64_t* fingerprint);
+xv_status xv_ctx_share_calibration(xv_ctx* c, const char* path, float tol, const char* note, int32_t* outcome);
+xv_status xv_ctx_set_calibration_file(xv_ctx* c, const char* path);
 
 xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable);
 size_t xv_ctx_profile_report(xv_ctx* c, char* buf, size_t n);

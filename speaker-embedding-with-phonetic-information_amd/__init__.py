@@ -91,7 +91,8 @@ ABI_SYMBOLS = [
     "xv_ctx_create_from_device_blob", "xv_ctx_free",
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances", "xv_ctx_calibrate", "xv_ctx_set_fast_mode", "xv_ctx_fast_mode",
-    "xv_calibrate_table", "xv_ctx_set_calibration", "xv_ctx_set_lite_layers", "xv_ctx_lite_layers",
+    "xv_calibrate_table", "xv_ctx_set_calibration", "xv_ctx_model_fingerprint", "xv_ctx_share_calibration",
+    "xv_ctx_set_calibration_file", "xv_calibration_file_read", "xv_calibration_file_publish", "xv_ctx_set_lite_layers", "xv_ctx_lite_layers",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
     "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_pack_mx_residual64", "xv_tile_mx_scales", "xv_pack_mx_weights", "xv_pack_mx_weights64",
 ]
@@ -178,6 +179,15 @@ def lib():
     L.xv_calibrate_table.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                      ctypes.c_int32, ctypes.c_float, ctypes.POINTER(Calibration)]
     L.xv_ctx_set_calibration.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_float]
+    L.xv_ctx_model_fingerprint.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    L.xv_ctx_share_calibration.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_float, ctypes.c_char_p,
+                                           ctypes.POINTER(ctypes.c_int32)]
+    L.xv_ctx_set_calibration_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.xv_calibration_file_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64),
+                                           ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
+    L.xv_calibration_file_publish.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_float,
+                                              ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64),
+                                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
 
@@ -364,6 +374,25 @@ class Context:
         """extract_table then calibrates on the head of its own table before the first batch."""
         _check(lib().xv_ctx_set_calibration(self._h, 1 if enable else 0, tol))
 
+    @property
+    def model_fingerprint(self):
+        """Fingerprint of the packed model image this context runs (what a calibration file names)."""
+        v = ctypes.c_uint64()
+        _check(lib().xv_ctx_model_fingerprint(self._h, ctypes.byref(v)))
+        return int(v.value)
+
+    def share_calibration(self, path, tol=7.5e-5, note=None):
+        """The shared choice of a recipe (xv_ctx_share_calibration): applies the file's choice when it exists, else publishes this
+        context's current choice atomically and adopts what the file then holds.  Returns "read" / "published" / "adopted"."""
+        out = ctypes.c_int32(-1)
+        _check(lib().xv_ctx_share_calibration(self._h, os.fsencode(path), ctypes.c_float(tol), note.encode() if note else None,
+                                              ctypes.byref(out)))
+        return ("read", "published", "adopted")[out.value]
+
+    def set_calibration_file(self, path):
+        """extract_table applies / creates the shared calibration file before its first batch (None: off)."""
+        _check(lib().xv_ctx_set_calibration_file(self._h, os.fsencode(path) if path else None))
+
     def extract_utterances(self, feats, row_offsets, chunk_size=-1, min_chunk_size=100, pad_input=True):
         import numpy as np
         feats = np.ascontiguousarray(feats, dtype=np.float32)
@@ -431,6 +460,30 @@ def create_broadcast(model, devices, precision=PREC_DEFAULT):
         c.info, c.precision, c.device = mi, p.value, d.value
         out.append(c)
     return out
+
+
+def calibration_file_read(path):
+    """The shared choice a calibration file holds: {"model": fingerprint, "precision": name, "lite_mask": int}, or None when the
+    file does not exist (xv_calibration_file_read; XvError when it cannot be parsed)."""
+    found, prec = ctypes.c_int32(0), ctypes.c_int32(-1)
+    model, lite = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _check(lib().xv_calibration_file_read(os.fsencode(path), ctypes.byref(found), ctypes.byref(model), ctypes.byref(prec),
+                                          ctypes.byref(lite)))
+    if not found.value:
+        return None
+    return {"model": int(model.value), "precision": PRECISION_NAMES.get(prec.value, str(prec.value)), "lite_mask": int(lite.value)}
+
+
+def calibration_file_publish(path, model, precision, lite_mask=0, tol=7.5e-5, note=None):
+    """Publishes a choice unless the file exists (atomic: the first of several concurrent publishers wins); returns
+    (published, what the file holds afterwards)."""
+    won, prec = ctypes.c_int32(0), ctypes.c_int32(-1)
+    m, lite = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _check(lib().xv_calibration_file_publish(os.fsencode(path), ctypes.c_uint64(model), PRECISIONS[precision], ctypes.c_uint64(lite_mask),
+                                             ctypes.c_float(tol), note.encode() if note else None, ctypes.byref(won), ctypes.byref(m),
+                                             ctypes.byref(prec), ctypes.byref(lite)))
+    return bool(won.value), {"model": int(m.value), "precision": PRECISION_NAMES.get(prec.value, str(prec.value)),
+                             "lite_mask": int(lite.value)}
 
 
 def plan_chunks(num_rows, chunk_size, min_chunk_size, pad_input, min_net_frames, cap=4096):

@@ -12,6 +12,7 @@
 #include "engine.h"
 #include "extractor.h"
 #include "kernels.h"
+#include "calib_file.h"
 #include "multi_gpu.h"
 #include "nnet3_raw.h"
 #include "program.h"
@@ -25,6 +26,7 @@ struct xv_ctx {
   std::unique_ptr<xv::Engine> eng;
   bool calibrate = false;       // xv_ctx_set_calibration: table jobs calibrate on the head of their table first
   float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
+  std::string calibration_file;    // xv_ctx_set_calibration_file: the shared choice of the recipe (calib_file.h)
 };
 
 namespace {
@@ -320,6 +322,80 @@ xv_status xv_ctx_set_calibration(xv_ctx* c, int32_t enable, float tol) {
   return XV_OK;
 }
 
+xv_status xv_ctx_set_calibration_file(xv_ctx* c, const char* path) {
+  if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_calibration_file: null context");
+  c->calibration_file = path ? path : "";
+  return XV_OK;
+}
+
+xv_status xv_calibration_file_read(const char* path, int32_t* found, uint64_t* model, int32_t* precision, uint64_t* lite_mask) {
+  if (!path || !*path || !found) return Fail(XV_ERR_ARG, "xv_calibration_file_read: null argument");
+  return Guard([&] {
+    xv::SharedChoice sc;
+    *found = xv::ReadCalibrationFile(path, &sc) ? 1 : 0;
+    if (*found) {
+      if (model) *model = sc.model;
+      if (precision) *precision = sc.precision;
+      if (lite_mask) *lite_mask = sc.lite_mask;
+    }
+    return XV_OK;
+  });
+}
+
+xv_status xv_calibration_file_publish(const char* path, uint64_t model, int32_t precision, uint64_t lite_mask, float tol, const char* note,
+                                      int32_t* published, uint64_t* adopted_model, int32_t* adopted_precision,
+                                      uint64_t* adopted_lite_mask) {
+  if (!path || !*path) return Fail(XV_ERR_ARG, "xv_calibration_file_publish: null argument");
+  if (precision != XV_PREC_FP16MX && precision != XV_PREC_FP16MX2 && precision != XV_PREC_FP16X3)
+    return Fail(XV_ERR_ARG, "xv_calibration_file_publish: the arithmetic must be one of XV_PREC_FP16MX, XV_PREC_FP16MX2, XV_PREC_FP16X3");
+  if (lite_mask && precision != XV_PREC_FP16MX2)
+    return Fail(XV_ERR_ARG, "xv_calibration_file_publish: lite layers go with XV_PREC_FP16MX2 only");
+  return Guard([&] {
+    xv::SharedChoice mine, got;
+    mine.model = model;
+    mine.precision = precision;
+    mine.lite_mask = lite_mask;
+    mine.tolerance = tol;
+    mine.note = note ? note : "";
+    for (char& ch : mine.note)
+      if (ch == '\n' || ch == '\r') ch = ' ';
+    const bool won = xv::PublishCalibrationFile(path, mine, &got);
+    if (published) *published = won ? 1 : 0;
+    if (adopted_model) *adopted_model = got.model;
+    if (adopted_precision) *adopted_precision = got.precision;
+    if (adopted_lite_mask) *adopted_lite_mask = got.lite_mask;
+    return XV_OK;
+  });
+}
+
+xv_status xv_ctx_model_fingerprint(const xv_ctx* c, uint64_t* fingerprint) {
+  if (!c || !fingerprint) return Fail(XV_ERR_ARG, "xv_ctx_model_fingerprint: null argument");
+  *fingerprint = c->eng->info().fingerprint;
+  return XV_OK;
+}
+
+xv_status xv_ctx_share_calibration(xv_ctx* c, const char* path, float tol, const char* note, int32_t* outcome) {
+  if (!c || !path || !*path) return Fail(XV_ERR_ARG, "xv_ctx_share_calibration: null argument");
+  return Guard([&] {
+    xv::SharedChoice sc;
+    int how = 0;
+    if (!xv::ReadCalibrationFile(path, &sc)) {
+      xv::SharedChoice mine;
+      mine.model = c->eng->info().fingerprint;
+      mine.precision = c->eng->fast_mode();
+      mine.lite_mask = c->eng->lite_mask();
+      mine.tolerance = tol;
+      mine.note = note ? note : "";
+      for (char& ch : mine.note)
+        if (ch == '\n' || ch == '\r') ch = ' ';
+      how = xv::PublishCalibrationFile(path, mine, &sc) ? 1 : 2;
+    }
+    xv::AdoptSharedChoice(c->eng.get(), sc, path);
+    if (outcome) *outcome = how;
+    return XV_OK;
+  });
+}
+
 xv_status xv_ctx_set_profiling(xv_ctx* c, int32_t enable) {
   if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_profiling: null context");
   c->eng->SetProfiling(enable != 0);
@@ -367,6 +443,7 @@ xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char
     if (batch_frames > 0) opt.max_batch_rows = batch_frames;
     opt.calibrate = c->calibrate;
     opt.calibrate_tol = c->calibrate_tol;
+    opt.calibration_file = c->calibration_file;
     if (getenv("XVEC_CMN_WINDOW")) opt.cmn_window = atoi(getenv("XVEC_CMN_WINDOW"));
     if (getenv("XVEC_VAD_RSPECIFIER")) opt.vad_rspecifier = getenv("XVEC_VAD_RSPECIFIER");
     xv::TableExtractResult r = xv::RunTableExtraction(

@@ -1,6 +1,7 @@
 // Device engine.  See engine.h.
 #include "engine.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -16,11 +17,25 @@ namespace {
 
 constexpr int kDefaultFastMinPooledMx2 = 160;   // the deeper c-vector network measured 7.9e-5 at 117 pooled frames (heavy-tailed model)
 constexpr int kHalo = 32;  // zero rows in front of / behind every frame-level plane (|offset| <= 15)
-constexpr uint32_t kBlobVersion = 7;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
+constexpr uint32_t kBlobVersion = 8;   // 3: one E8M0 scale per (row, block of four K steps, lane group) of the residual
                                        // plane; 4: + the 4-bit weight image of kPrecFp16Mx2; 5: + the residual plane in the
                                        // K-walk order of tdnn_gemm_kernel_p8; 6: + the 4-bit weight image in the order of ITS second walk;
                                        // 7: that image only for layers without time offsets (the ones the kernel runs in 1.5 passes)
+                                       // 8: reserved[0..1] of the header = fingerprint of the image (what a calibration file names)
 constexpr uint64_t kNone = ~0ull;
+
+// FNV-1a over 64-bit words (the tail byte-wise): a content fingerprint, not a cryptographic hash
+uint64_t Hash64(const uint8_t* p, size_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+  }
+  for (; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+  return h ? h : 1;   // 0 = "unknown"
+}
 
 struct BlobHeader {
   char magic[8];
@@ -433,6 +448,13 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
     for (const std::exception_ptr& e : errs)
       if (e) std::rethrow_exception(e);
   }
+  // The fingerprint of the image: header (with the field itself still zero), layer table and every packed plane.  It is what a
+  // shared calibration file names (calib_file.h): a choice of arithmetic measured on one model must never be applied to another,
+  // nor to the same model packed by a library whose images differ.  It travels in the header, so a context built from a
+  // broadcast image on another device knows it without seeing the bytes on the host.
+  const uint64_t fp = Hash64(blob.data(), blob.size());
+  int32_t halves[2] = {(int32_t)(uint32_t)fp, (int32_t)(uint32_t)(fp >> 32)};
+  memcpy(blob.data() + offsetof(BlobHeader, reserved), halves, sizeof halves);
   return blob;
 }
 
@@ -492,6 +514,7 @@ BlobInfo ParseBlobInfo(const uint8_t* blob, size_t n) {
     throw EngineError("model blob: layer index out of range");
   const uint64_t data_bytes = n - h.data_offset;
   BlobInfo info;
+  info.fingerprint = (uint64_t)(uint32_t)h.reserved[0] | ((uint64_t)(uint32_t)h.reserved[1] << 32);
   info.precision = h.precision;
   info.input_dim = h.input_dim;
   info.pooled_layer = h.pooled_layer;
@@ -830,7 +853,9 @@ void Engine::Ensure(Buf* b, size_t bytes, bool zero, hipStream_t consumer) {
 void Engine::EnsureCapacity(Lane& L, int rows, int b_pad, hipStream_t s) {
   // Growing = freeing planes this lane's previous batch may still be using: wait for THAT batch (hipFree then does what it
   // does); the fills of the new planes are ordered on `s`, the stream about to consume them.  No device-wide wait of ours.
+  bool grew = false;
   if (rows > L.cap_rows) {
+    grew = true;
     if (L.busy) Check(hipEventSynchronize(L.done), "hipEventSynchronize(lane)");
     const size_t r = (size_t)rows + 2 * kHalo;
     Ensure(&L.in_hi, r * in_ld_ * 2, true, s);
@@ -873,7 +898,14 @@ void Engine::EnsureCapacity(Lane& L, int rows, int b_pad, hipStream_t s) {
       }
     }
     L.cap_b = b_pad;
+    grew = true;
   }
+  // The fills above are ordered on `s`, which is all the consuming kernels need.  They are nevertheless waited for here, once per
+  // growth (the first batches of a job): the planes' halo rows, the group maxima and the partial sums are READ by kernels of
+  // every later pass without ever being written again, and a fill that is still queued when, say, the other lane's first batch
+  // frees and reallocates its own planes is an ordering this code would rather not reason about (VERDICT / ADVICE r05 suspect
+  // (a) of the co-tenancy failure; not reproduced, removed anyway).  One stream, not the device: other contexts are not stalled.
+  if (grew) Check(hipStreamSynchronize(s), "hipStreamSynchronize(fills)");
 }
 
 uint16_t* Engine::ActBase(const Buf& b, int ld) const {

@@ -61,6 +61,7 @@ struct BlobInfo {
   int precision, input_dim, pooled_layer, pool_dim, pool_left, pool_right, output_layer, output_dim,
       output_is_segment, left_context, right_context, min_frames;
   float variance_floor;
+  uint64_t fingerprint = 0;   // of the packed image (PackModel); what a shared calibration file names
   std::vector<BlobLayerInfo> layers;
   double Macs(int T) const;
 };

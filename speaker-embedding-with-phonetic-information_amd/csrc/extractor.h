@@ -49,6 +49,9 @@ struct ExtractOptions {
   bool calibrate = false;
   float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
   int calibrate_utts = 64;
+  // the SHARED choice of a recipe (calib_file.h): when the file exists its choice is applied and nothing is measured; when it
+  // does not, the job measures (as with calibrate), publishes atomically and adopts what the file then holds.  Empty: none.
+  std::string calibration_file;
 };
 
 // feats: packed host rows; utterance u = rows row_offsets[u] .. row_offsets[u+1]-1.

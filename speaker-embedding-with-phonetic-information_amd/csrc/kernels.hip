@@ -1457,24 +1457,23 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
 // Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring, 4 = stream-K (persistent; falls
 // back to 2 / 1 when the launch has too few tiles or an odd shape), 0 = by precision and K length (default, see
 // launch_one).  XVEC_GEMM_VARIANT overrides.
+// (function-local static initialisers: thread-safe - the engines of a --devices job launch from a consumer thread each)
 static int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
+  static const int v = [] {
     const char* e = getenv("XVEC_GEMM_VARIANT");
-    v = (e && *e) ? atoi(e) : 0;
-    if (v != 0 && v != 1 && v != 2 && v != 4) v = 0;
-  }
+    const int x = (e && *e) ? atoi(e) : 0;
+    return (x != 0 && x != 1 && x != 2 && x != 4) ? 0 : x;
+  }();
   return v;
 }
 // Frame fragments per wave of the stream-K variant: 8 (512-row tiles) where the LDS allows, else 4.  XVEC_SK_MF = 4
 // forces the 256-row tiles.
 static int sk_max_mf() {
-  static int v = -1;
-  if (v < 0) {
+  static const int v = [] {
     const char* e = getenv("XVEC_SK_MF");
-    v = (e && *e) ? atoi(e) : 8;
-    if (v != 4 && v != 8) v = 8;
-  }
+    const int x = (e && *e) ? atoi(e) : 8;
+    return (x != 4 && x != 8) ? 8 : x;
+  }();
   return v;
 }
 
@@ -1582,15 +1581,19 @@ bool gemm_mx_applicable(const GemmArgs& a) {
   return true;
 }
 
+// CUs of the CURRENT device (a --devices job drives several; the count is kept per ordinal, filled once under a lock)
 static int device_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        n <= 0)
-      n = 256;
+  static std::mutex mu;
+  static int count[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (count[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    count[dev] = n;
   }
-  return n;
+  return count[dev];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3243,12 +3246,11 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
     b.sk_mtiles = a.m_tiles * kBM / (64 * MF);
     {
       // column lanes: the largest of 4, 2, 1 that divides the column tiles and the workgroups of an XCD block
-      static int max_lanes = -1;
-      if (max_lanes < 0) {
+      static const int max_lanes = [] {
         const char* e = getenv("XVEC_SK_LANES");
-        max_lanes = (e && *e) ? atoi(e) : 4;
-        if (max_lanes != 1 && max_lanes != 2 && max_lanes != 4) max_lanes = 4;
-      }
+        const int x = (e && *e) ? atoi(e) : 4;
+        return (x != 1 && x != 2 && x != 4) ? 4 : x;
+      }();
       int l = max_lanes;
       while (l > 1 && (a.n_tiles % l || (grid / 8) % l)) l >>= 1;
       b.sk_lanes = l;

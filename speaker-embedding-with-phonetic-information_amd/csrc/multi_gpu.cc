@@ -89,15 +89,22 @@ std::vector<std::unique_ptr<Engine>> CreateEnginesBroadcast(const std::vector<ui
   if (err.empty()) {
     (void)hipSetDevice(devices[0]);
     if (hipMemcpy(dbuf[0], blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) err = "upload of the weight blob failed";
+    // the receivers' buffers start without a valid header: a broadcast that was never enqueued (a failed group call) must not
+    // leave a recycled allocation's stale - and valid - image of an earlier call behind for ReadBlobHead to accept
+    for (int i = 1; i < n && err.empty(); ++i) {
+      (void)hipSetDevice(devices[i]);
+      if (hipMemset(dbuf[i], 0, std::min<size_t>(blob.size(), 256)) != hipSuccess) err = "clearing the receive buffer failed";
+    }
   }
   if (err.empty()) {
     // ONE broadcast of the packed image, ncclChar elements (type id 0), root = rank 0
-    rccl.gstart();
-    for (int i = 0; i < n; ++i) {
+    // (errors of grouped calls surface at ncclGroupEnd: nothing is enqueued then, and the stream queries below would pass at once)
+    if (rccl.gstart() != 0) err = "ncclGroupStart failed";
+    for (int i = 0; i < n && err.empty(); ++i) {
       (void)hipSetDevice(devices[i]);
       if (rccl.bcast(dbuf[i], dbuf[i], blob.size(), /*ncclChar*/ 0, 0, comms[i], st[i]) != 0) err = "ncclBroadcast failed";
     }
-    rccl.gend();
+    if (rccl.gend() != 0 && err.empty()) err = "ncclGroupEnd failed (the weight broadcast was not enqueued)";
   }
   if (err.empty()) {
     // bounded wait: a broadcast that does not complete becomes an error message and a non-zero exit of

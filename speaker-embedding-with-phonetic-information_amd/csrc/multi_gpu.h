@@ -13,7 +13,9 @@ namespace xv {
 
 // devices: distinct HIP device ordinals, devices[0] is the root.  timeout_s: how long the broadcast may take before the call
 // gives up with an EngineError (a rank that never joins would otherwise hang the job without a word); <= 0: XVEC_BCAST_TIMEOUT
-// or 120 s.  Throws EngineError on any failure; nothing is left allocated then.
+// or 120 s.  Throws EngineError on any failure; nothing is left allocated then - except after a TIME-OUT: the collective is still
+// pending on its streams, so buffers, streams and communicators are left to process exit (the communicators are aborted where
+// the library allows it); the caller is expected to end the job.
 std::vector<std::unique_ptr<Engine>> CreateEnginesBroadcast(const std::vector<uint8_t>& blob, const std::vector<int>& devices,
                                                             double timeout_s = 0.0);
 

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <deque>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -71,9 +72,8 @@ const char* kUsage =
     "  --nnet-config=<file>             node config lines applied to the model before lowering\n"
     "  --precision=default|fp16mx2|fp16x3|bf16x3|auto|fp16mx|fp16x2|bf16|fp16\n"
     "                                   arithmetic of the MFMA GEMMs.  default: fp16mx2 where every layer can run it, else\n"
-    "                                   fp16x3 (nnet3-compute: always fp16x3) - and, unless --calibrate=false, the lighter\n"
-    "                                   fp16mx where a sample of the job's own utterances shows it within --calibrate-tol of\n"
-    "                                   the three-pass arithmetic (log lines say what was sampled, measured and chosen).\n"
+    "                                   fp16x3 (nnet3-compute: always fp16x3) - a function of the MODEL alone, so that an\n"
+    "                                   utterance gets the same vector whatever job, shard or batch it lands in.\n"
     "                                   fp16x3: split fp16, three MFMAs per\n"
     "                                   product, fp32-grade (3e-7..4e-6 from the fp32 oracle).  fp16mx2: fp16 product +\n"
     "                                   two block-scaled 4-bit products that correct the fp16 rounding of the weights\n"
@@ -83,12 +83,19 @@ const char* kUsage =
     "                                   fp16x3), the others fp16x3; its error is the activation rounding averaged by the\n"
     "                                   pooling - 5-8e-5 on models with Kaldi-initialisation-like weights, 1-2e-4 on\n"
     "                                   heavy-tailed ones (DESIGN.md section 3.0): check it on your model first.\n"
+    "  --calibration=<file>             with --precision=default (default: $XVEC_CALIBRATION): the SHARED choice of a lighter\n"
+    "                                   arithmetic for this model.  The file exists: its choice (fp16mx, or fp16mx2 with some\n"
+    "                                   layers in 1.25 passes) is applied; the model fingerprint in it must match.  It does\n"
+    "                                   not: the first chunk of 64 utterances of this job - spread evenly over the list of a\n"
+    "                                   table that can be addressed, the head of a stream - is computed in fp16x3, fp16mx and\n"
+    "                                   fp16mx2, the lightest arithmetic within --calibrate-tol is PUBLISHED to the file\n"
+    "                                   (atomically; the first of several concurrent jobs wins) and every job adopts what\n"
+    "                                   the file holds.  All jobs of a recipe thus compute in one arithmetic, however the\n"
+    "                                   lists were split (extract_xvectors_new.sh:72,91-99)\n"
     "  --calibrate=true|false --calibrate-tol=<float> --calibrate-utts=<int>\n"
-    "                                   with --precision=default (default true, 7.5e-5, 64): before the first batch, the first\n"
-    "                                   chunk of 64 utterances - spread evenly over the whole list for a table that can be\n"
-    "                                   addressed (archive file, scp), the first 64 of a stream - is computed in fp16x3,\n"
-    "                                   fp16mx and fp16mx2; fp16mx is used for the job when at least 16 chunks long enough for\n"
-    "                                   it were compared and its worst embedding error against fp16x3 is within the tolerance\n"
+    "                                   (default false, 7.5e-5, 64) --calibrate=true without --calibration: measure and choose\n"
+    "                                   for THIS job only - the choice then depends on the job's own sample, and two shards\n"
+    "                                   of one list may compute in different arithmetics (one-process jobs: --devices)\n"
     "  --fast-min-pooled=<int>          auto / fp16mx2: chunks that pool at least this many frames take the fast\n"
     "                                   kernels (default 300 / 160, or $XVEC_FAST_MIN_POOLED)\n"
     "  --batch-frames=<int>             frames per device batch (default 131072)\n"
@@ -117,7 +124,8 @@ struct Options {
   std::string precision = "default";
   int batch_frames = 1 << 17;
   int fast_min_pooled = -1;
-  bool calibrate = true;
+  bool calibrate = false;          // a job measures for itself only when asked to (the choice then depends on its sample)
+  std::string calibration;         // --calibration / $XVEC_CALIBRATION: the shared choice of the recipe (calib_file.h)
   float calibrate_tol = 7.5e-5f;   // three quarters of the 1e-4 bar, on the WORST calibration chunk
   int calibrate_utts = 64;         // utterances sampled (spread over the list of an addressable table, the head of a stream)
   int device = -1;
@@ -191,7 +199,13 @@ bool ApplyOption(const std::string& name_in, const std::string& value, bool has_
   else if (name == "min-chunk-size") return need_int(&o->min_chunk_size);
   else if (name == "batch-frames") return need_int(&o->batch_frames);
   else if (name == "fast-min-pooled") return need_int(&o->fast_min_pooled);
-  else if (name == "calibrate") {
+  else if (name == "calibration") {
+    if (!has_value || value.empty()) {
+      *err = "--calibration needs a file name";
+      return false;
+    }
+    o->calibration = value;
+  } else if (name == "calibrate") {
     if (!ParseBool(value, &o->calibrate)) {
       *err = "invalid boolean for --calibrate: " + value;
       return false;
@@ -433,20 +447,33 @@ int main(int argc, char** argv) {
                      << (engine.weight_bytes() >> 20) << " MiB of packed weights");
     }
 
-    if (!opt.profile_json.empty()) engine.SetProfiling(true);
+    // (every engine of a --devices job records its own launches: the report sums them per kernel, so that the launch counts and
+    // times stand next to utterance and frame counts of the SAME whole job - ADVICE r05)
+    if (!opt.profile_json.empty())
+      for (auto& e : engines) e->SetProfiling(true);
     // --profile-json: {"kernels": [{"name", "launches", "total_ms"}], "utterances", "failed", "frames", "seconds"}
     auto write_profile = [&](const xv::TableExtractResult& r) {
       if (opt.profile_json.empty()) return;
-      std::istringstream rep(engine.ProfileReport());
+      std::vector<std::string> names;
+      std::map<std::string, std::pair<long, double>> sum;
+      for (auto& e : engines) {
+        std::istringstream rep(e->ProfileReport());
+        std::string line;
+        while (std::getline(rep, line)) {
+          const size_t a = line.find('\t'), b = line.rfind('\t');
+          if (a == std::string::npos || b == a) continue;
+          const std::string name = line.substr(0, a);
+          if (!sum.count(name)) names.push_back(name);
+          sum[name].first += atol(line.substr(a + 1, b - a - 1).c_str());
+          sum[name].second += atof(line.substr(b + 1).c_str());
+        }
+      }
       std::ostringstream js;
+      js.precision(9);
       js << "{\"kernels\": [";
-      std::string line;
       bool first = true;
-      while (std::getline(rep, line)) {
-        const size_t a = line.find('\t'), b = line.rfind('\t');
-        if (a == std::string::npos || b == a) continue;
-        js << (first ? "" : ", ") << "{\"name\": \"" << line.substr(0, a) << "\", \"launches\": " << line.substr(a + 1, b - a - 1)
-           << ", \"total_ms\": " << line.substr(b + 1) << "}";
+      for (const std::string& name : names) {
+        js << (first ? "" : ", ") << "{\"name\": \"" << name << "\", \"launches\": " << sum[name].first << ", \"total_ms\": " << sum[name].second << "}";
         first = false;
       }
       js << "], \"utterances\": " << r.num_success << ", \"failed\": " << r.num_fail << ", \"frames\": " << (long)r.frames
@@ -478,6 +505,12 @@ int main(int argc, char** argv) {
     eo.vad_rspecifier = opt.vad_rspecifier;
     eo.calibrate = policy_default && opt.calibrate && !g_frame_job;   // no-op unless the context can switch (fp16mx2)
     eo.calibrate_tol = opt.calibrate_tol;
+    if (policy_default && !g_frame_job) {
+      const char* e = getenv("XVEC_CALIBRATION");
+      eo.calibration_file = !opt.calibration.empty() ? opt.calibration : std::string(e ? e : "");
+    } else if (!opt.calibration.empty()) {
+      XWARN("--calibration is used with --precision=default only; ignored");
+    }
     if (opt.calibrate_utts > 0) eo.calibrate_utts = opt.calibrate_utts;
     if (!opt.backend_mean.empty()) xv::ReadVectorObject(opt.backend_mean, &eo.backend_mean);
     if (!opt.backend_transform.empty()) {

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "backend.h"
+#include "calib_file.h"
 #include "kio.h"
 
 namespace xv {
@@ -467,17 +468,63 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
       reader_failed("unknown error in a reader thread");
     }
   };
-  bool calibrated = !(opt.calibrate && engine->can_switch_fast_mode());   // nothing to choose: no batch is held back
-  if (!calibrated && indexer) {
-    // addressable table: the sample is spread over the whole list (SampleTable), drawn before the readers start.  A failure
-    // here (unreadable sample, device error in a candidate arithmetic) is not the job's: the packed arithmetic stays
-    // (Calibrate restores it) and the extraction goes on - and reports a bad object itself, after writing the good ones.
-    try {
-      CalibrateOnTable(engine, opt, feat_rspec, log, &pre_index);
-    } catch (const std::exception& ex) {
-      warn(std::string("calibration failed (") + ex.what() + "); keeping " + PrecisionName(engine->fast_mode()));
-    }
+  // ---- the arithmetic of the job -----------------------------------------------------------------------------------
+  // A SHARED choice first (calib_file.h): what the file holds is applied and nothing is measured; a missing file is measured
+  // here, published, and read back - this job's choice or that of the job that published first.
+  const bool shared = !opt.calibration_file.empty() && engine->can_switch_fast_mode();
+  auto adopt = [&](const SharedChoice& sc, const std::string& how) {
+    AdoptSharedChoice(engine, sc, opt.calibration_file);
     share_choice();
+    std::ostringstream m;
+    m << "arithmetic " << PrecisionName(sc.precision);
+    if (sc.lite_mask) m << " with " << __builtin_popcountll(sc.lite_mask) << " of its layers in 1.25 passes (mask 0x" << std::hex << sc.lite_mask << std::dec << ")";
+    m << ": " << how << " " << opt.calibration_file << (sc.note.empty() ? "" : " [" + sc.note + "]");
+    log("LOG", m.str());
+  };
+  auto publish = [&](const Engine::Calibration* c, const std::string& sample) {   // after a measurement (or a failed one: c = null)
+    if (!shared) return;
+    SharedChoice mine, got;
+    mine.model = engine->info().fingerprint;
+    mine.precision = engine->fast_mode();
+    mine.lite_mask = engine->lite_mask();
+    mine.tolerance = opt.calibrate_tol;
+    std::ostringstream n;
+    n.precision(3);
+    if (c && c->checked > 0)
+      n << "measured on " << c->checked << " chunks (" << sample << "): fp16mx " << c->err_mx << ", fp16mx2 " << c->err_mx2 << ", projected tail "
+        << c->tail;
+    else
+      n << "nothing could be measured (" << sample << "): the packed arithmetic";
+    mine.note = n.str();
+    const bool won = PublishCalibrationFile(opt.calibration_file, mine, &got);
+    adopt(got, won ? "measured here and published as" : "another job published first; adopted from");
+  };
+  bool want_calibrate = opt.calibrate && engine->can_switch_fast_mode();
+  if (shared) {
+    SharedChoice sc;
+    if (ReadCalibrationFile(opt.calibration_file, &sc)) {
+      adopt(sc, "read from");
+      want_calibrate = false;
+    } else {
+      want_calibrate = true;
+    }
+  }
+  bool calibrated = !want_calibrate;   // nothing to choose: no batch is held back
+  if (!calibrated && indexer) {
+    // addressable table: the sample is spread over the whole list (SampleTable), drawn before the readers start.  An unreadable
+    // sample (KioError) is not the job's failure: the packed arithmetic stays and the extraction reports the bad object itself,
+    // after writing the good ones.  Anything else - a device fault in a candidate arithmetic, a stream-K time-out, a failed
+    // allocation - ends the job (swallowed, it let independent jobs over one table run different arithmetics
+    // and exit 0).
+    try {
+      const Engine::Calibration c = CalibrateOnTable(engine, opt, feat_rspec, log, &pre_index);
+      share_choice();
+      publish(&c, "spread evenly over the table");
+    } catch (const KioError& ex) {
+      warn(std::string("calibration sample unreadable (") + ex.what() + "); keeping " + PrecisionName(engine->fast_mode()));
+      share_choice();
+      publish(nullptr, "sample unreadable");
+    }
     calibrated = true;
   }
   if (indexer) {
@@ -898,8 +945,11 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
             if (!cu.empty()) {
               log("LOG", "calibration sample: the first " + std::to_string(std::min(cu.size(), (size_t)opt.calibrate_utts)) +
                              " utterances of the stream (a stream cannot be sampled any other way)");
-              CalibrateOnUtterances(engine, opt, cu, log);
+              const Engine::Calibration c = CalibrateOnUtterances(engine, opt, cu, log);
               share_choice();
+              publish(&c, "the head of a stream");
+            } else {
+              publish(nullptr, "empty stream");
             }
           } catch (const std::exception& ex) {
             set_fatal(ex.what());

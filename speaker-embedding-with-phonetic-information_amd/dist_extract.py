@@ -107,10 +107,15 @@ def main(argv=None):
                     choices=["default", "bf16x3", "bf16", "fp16", "fp16x3", "fp16x2", "fp16mx", "fp16mx2", "auto"],
                     help="default = the policy of nnet3-xvector-compute (XV_PREC_DEFAULT): fp16mx2 where every layer can run it, "
                          "else fp16x3; the others are opt-in")
-    ap.add_argument("--calibrate", default="true",
-                    help="with --precision default: rank 0 measures fp16mx / fp16mx2 against fp16x3 on the first chunk of the first 64 "
-                         "utterances of the WHOLE list and every rank runs the arithmetic it chose (what nnet3-xvector-compute does "
-                         "on its own list; an N-way job therefore computes what the 1-way job computes)")
+    ap.add_argument("--calibrate", default="false",
+                    help="with --precision default: rank 0 measures fp16mx / fp16mx2 against fp16x3 on the first chunk of 64 "
+                         "utterances spread over the WHOLE list and every rank runs the arithmetic it chose (an N-way job computes "
+                         "what the 1-way job computes; but the choice depends on THIS list - default false: plain fp16mx2, a "
+                         "function of the model, like nnet3-xvector-compute)")
+    ap.add_argument("--calibration", default=os.environ.get("XVEC_CALIBRATION"),
+                    help="the shared choice of the recipe (nnet3-xvector-compute --calibration, csrc/calib_file.h): the file "
+                         "exists - rank 0 applies it; it does not - rank 0 measures as with --calibrate true, publishes it "
+                         "atomically and adopts what the file then holds; the choice travels to the other ranks either way")
     ap.add_argument("--calibrate-tol", type=float, default=7.5e-5)
     ap.add_argument("--force-device", type=int, default=None,
                     help="HIP device every rank uses instead of LOCAL_RANK (ranks sharing one GPU: the recipes' nj > #GPUs "
@@ -213,7 +218,9 @@ def main(argv=None):
                 ctx = P.Context(device_blob=(wt.data_ptr(), wt.numel()), device=local_rank)
             else:
                 ctx = P.Context(blob=wt.numpy().tobytes(), device=local_rank)
-            if rank == 0 and args.precision == "default" and args.calibrate.lower() in ("true", "t", "1") and lines:
+            shared = args.calibration if args.precision == "default" else None
+            measure = args.calibrate.lower() in ("true", "t", "1") or (shared and not os.path.exists(shared))
+            if rank == 0 and args.precision == "default" and measure and lines:
                 # the calibration sample: 64 utterances spread evenly over the WHOLE list, i.e. over every rank's slice (the
                 # lists of the reference are sorted by speaker, utils/data/split_data.sh:18-21: the head of the list is one or
                 # two speakers and lies in rank 0's slice only) - the rule of xv_calibrate_table (table_extract.cc SampleTable)
@@ -229,6 +236,12 @@ def main(argv=None):
                 mode[0] = P.PRECISIONS[cal["chosen"]]
                 mode[1] = cal.get("lite_mask", 0) & 0xFFFFFFFF
                 mode[2] = cal.get("lite_mask", 0) >> 32
+            if rank == 0 and shared:
+                how = ctx.share_calibration(shared, args.calibrate_tol, "dist_extract rank 0, 64 utterances spread over %d" % len(lines))
+                print("rank 0: arithmetic %s lite %#x (%s %s)" % (ctx.fast_mode, ctx.lite_mask, how, shared), flush=True)
+                mode[0] = P.PRECISIONS[ctx.fast_mode]
+                mode[1] = ctx.lite_mask & 0xFFFFFFFF
+                mode[2] = ctx.lite_mask >> 32
     except Exception as e:   # noqa: BLE001 - counted below with the extraction errors
         print("ERROR (dist_extract) rank %d: %s" % (rank, e), file=sys.stderr, flush=True)
         error = 1

@@ -79,13 +79,20 @@ def test_contexts_give_their_device_memory_back(v2):
         c.close()
 
     cycle()                                 # one-time allocations of the runtime (code objects, streams)
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
-    for _ in range(10):
-        cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < (8 << 20), (free0, free1)     # one context of this size holds ~60 MB
+    # A leak costs every cycle; the runtime's own pools (and torch's, in a process that ran two hundred tests before this one)
+    # grow once in a while: three rounds of ten contexts, and the round that lost least must have lost (almost) nothing.
+    # Round 6: the test used to run early in the session; behind the kernel tests ONE round of ten was seen to lose 46 MB that
+    # the next rounds did not lose again.
+    lost = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for _ in range(10):
+            cycle()
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        lost.append(free0 - free1)
+    assert min(lost) < (8 << 20), lost      # one context of this size holds ~60 MB
 
 
 def test_repeatability_and_single_utterance_batch(v2):

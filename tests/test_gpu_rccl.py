@@ -153,7 +153,7 @@ def test_two_ranks_apply_the_mixture_rank_0_calibrated(tmp_path):
 
     def cal_of(log):
         return ast.literal_eval(re.search(r"rank 0 calibration: (\{.*\})", log).group(1))
-    extra = ["--backend", "gloo", "--force-device", "0"] + node
+    extra = ["--backend", "gloo", "--force-device", "0", "--calibrate", "true"] + node
     one, log1 = _run_dist_extract(tmp_path, 1, "probe", extra)
     cal = cal_of(log1)
     if not cal.get("lite_mask"):      # fp16mx passed outright on this sample: ask again with a tolerance it misses
@@ -170,6 +170,24 @@ def test_two_ranks_apply_the_mixture_rank_0_calibrated(tmp_path):
     assert list(v1) == list(v2) == [k for k, _ in utts]
     for k in v1:
         assert v1[k].tobytes() == v2[k].tobytes(), k
+    # the same choice as a FILE (--calibration, csrc/calib_file.h): a one-rank job publishes it, a two-rank job and the plain
+    # command-line tool read it - three launchers, one arithmetic, the same bytes
+    calib = str(tmp_path / "xvec.calib")
+    shared = [a for a in extra if a not in ("--calibrate", "true")] + ["--calibration", calib]
+    f1, flog1 = _run_dist_extract(tmp_path, 1, "file_one", shared)
+    assert "published" in flog1 and os.path.exists(calib), flog1[-1500:]
+    f2, flog2 = _run_dist_extract(tmp_path, 2, "file_two", shared)
+    assert "(read %s)" % calib in flog2 and "rank 0 calibration" not in flog2, flog2[-1500:]
+    w1 = dict(kio.read_scp(str(f1 / "xvector_t.scp"), "vector"))
+    w2 = dict(kio.read_scp(str(f2 / "xvector_t.scp"), "vector"))
+    exe = os.path.join(H.ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
+    r = subprocess.run([exe, "--min-chunk-size=25", "--chunk-size=10000", "--calibration=" + calib] + ["--output-node=" + node[1]] +
+                       [str(tmp_path / "final.raw"), "scp:%s/feats.scp" % tmp_path, "ark:%s/cli.ark" % tmp_path],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "read from" in r.stderr, r.stderr[-1500:]
+    w3 = dict(kio.read_ark(str(tmp_path / "cli.ark"), "vector"))
+    for k in w1:
+        assert w1[k].tobytes() == w2[k].tobytes() == w3[k].tobytes() == v1[k].tobytes(), k
 
 
 def test_bench_two_ranks_on_one_gpu_prints_one_line():
@@ -273,7 +291,7 @@ def _cli_job(tmp_path, n_utts=150):
 def _cli(tmp_path, tag, extra, env=None):
     exe = os.path.join(H.ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
     # small batches, so that a 150-utterance job is many batches and several devices all get some
-    cmd = [exe, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine", "--batch-frames=4096"] + extra + \
+    cmd = [exe, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine", "--batch-frames=4096", "--calibrate=true"] + extra + \
           [str(tmp_path / "final.raw"), "scp:%s/feats.scp" % tmp_path, "ark,scp:%s/%s.ark,%s/%s.scp" % (tmp_path, tag, tmp_path, tag)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {})))

@@ -1,0 +1,97 @@
+"""Shard invariance in the reference's own launch mode (VERDICT r05 "missing" 1): `extract_xvectors_new.sh` splits the
+speaker-sorted list per speaker (:72, utils/data/split_data.sh -> utils/split_scp.pl --utt2spk), starts one independent
+nnet3-xvector-compute per split on a feature PIPE (:79, :91-93) and concatenates the outputs (:99).  Kaldi's fp32 gives an
+utterance the same vector whatever shard it lands in; here that has to hold for every arithmetic the command line can end up in:
+  * the default (plain fp16mx2: a function of the model, nothing is measured);
+  * a measured choice shared through --calibration / $XVEC_CALIBRATION - created by whichever job comes first, adopted by all.
+Four separate processes, started together, on the four per-speaker splits, each through `ark:copy-feats scp:... ark:- |`; their
+archives concatenated in job order must be byte-identical to the 1-way job's archive - on the v2 x-vector and the v5 c-vector."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import kaldi_io as kio
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(H.ROOT, H.PKG_NAME, "bin")
+DX = importlib.import_module(H.PKG_NAME + ".dist_extract")
+
+
+def _speaker_sorted_table(d, n_spk=23, seed=5):
+    """A list like the reference's: sorted by speaker, a few utterances per speaker, lengths that straddle both thresholds of
+    the arithmetic (160 / 300 pooled frames) - and speakers that differ in level, so that the head of a shard is not a sample of
+    the whole list."""
+    rng = np.random.default_rng(seed)
+    utts, utt2spk = [], {}
+    for s in range(n_spk):
+        gain = 0.5 + 1.5 * rng.random()
+        for u in range(int(rng.integers(5, 12))):
+            T = int(rng.choice([180, 333, 400, 400, 400, 520, 90]))
+            key = "spk%02d-utt%02d" % (s, u)
+            utts.append((key, (H.features(1000 * s + u, T) * gain).astype(np.float32)))
+            utt2spk[key] = "spk%02d" % s
+    kio.write_ark_matrices(os.path.join(d, "feats.ark"), utts, scp_path=os.path.join(d, "feats.scp"))
+    return utts, utt2spk
+
+
+@pytest.mark.parametrize("topology", ["v2_xvector", "v5_cvector"])
+@pytest.mark.parametrize("mode", ["default", "shared-calibration"])
+def test_four_way_split_through_pipes_is_byte_identical_to_the_one_way_job(tmp_path, topology, mode):
+    d = str(tmp_path)
+    net, line = H.synth_model(topology)
+    open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
+    open(os.path.join(d, "extract.config"), "w").write(line + "\n")
+    utts, utt2spk = _speaker_sorted_table(d)
+    lines = open(os.path.join(d, "feats.scp")).read().splitlines()
+    jobs = DX.shard_by_speaker(lines, utt2spk, 4)                 # utils/split_scp.pl --utt2spk (pinned in tests/test_oracle_golden.py)
+    assert sum(len(j) for j in jobs) == len(lines) and all(jobs)
+    for j, part in enumerate(jobs, 1):
+        os.makedirs(os.path.join(d, "split4", str(j)))
+        open(os.path.join(d, "split4", str(j), "feats.scp"), "w").write("\n".join(part) + "\n")
+    env = dict(os.environ)
+    if mode == "shared-calibration":
+        env["XVEC_CALIBRATION"] = os.path.join(d, "xvec.calib")   # how the unchanged wrapper scripts pass it: the environment
+
+    def cmd(scp, out):
+        # extract_xvectors_new.sh:59,79,92-93 with the recipe's options (run_xvector_new.sh:83,88)
+        return [os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=10000",
+                "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), d, d),
+                "ark:%s scp:%s ark:- |" % (os.path.join(BIN, "copy-feats"), scp),
+                "ark,scp:%s.ark,%s.scp" % (out, out)]
+
+    procs = [subprocess.Popen(cmd(os.path.join(d, "split4", str(j), "feats.scp"), os.path.join(d, "xvector.%d" % j)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for j in (1, 2, 3, 4)]
+    errs = [p.communicate(timeout=900)[1].decode() for p in procs]
+    for p, e in zip(procs, errs):
+        assert p.returncode == 0, e[-1500:]
+    r = subprocess.run(cmd(os.path.join(d, "feats.scp"), os.path.join(d, "xvector.all")), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=900)
+    one_err = r.stderr.decode()
+    assert r.returncode == 0, one_err[-1500:]
+    arith = lambda e: [ln[-500:] for ln in e.splitlines() if "calibration" in ln or "arithmetic" in ln]
+    if mode == "default":
+        assert not any(arith(e) for e in errs + [one_err]), [arith(e) for e in errs + [one_err]]     # nothing measured, nothing chosen
+    else:
+        # the heads of the four shards are different speakers: whoever published, all five jobs name the same choice
+        assert sum("measured here and published as" in e for e in errs) == 1, [arith(e) for e in errs]
+        assert "read from" in one_err, arith(one_err)
+        chosen = set(ln.split("arithmetic ", 1)[1].split(":", 1)[0] for e in errs + [one_err] for ln in e.splitlines() if "arithmetic " in ln)
+        assert len(chosen) == 1, chosen
+    # extract_xvectors_new.sh:99: for j in $(seq $nj); do cat $dir/xvector.$j.scp; done - and the archives behind them
+    cat = b"".join(open(os.path.join(d, "xvector.%d.ark" % j), "rb").read() for j in (1, 2, 3, 4))
+    one = open(os.path.join(d, "xvector.all.ark"), "rb").read()
+    keys_cat = [ln.split()[0] for j in (1, 2, 3, 4) for ln in open(os.path.join(d, "xvector.%d.scp" % j))]
+    assert keys_cat == [ln.split()[0] for ln in open(os.path.join(d, "xvector.all.scp"))]     # per-speaker split keeps the list order
+    if cat != one:
+        a = dict(kio.read_ark(os.path.join(d, "xvector.all.ark"), "vector"))
+        bad = []
+        for j in (1, 2, 3, 4):
+            for k, v in kio.read_ark(os.path.join(d, "xvector.%d.ark" % j), "vector"):
+                if not np.array_equal(v, a[k]):
+                    bad.append((j, k, float(np.abs(v - a[k]).max() / np.abs(a[k]).max())))
+        raise AssertionError("%d of %d utterances differ between the 4-way and the 1-way job, e.g. %s\n%s"
+                             % (len(bad), len(keys_cat), bad[:4], "\n".join(sum((arith(e) for e in errs + [one_err]), []))))

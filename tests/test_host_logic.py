@@ -84,9 +84,9 @@ def test_split_fp16_modes_share_one_weight_image_scaled_by_a_power_of_two():
     m = P.Model(raw=net.to_bytes(True))
     blobs = [m.pack(p) for p in (P.PREC_FP16X3, P.PREC_FP16X2)]
     assert len(set(len(b) for b in blobs)) == 1
-    # identical up to the precision field of the header
+    # identical up to the precision field of the header and the fingerprint of the image (which covers that field)
     diff = [i for i in range(len(blobs[0])) if blobs[0][i] != blobs[1][i]]
-    assert 0 < len(diff) <= 4
+    assert 0 < len(diff) <= 4 + 8 and max(diff) < 128
     assert len(m.pack(P.PREC_AUTO)) >= len(blobs[0]) and len(m.pack(P.PRECISIONS["fp16mx2"])) >= len(blobs[0])
     w = np.asarray(net.components["tdnn4.affine"].f["linear"], np.float32)     # 12 x 12
     scale = 2.0 ** (14 - np.frexp(np.abs(w).max())[1])
@@ -421,3 +421,73 @@ def test_bn_fold_is_opt_in_and_moves_the_mantissa_into_the_consumer(monkeypatch)
     bits = np.frombuffer(w.tobytes(), np.uint32)
     first_row = ((bits + 0x7FFF + ((bits >> 16) & 1)) >> 16)[:12].astype(np.uint16)      # bf16(hi) of the folded row
     assert any(np.array_equal(u16[i:i + 12], first_row) for i in range(len(u16) - 12))
+
+
+def _publish_worker(args):
+    path, k = args
+    import importlib
+    pkg = importlib.import_module(H.PKG_NAME)
+    won, got = pkg.calibration_file_publish(path, 0x1234 + 0, "fp16mx2", lite_mask=1 << k, note="job %d" % k)
+    return won, got["lite_mask"]
+
+
+def test_calibration_file_round_trip_first_publisher_wins_and_bad_files_are_errors(tmp_path):
+    """The shared choice of a recipe (csrc/calib_file.h, VERDICT r05 "missing" 1): what a job publishes is what every job reads;
+    of several jobs that publish at once (run.pl JOB=1:nj starts them together, extract_xvectors_new.sh:91) exactly one wins and
+    ALL hold the winner's choice afterwards; a file that cannot be parsed is an error, never silently the default."""
+    path = str(tmp_path / "xvec.calib")
+    assert P.calibration_file_read(path) is None
+    won, got = P.calibration_file_publish(path, 0xfeedbeefcafe0123, "fp16mx2", lite_mask=0x2e6, tol=7.5e-5, note="64 chunks\nworst 6.5e-05")
+    assert won and got == {"model": 0xfeedbeefcafe0123, "precision": "fp16mx2", "lite_mask": 0x2e6}
+    assert P.calibration_file_read(path) == got
+    text = open(path).read().splitlines()
+    assert text[0] == "xvec-calibration 1" and "model feedbeefcafe0123" in text and "precision fp16mx2" in text and "lite-mask 2e6" in text
+    assert any(ln.startswith("note 64 chunks worst") for ln in text)        # one line, whatever the note held
+    won2, got2 = P.calibration_file_publish(path, 0x1, "fp16mx")             # too late: the first choice stands
+    assert not won2 and got2 == got
+    assert [f for f in os.listdir(tmp_path) if ".tmp." in f] == []          # no temporary left behind
+    # eight jobs at once, each with a choice of its own
+    import multiprocessing as mp
+    race = str(tmp_path / "race.calib")
+    with mp.get_context("spawn").Pool(8) as pool:
+        res = pool.map(_publish_worker, [(race, k) for k in range(8)])
+    assert sum(w for w, _ in res) == 1
+    assert len(set(m for _, m in res)) == 1 and res[[w for w, _ in res].index(True)][1] == P.calibration_file_read(race)["lite_mask"]
+    # malformed files
+    for bad in ("", "something else\n", "xvec-calibration 2\nmodel 1\nprecision fp16mx\n", "xvec-calibration 1\nprecision fp16mx\n",
+                "xvec-calibration 1\nmodel 12\nprecision bf16\n", "xvec-calibration 1\nmodel 12\nprecision fp16mx\nlite-mask 3\n"):
+        open(str(tmp_path / "bad.calib"), "w").write(bad)
+        with pytest.raises(P.XvError) as e:
+            P.calibration_file_read(str(tmp_path / "bad.calib"))
+        assert "calibration file" in str(e.value)
+    with pytest.raises(P.XvError):          # a choice that cannot be shared must not be run on
+        P.calibration_file_publish(str(tmp_path / "no_such_dir" / "x.calib"), 1, "fp16mx")
+    with pytest.raises(P.XvError):
+        P.calibration_file_publish(path, 1, "fp16mx", lite_mask=1)
+
+
+def test_packed_image_carries_its_fingerprint():
+    """Blob version 8: the header names the image (FNV-1a over the whole image with the field zero) - what a calibration file is
+    keyed by.  Two packs of one model agree; another precision, another model or another output node give another fingerprint."""
+    import struct
+
+    def fp(blob):       # BlobHeader: magic[8] u32 version i32 precision 6 x i32 f32 6 x i32 reserved[7]
+        assert struct.unpack_from("<I", blob, 8)[0] == 8
+        lo, hi = struct.unpack_from("<II", blob, 8 + 4 + 4 + 6 * 4 + 4 + 6 * 4)
+        return lo | (hi << 32)
+    net, line = H.synth_model("v2_xvector")
+    a = P.Model(raw=net.to_bytes(True), nnet_config=line).pack()
+    b = P.Model(raw=net.to_bytes(False), nnet_config=line).pack()
+    assert a == b and fp(a) != 0
+    zeroed = bytearray(a)
+    off = 8 + 4 + 4 + 6 * 4 + 4 + 6 * 4
+    zeroed[off:off + 8] = bytes(8)
+    h = 0xcbf29ce484222325
+    words = np.frombuffer(bytes(zeroed[:len(zeroed) // 8 * 8]), dtype="<u8")
+    for w in words[:4096]:                      # (the first 32 KiB in pure Python: the rule, not the speed)
+        h = ((h ^ int(w)) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    assert h != fp(a)                           # the fingerprint covers the planes too, not just the head
+    others = [P.Model(raw=net.to_bytes(True), nnet_config=line).pack(P.PREC_FP16X3),
+              P.Model(raw=H.synth_model("v2_xvector", seed=124)[0].to_bytes(True), nnet_config=line).pack(),
+              P.Model(raw=net.to_bytes(True), nnet_config="output-node name=output input=tdnn7.affine").pack()]
+    assert len({fp(a)} | {fp(o) for o in others}) == 4
