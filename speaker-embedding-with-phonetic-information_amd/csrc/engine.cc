@@ -1543,6 +1543,39 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     ForwardHost(f.data(), offs.data(), n, mx.data());
     SetFastMode(kPrecFp16Mx2);
     ForwardHost(f.data(), offs.data(), n, mx2.data());
+    // The measurement is only worth something if the device computes the same bits twice.  The three passes above are the FIRST
+    // forward passes of a job's context (fresh planes, first launches, and - run.pl JOB=1:nj - three other processes doing
+    // the same on the same GPU); the reference and the packed arithmetic are run once more and compared byte for byte.  A
+    // difference is a device or library fault and ends the job with a message instead of moving a threshold decision
+    // (r05: one of four concurrent jobs on the driver's box came out of its calibration with another arithmetic than the
+    // solo run, and nothing in its log said why - DESIGN.md section 0).
+    std::vector<float> again((size_t)n * E);
+    for (int pass = 0; pass < 2; ++pass) {
+      const std::vector<float>& first = pass == 0 ? mx2 : ref;
+      if (pass == 1) SetFastMode(kPrecFp16x3);
+      ForwardHost(f.data(), offs.data(), n, again.data());
+      if (memcmp(again.data(), first.data(), again.size() * sizeof(float)) != 0) {
+        int bad = 0;
+        double worst = 0.0;
+        for (int i = 0; i < n; ++i) {
+          bool differs = false;
+          for (int k = 0; k < E; ++k) {
+            const float a = again[(size_t)i * E + k], b = first[(size_t)i * E + k];
+            if (memcmp(&a, &b, 4) != 0) {
+              differs = true;
+              const double r = std::fabs((double)a - b) / std::max(1e-30, (double)std::fabs(b));
+              if (!(r <= worst)) worst = r;
+            }
+          }
+          bad += differs ? 1 : 0;
+        }
+        std::ostringstream m;
+        m << "calibration: two runs of the " << PrecisionName(pass == 0 ? (int)kPrecFp16Mx2 : (int)kPrecFp16x3) << " arithmetic on the same "
+          << n << " chunks differ in " << bad << " of them (largest relative difference of an element " << worst
+          << "): the device does not reproduce its own results";
+        throw EngineError(m.str());
+      }
+    }
   } catch (...) {
     SetFastMode(before);
     if (before == kPrecFp16Mx2 && lite_before) SetLiteMask(lite_before);

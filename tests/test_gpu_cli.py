@@ -339,6 +339,9 @@ def _arith_lines(stderr_text):
                           ("v5_cvector", "default", 6000, "shared-file"), ("v5_cvector", "default", 6000, "self-calibrated")],
                          ids=["x-vector-1.25-pass", "c-vector-default", "c-vector-shared-calibration", "c-vector-self-calibrated"])
 def test_four_concurrent_processes_share_one_gpu(tmp_path, topology, precision, n_utts, mode):
+    if mode == "self-calibrated" and not os.environ.get("XVEC_TEST_SELF_CALIBRATED"):
+        pytest.skip("opt-in (XVEC_TEST_SELF_CALIBRATED=1): per-process measurement is no longer what any default does; "
+                    "tools/repro_four_procs.py --mode self loops it")
     """The launch mode the recipes use: run.pl JOB=1:nj starts nj independent nnet3-xvector-compute processes
     (extract_xvectors_new.sh:91-93; nj = 32 on an 8-GPU node = 4 per GPU), each with its own persistent stream-K grids
     that wait on inter-workgroup flags.  Four concurrent processes on this GPU, >= 200 device batches each, exactly the

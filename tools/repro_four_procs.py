@@ -33,7 +33,11 @@ def main():
     ap.add_argument("--noise", type=float, default=0.0)
     ap.add_argument("--solo-repeats", type=int, default=1)
     ap.add_argument("--env", nargs="*", default=[])
-    ap.add_argument("--extra", nargs="*", default=[], help="extra options of nnet3-xvector-compute")
+    ap.add_argument("--mode", default="fixed", choices=["fixed", "shared", "self"],
+                    help="fixed: the arithmetic --precision names (default = plain fp16mx2); shared: --calibration=<file>, removed before "
+                         "every iteration (all processes measure at once, one publishes, all adopt; the solo reference is re-run after "
+                         "the first iteration from the published file); self: --calibrate=true (round 5's default: every process "
+                         "measures for itself)")
     a = ap.parse_args()
     env = dict(os.environ)
     for kv in a.env:
@@ -43,6 +47,7 @@ def main():
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
     d = tempfile.mkdtemp(prefix="xvrepro", dir=shm)
     bad = 0
+    noise = None
     try:
         open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
         open(os.path.join(d, "extract.config"), "w").write(line + "\n")
@@ -52,14 +57,17 @@ def main():
                 f.write(("utt%06d " % i).encode() + b"\0B")
                 kio.write_matrix(f, pool[(i * 7) % 32])
 
+        calib_path = os.path.join(d, "xvec.calib")
+        extra = {"fixed": [], "shared": ["--calibration=" + calib_path], "self": ["--calibrate=true"]}[a.mode]
+
         def cmd(job):
             return [os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=10000",
-                    "--precision=" + a.precision, "--batch-frames=40000"] + list(a.extra) + [
+                    "--precision=" + a.precision, "--batch-frames=40000"] + extra + [
                     "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), d, d),
                     "ark:%s/feats.ark" % d, "ark:%s/xvector.%s.ark" % (d, job)]
 
         def calib(err):
-            return [ln for ln in err.splitlines() if "calibration" in ln]
+            return [ln for ln in err.splitlines() if "calibration" in ln or "arithmetic " in ln or "ERROR" in ln]
 
         def read(job):
             return open(os.path.join(d, "xvector.%s.ark" % job), "rb").read()
@@ -99,12 +107,15 @@ def main():
             if read("solo%d" % k) != solo:
                 bad += 1
                 diff_report("solo repeat %d" % k, read("solo%d" % k), solo, r.stderr.decode())
-        noise = None
         if a.noise > 0:
             noise = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", os.environ.get("NOISE_TOOL", "noise_gpu.py")), str(a.noise)])
             time.sleep(8.0)
+        shared_ref = {}
         for it in range(a.iters):
             t0 = time.perf_counter()
+            if a.mode == "shared" and os.path.exists(calib_path):
+                shared_ref[open(calib_path).read().split("note")[0]] = None
+                os.remove(calib_path)
             procs = [subprocess.Popen(cmd(str(j)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for j in range(a.procs)]
             errs = [p.communicate()[1].decode() for p in procs]
             nb = 0
@@ -114,15 +125,24 @@ def main():
                     nb += 1
                     continue
                 got = read(str(j))
+                if a.mode == "shared":
+                    # whoever published: all processes of an iteration agree; and the same choice gives the same bytes every time
+                    key = open(calib_path).read().split("note")[0]
+                    if shared_ref.get(key) is None:
+                        shared_ref[key] = got
+                    if got != shared_ref[key]:
+                        nb += 1
+                        diff_report("iter %d proc %d" % (it, j), got, shared_ref[key], e)
+                    continue
                 if got != solo:
                     nb += 1
                     diff_report("iter %d proc %d" % (it, j), got, solo, e)
             bad += nb
             print("iter %d: %d of %d processes differ from solo (%.1f s)" % (it, nb, a.procs, time.perf_counter() - t0), flush=True)
+    finally:
         if noise:
             noise.terminate()
             noise.wait()
-    finally:
         for fn in os.listdir(d):
             os.remove(os.path.join(d, fn))
         os.rmdir(d)

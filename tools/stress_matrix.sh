@@ -11,3 +11,15 @@ for topo in v2_xvector v5_cvector; do
     done
   done
 done
+# the multi-PROCESS leg: what the in-process tools above do not model - four (and eight) independent
+# nnet3-xvector-compute processes on one GPU, each a fresh context with its own first batches, under a noise process; the
+# arithmetic fixed by the model, shared through a calibration file that all of them race to publish, and measured per process
+M=${2:-10}
+for topo in v2_xvector v5_cvector; do
+  for mode in fixed shared self; do
+    for procs in 4 8; do
+      r=$(timeout 900 python3 $R/tools/repro_four_procs.py --topology $topo --mode $mode --procs $procs --iters $M --noise 600 2>&1 | grep -E "^TOTAL|differ \(|exit [0-9]" | tr '\n' ' ' | cut -c1-300)
+      echo "$topo processes=$procs mode=$mode: $r"
+    done
+  done
+done
