@@ -618,13 +618,13 @@ def main():
                                 "rel_err_vs_oracle_fp32": H.rel_err(o2[:nchk].cpu().numpy(), ref), "parity_chunks_vs_oracle": nchk}
                 del c2
             res["other_modes"] = extra
-            # the same arithmetic with tdnn_gemm_kernel_p8 dealing out WHOLE output tiles (XVEC_P8_WHOLE=1, read per context): every
+            # the same arithmetic with tdnn_gemm_kernel_p8 dealing out WHOLE output tiles (XVEC_DEBUG=p8_whole=1, read per context): every
             # launch is longer on its own (no even split of the K tiles), but there is no exchange of partial tiles, and with two
             # batches in flight the other lane's kernels fill the CUs that finish early (profiles/r05_p8_whole_tiles.md)
             try:
-                os.environ["XVEC_P8_WHOLE"] = "1"
+                os.environ["XVEC_DEBUG"] = "p8_whole=1"
                 cw = P.Context(model, device=local_rank, precision=prec)
-                os.environ.pop("XVEC_P8_WHOLE", None)
+                os.environ.pop("XVEC_DEBUG", None)
                 if calibration:
                     cw.set_fast_mode(calibration["chosen"])
                     if calibration.get("lite_mask"):
@@ -635,10 +635,10 @@ def main():
                 dw = time_steps(torch, fw, args.steps)
                 res["whole_tiles"] = {"value": B * args.steps / dw, "unit": "utt/s", "lanes": args.lanes, "ms_per_step": dw / args.steps * 1e3,
                                       "bit_identical_to_the_timed_run": bool(torch.equal(ow, out)),
-                                      "note": "XVEC_P8_WHOLE=1: not the default - the dominant kernel's own launch is ~13 % longer this way"}
+                                      "note": "XVEC_DEBUG=p8_whole=1: not the default - the dominant kernel's own launch is ~13 % longer this way"}
                 del cw
             except Exception as e:   # noqa: BLE001
-                os.environ.pop("XVEC_P8_WHOLE", None)
+                os.environ.pop("XVEC_DEBUG", None)
                 res["whole_tiles"] = {"error": str(e)}
             # the fast modes on a model closer to a trained one (heavy-tailed weights, calibrated BatchNorm): see docstring
             try:

@@ -1,7 +1,9 @@
 // Device engine.  See engine.h.
 #include "engine.h"
+#include "knobs.h"
 
 #include <stddef.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -256,10 +258,8 @@ std::vector<uint8_t> PackModel(const TdnnProgram& prog, int precision) {
           // WITHOUT time offsets: on those the kernel beats tdnn_gemm_kernel_sk in this arithmetic, on the spliced ones it loses
           // (kernels.h kP8Mx2Built).  A property of the layer: every 1.5-pass launch of the layer runs the same kernel.
           bool lo64 = kP8Mx2Built && b.w4p != kNone;
-          // (XVEC_P8_MX2_SPLICED=1: measurement knob - the spliced layers on that kernel as well)
-          static const bool spliced_too = getenv("XVEC_P8_MX2_SPLICED") && atoi(getenv("XVEC_P8_MX2_SPLICED")) == 1;
           for (int j = 0; j < b.nsrc; ++j)
-            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256 || (b.src_offset[j] != 0 && !spliced_too)) lo64 = false;
+            if (SrcKPad(b.src_dim[j], b.src_layer[j], b.segment_level, precision) % 256 || b.src_offset[j] != 0) lo64 = false;
           if (lo64) {
             b.w4bp = cur;
             cur = Align256(cur + (uint64_t)b.n_pad * b.k_pad * 2);
@@ -721,24 +721,21 @@ Engine::Engine(const uint8_t* blob, size_t n, int device, const void* device_ima
   // is enough - other contexts' (non-blocking) streams on this device keep running
   Check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(weights)");
   {
-    const char* e = getenv("XVEC_P8");   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
-    use_p8_ = !(e && *e && atoi(e) == 0);
-    // XVEC_P8_WHOLE (read per context): how tdnn_gemm_kernel_p8 deals its work out.  0 (default): K tiles evenly, partial tiles
+    use_p8_ = DebugKnobInt("p8", 1) != 0;   // 0: never run tdnn_gemm_kernel_p8 (A/B against the 32-column kernels)
+    // XVEC_DEBUG=p8_whole=... (read per context): how tdnn_gemm_kernel_p8 deals its work out.  0 (default): K tiles evenly, partial tiles
     // exchanged through the workspace - the shortest launch when a launch has the GPU to itself.  1: whole output tiles only -
     // every launch is LONGER on its own (800 tiles on 256 workgroups: a quarter of them gets a fourth tile) but needs no exchange,
     // and with two batches in flight the other lane's kernels fill the CUs that finish early: +3 % throughput at two lanes,
     // -10 % on the dominant kernel's own roofline fraction (profiles/r05_p8_whole_tiles.md).  2: whole tiles for the K <= 512 layers.
     // Same bits either way: every output element is accumulated in one fixed order.
-    const char* w = getenv("XVEC_P8_WHOLE");
-    p8_whole_ = (w && *w) ? atoi(w) : 0;
+    p8_whole_ = DebugKnobInt("p8_whole", 0);
   }
   in_ld_ = RoundUp(info_.input_dim, kBK);
   stats_ld_ = RoundUp(2 * info_.pool_dim, kBK);
   // Layers whose every source is the network input run tdnn_first_kernel (kernels.h) in the split-precision families:
   // fp32 features in, planes out, weights resident on the CU; prep_input then only runs for whatever else reads the input.
   {
-    const char* e = getenv("XVEC_FIRST_KERNEL");
-    const bool allow = !(e && *e && atoi(e) == 0) && nplanes_ == 2;
+    const bool allow = DebugKnobInt("first_kernel", 1) != 0 && nplanes_ == 2;
     need_prep_ = false;
     for (size_t i = 0; i < layers_.size(); ++i) {
       const BlobLayerInfo& li = info_.layers[i];
@@ -1622,10 +1619,12 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     }
     return st;
   };
-  // (XVEC_TAIL_OVER_TOL: diagnostic override of the factor, for studies like tools/tail_error.py)
+  // (XVEC_DEBUG=tail_over_tol=<factor>: diagnostic override, for studies like tools/tail_error.py)
   float tail_over_tol = kTailOverTol;
-  if (const char* e = getenv("XVEC_TAIL_OVER_TOL"))
-    if (*e && atof(e) >= 1.0) tail_over_tol = (float)atof(e);
+  {
+    const std::string e = DebugKnob("tail_over_tol");
+    if (!e.empty() && atof(e.c_str()) >= 1.0) tail_over_tol = (float)atof(e.c_str());
+  }
   auto accepted = [&](const ErrStat& st) { return st.worst <= tol && st.tail <= tol * tail_over_tol; };
   int n_mx = 0, n_mx_hold = 0;
   for (int i = 0; i < n; ++i) {
@@ -1896,7 +1895,7 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
 void Engine::CheckKernelFaults(int lane) const {
   // a stream-K workgroup that gave up waiting for another workgroup's partial tile (bounded spin, kernels.hip) left
   // a word behind on its launch stream; the results of that launch are not to be trusted.  The word belongs to the
-  // stream, i.e. to this engine, and reading it clears it: the caller may retry (XVEC_GEMM_VARIANT=2) or exit cleanly.
+  // stream, i.e. to this engine, and reading it clears it: the caller may retry (XVEC_DEBUG=gemm_variant=2) or exit cleanly.
   // The words of all streams are collected into fault_mask_, but a caller that waited for ONE lane's batch is only told about
   // that lane: a fault of the batch still in flight on the other lane stays recorded until its own WaitHost.
   (void)hipSetDevice(device_);
@@ -1920,14 +1919,31 @@ void Engine::CheckKernelFaults(int lane) const {
   }
   if (err)
     throw EngineError("a stream-K GEMM launch timed out waiting for a partial tile of another workgroup (results invalid); "
-                      "XVEC_GEMM_VARIANT=2 selects the per-tile kernels");
+                      "XVEC_DEBUG=gemm_variant=2 selects the per-tile kernels");
 }
 
 const float* Engine::WaitHost(int slot) {
   if (slot < 0 || slot >= kNumHostSlots) throw EngineError("bad host slot");
   HostSlot& S = host_slots_[slot];
   if (!S.pending) throw EngineError("WaitHost: nothing submitted on this slot");
-  Check(hipEventSynchronize(S.done), "hipEventSynchronize(slot)");
+  // The wait SLEEPS between polls.  hipEventSynchronize spins - a whole core per process for as long as the GPU is the slower side
+  // (3 us of a 9 us host budget per utterance; an event created with hipEventBlockingSync measured the same) - and with three
+  // batches queued per engine a wake-up some tens of microseconds late is never on the GPU's critical path: eight ranks of a node
+  // share its cores.  XVEC_DEBUG=spin_wait=1: the runtime's wait.
+  static const bool spin = [] {
+    return DebugKnobInt("spin_wait", 0) != 0;
+  }();
+  if (spin) {
+    Check(hipEventSynchronize(S.done), "hipEventSynchronize(slot)");
+  } else {
+    for (;;) {
+      const hipError_t q = hipEventQuery(S.done);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) Check(q, "hipEventQuery(slot)");
+      struct timespec ts = {0, 40000};
+      nanosleep(&ts, nullptr);
+    }
+  }
   S.pending = false;   // before the fault check: the slot is free again whatever the launch reported
   CheckKernelFaults(S.lane);
   return (const float*)S.h_out;

@@ -271,8 +271,8 @@ class Engine {
   int slow_prec_ = 0;
   bool has_fast_ = false;
   bool fast_mx_ = false;
-  int p8_whole_ = 0;   // XVEC_P8_WHOLE: partition policy of tdnn_gemm_kernel_p8 (engine.cc)
-  bool use_p8_ = true;      // tdnn_gemm_kernel_p8 for the layers and modes it can run (XVEC_P8=0: never)
+  int p8_whole_ = 0;   // XVEC_DEBUG=p8_whole: partition policy of tdnn_gemm_kernel_p8 (engine.cc)
+  bool use_p8_ = true;      // tdnn_gemm_kernel_p8 for the layers and modes it can run (XVEC_DEBUG=p8=0: never)
   bool fast_mx2_ = false;   // kPrecFp16Mx2: every frame-level layer of a fast chunk runs it (or kPrecFp16x3E on the input)
   // Frame-level log-posteriors in the single-pass fp16 mode: the head's logits stay a 16-bit plane like every other layer's
   // output of that mode (2 instead of 4 bytes per logit written by the head GEMM and read by the LogSoftmax pass: the two

@@ -1,5 +1,8 @@
 // Chunk loop + weighted average.  See extractor.h.
 #include "extractor.h"
+#include "knobs.h"
+
+#include <pthread.h>
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
@@ -15,7 +18,7 @@ namespace xv {
 
 namespace {
 // A few helper threads for the bulk host copies of table jobs (started on first use, alive until exit).  ParallelFor splits
-// [0, n) into contiguous ranges, the caller takes one of them and returns when all are done.  XVEC_COPY_THREADS (default 3
+// [0, n) into contiguous ranges, the caller takes one of them and returns when all are done.  XVEC_DEBUG=copy_threads=n (default 3
 // helpers, 0 = the caller alone).
 class CopyPool {
  public:
@@ -49,11 +52,12 @@ class CopyPool {
  private:
   CopyPool() {
     int t = 3;
-    if (const char* e = getenv("XVEC_COPY_THREADS")) t = std::max(0, std::min(15, atoi(e)));
+    t = std::max(0, std::min(15, DebugKnobInt("copy_threads", t)));
     for (int i = 0; i < t; ++i) workers_.emplace_back([this] { Loop(); });
     for (std::thread& w : workers_) w.detach();
   }
   void Loop() {
+    (void)pthread_setname_np(pthread_self(), "xv-copy");
     unsigned long seen = 0;
     for (;;) {
       int part;

@@ -30,6 +30,7 @@
 //     one frame (32-byte stores per plane); kEpiStats feeds activations as A so the 16-row
 //     reduction is 3 in-register adds + 2 cross-lane adds.
 #include "kernels.h"
+#include "knobs.h"
 
 #include <hip/hip_ext.h>
 
@@ -1456,22 +1457,20 @@ __global__ __launch_bounds__(512) void tdnn_gemm_kernel_v2(const GemmArgs a) {
 
 // Which GEMM variant to launch: 1 = 128x128 / 2-stage, 2 = 256x128 / 3-stage ring, 4 = stream-K (persistent; falls
 // back to 2 / 1 when the launch has too few tiles or an odd shape), 0 = by precision and K length (default, see
-// launch_one).  XVEC_GEMM_VARIANT overrides.
+// launch_one).  XVEC_DEBUG=gemm_variant=... overrides.
 // (function-local static initialisers: thread-safe - the engines of a --devices job launch from a consumer thread each)
 static int gemm_variant() {
   static const int v = [] {
-    const char* e = getenv("XVEC_GEMM_VARIANT");
-    const int x = (e && *e) ? atoi(e) : 0;
+    const int x = DebugKnobInt("gemm_variant", 0);
     return (x != 0 && x != 1 && x != 2 && x != 4) ? 0 : x;
   }();
   return v;
 }
-// Frame fragments per wave of the stream-K variant: 8 (512-row tiles) where the LDS allows, else 4.  XVEC_SK_MF = 4
+// Frame fragments per wave of the stream-K variant: 8 (512-row tiles) where the LDS allows, else 4.  XVEC_DEBUG=sk_mf=4
 // forces the 256-row tiles.
 static int sk_max_mf() {
   static const int v = [] {
-    const char* e = getenv("XVEC_SK_MF");
-    const int x = (e && *e) ? atoi(e) : 8;
+    const int x = DebugKnobInt("sk_mf", 8);
     return (x != 4 && x != 8) ? 8 : x;
   }();
   return v;
@@ -3247,8 +3246,7 @@ static hipError_t launch_one_sk(const GemmArgs& a, hipStream_t s) {
     {
       // column lanes: the largest of 4, 2, 1 that divides the column tiles and the workgroups of an XCD block
       static const int max_lanes = [] {
-        const char* e = getenv("XVEC_SK_LANES");
-        const int x = (e && *e) ? atoi(e) : 4;
+        const int x = DebugKnobInt("sk_lanes", 4);
         return (x != 1 && x != 2 && x != 4) ? 4 : x;
       }();
       int l = max_lanes;
@@ -3315,7 +3313,7 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < b.ngrp_lo; ++i) b.p8_ktiles_lo += (b.grp[b.ngrp + i].ksteps >> 1) * b.grp[b.ngrp + i].nshift;
   }
   b.p8 = 1;
-  // GemmArgs::p8_whole as the caller's policy (Engine: XVEC_P8_WHOLE): 0 = K tiles dealt out evenly over the workgroups (stream-K
+  // GemmArgs::p8_whole as the caller's policy (Engine: XVEC_DEBUG=p8_whole): 0 = K tiles dealt out evenly over the workgroups (stream-K
   // exchange; the default), 1 = whole tiles for every launch, 2 = whole tiles for layers of at most 8 K tiles per output tile
   b.p8_whole = (a.p8_whole == 1 || (a.p8_whole == 2 && b.p8_ktiles + b.p8_ktiles_lo <= 8)) ? 1 : 0;
   b.sk_mtiles = a.m_tiles >> 1;
@@ -3326,6 +3324,15 @@ static hipError_t launch_one_p8(const GemmArgs& a, hipStream_t s) {
   // as the CUs allow, but every group's share must hold at least one whole tile
   int l = 4;
   while (l > 1 && (nt % l || (grid / 8) % l)) l >>= 1;
+  // Column tiles in threes (1536 = 6, 768 = 3 tiles of 256: the statistics layer, the 650-wide layers of the c-vector network):
+  // with two lanes - or one - every workgroup walks its row tile's frames once per column tile, 16 to 32 row tiles are in flight
+  // per XCD (4 - 8 MB of frames against 4 MB of L2), and every pass after the first misses: 578 MB per tdnn5 launch for a 105 MB
+  // plane (profiles/r05w_pmc_hbm.md).  As many lanes as column tiles instead: the lanes of a group walk the SAME row tile at the
+  // same time, the first brings a line into the XCD's L2 and the others find it there.  The workgroups of an XCD block are
+  // then a multiple of 3 (30 of 32 CUs); the partition is bit-identical whatever the cut.
+  // (same box, A/B: tdnn5 of the x-vector 572 -> 245 MB per launch at the same 0.205 ms; the 768-wide layers of the c-vector
+  // network 1141 -> 330 MB and 721 -> 285 MB, their launches +2.5 % on their own and the two-lane step -3.5 % - profiles/r06_lanes.md)
+  if (nt % 3 == 0 && nt <= 6 && grid / 8 >= nt) l = nt;
   b.sk_lanes = l;
   const int tiles_min = std::max(1, (b.sk_mtiles / 8) * (nt / l));
   grid = 8 * l * std::min(grid / 8 / l, tiles_min);
@@ -3357,13 +3364,9 @@ static hipError_t launch_one_v2(const GemmArgs& a, hipStream_t s) {
   build_groups(&b);
   if constexpr (PrecMx2(PREC)) build_lo_groups(&b);
   {
-    // stagger window = XVEC_GEMM_STAGGER percent of the modelled tile time (K steps x ~2200 cycles in split mode,
+    // stagger window = gemm_stagger (XVEC_DEBUG) percent of the modelled tile time (K steps x ~2200 cycles in split mode,
     // ~1000 single pass, + ~14000 fixed)
-    static int pct = -1;
-    if (pct < 0) {
-      const char* e = getenv("XVEC_GEMM_STAGGER");
-      pct = (e && *e) ? atoi(e) : 85;
-    }
+    static const int pct = DebugKnobInt("gemm_stagger", 85);
     const int cus = device_cu_count();
     b.stagger_wgs = cus;
     b.stagger_units = ((int)grid.x > 2 * cus) ? (int)(((long)b.total_ksteps * (400 + 600 * PrecPasses(PREC)) + 14000) * pct / 100 / 2048) : 0;

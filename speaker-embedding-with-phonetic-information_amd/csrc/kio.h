@@ -12,6 +12,8 @@
 
 #include <memory>
 #include <stdexcept>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -35,7 +37,7 @@ class Input {
   // rxfilename forms: "file", "file:123", "-", "cmd args |"
   // drain_pipe: for "cmd |" inputs, a second thread does the read(2) calls and the parser consumes from a ring of 1 MiB
   // blocks (feature archives through a pipe, extract_xvectors_new.sh:79: the syscalls and the kernel's copy out of the pipe
-  // buffer then overlap the parsing and the copy into the batch; XVEC_PIPE_DRAIN=0 turns it off)
+  // buffer then overlap the parsing and the copy into the batch; XVEC_DEBUG=pipe_drain=0 turns it off)
   void Open(const std::string& rxfilename, bool drain_pipe = false);
   void OpenMemory(const void* data, size_t n);
   void Seek(long offset);           // regular files / memory only
@@ -60,6 +62,7 @@ class Input {
   bool is_pipe_ = false, is_stdin_ = false;
   const unsigned char* mem_ = nullptr;
   size_t mem_n_ = 0, mem_pos_ = 0;
+  bool mapped_ = false;   // mem_ is this object's read-only mapping of a regular file (Open): unmapped by Close
   std::string name_;
   std::unique_ptr<PipeDrain> drain_;
 };
@@ -103,8 +106,12 @@ void SkipScalar(Input& in, bool binary);
 struct Matrix {
   int rows = 0, cols = 0;
   std::vector<float> data;  // row-major, no padding
+  // A VIEW instead of a copy (ViewIndexedMatrix): rows x cols floats that live in a mapped archive file.  The address has the
+  // alignment the archive gave it (a key of any length precedes the object): memcpy from it, never dereference it as float.
+  const float* ext = nullptr;
+  const float* Data() const { return ext ? ext : data.data(); }
   float* Row(int r) { return data.data() + (size_t)r * cols; }
-  const float* Row(int r) const { return data.data() + (size_t)r * cols; }
+  const float* Row(int r) const { return Data() + (size_t)r * cols; }
 };
 
 // Reads FM / DM / CM / CM2 / CM3 (binary) or " [ ... ]" (text).
@@ -183,6 +190,30 @@ class MatrixTableIndexer {
 };
 // Reads the matrix an index entry points to.  `in` / `in_path` cache the open data file between calls of one thread.
 void ReadIndexedMatrix(const MatrixTableIndexer::Entry& e, Input* in, std::string* in_path, Matrix* m);
+// The same without touching the data: for a binary FLOAT matrix ("FM") at a known offset of a regular file, *m becomes a view of
+// the file's pages (the file is mapped read-only once per FileMapper and path, and stays mapped while the FileMapper lives - a
+// job owns one, so every view dies before the mapping does and a file rewritten between two jobs of one process is mapped
+// anew).  The one host copy of such an utterance is then the one into the device's pinned staging buffer (table_extract.cc) -
+// read(2) into a buffer of its own first was half of the host time of a table job.  false: anything else
+// (compressed or double matrices, text, pipes, a header that does not check out): the caller reads it with ReadIndexedMatrix,
+// which also words the error.  Thread-safe.
+class FileMapper {
+ public:
+  FileMapper() = default;
+  ~FileMapper();
+  FileMapper(const FileMapper&) = delete;
+  FileMapper& operator=(const FileMapper&) = delete;
+  bool View(const MatrixTableIndexer::Entry& e, Matrix* m);
+
+ private:
+  struct Mapped {
+    const uint8_t* base = nullptr;
+    size_t size = 0;
+  };
+  Mapped Map(const std::string& path);
+  std::mutex mu_;
+  std::map<std::string, Mapped> maps_;   // by path; a file that could not be mapped is remembered with base == nullptr
+};
 
 // Sequential reader of a table of float vectors ("ark:..." or "scp:...").  A corrupt archive is fatal (KioError),
 // an unreadable scp entry is reported through `error` and reading continues.

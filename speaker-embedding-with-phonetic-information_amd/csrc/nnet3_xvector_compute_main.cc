@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "knobs.h"
 #include "extractor.h"
 #include "kio.h"
 #include "nnet3_raw.h"
@@ -415,13 +416,13 @@ int main(int argc, char** argv) {
       dev_list.clear();
     }
     std::vector<std::unique_ptr<xv::Engine>> engines;
-    // test knob: XVEC_ENGINES_ON_ONE_DEVICE=n builds n engines on the ONE device (each from the host image, no RCCL - the library
+    // test knob: XVEC_DEBUG=engines_on_one_device=n builds n engines on the ONE device (each from the host image, no RCCL - the library
     // refuses two ranks on one device), so that the several-engine path of the table loop (a consumer thread per engine, ordered
     // writer) can be exercised on a one-GPU box.  No speed-up to be had from it.
-    const int n_same = getenv("XVEC_ENGINES_ON_ONE_DEVICE") ? atoi(getenv("XVEC_ENGINES_ON_ONE_DEVICE")) : 0;
+    const int n_same = xv::DebugKnobInt("engines_on_one_device", 0);
     if (dev_list.empty() && n_same > 1 && n_same <= 8 && !g_frame_job) {
       for (int i = 0; i < n_same; ++i) engines.emplace_back(new xv::Engine(blob.data(), blob.size(), device));
-      XLOG("XVEC_ENGINES_ON_ONE_DEVICE: " << n_same << " engines on device " << device << " (test knob)");
+      XLOG("XVEC_DEBUG=engines_on_one_device: " << n_same << " engines on device " << device << " (test knob)");
     } else if (dev_list.empty()) {
       engines.emplace_back(new xv::Engine(blob.data(), blob.size(), device));
     } else {

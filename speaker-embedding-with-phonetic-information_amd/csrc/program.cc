@@ -1,5 +1,6 @@
 // Graph lowering.  See program.h.
 #include "program.h"
+#include "knobs.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -227,10 +228,9 @@ TdnnProgram LowerToProgram(const RawNnet& net, const std::string& output_name) {
   for (const AffineLayer& L : p.layers)
     for (const LayerSource& s : L.src)
       if (std::abs(s.offset) > 15) throw KioError("time offsets beyond +-15 frames are not supported (layer " + L.name + ")");
-  // XVEC_BN_FOLD=1 (opt-in, measured in round 5 and NOT the default - see FoldBatchNormIntoConsumers): move the BatchNorm of
+  // XVEC_DEBUG=bn_fold=1 (opt-in, measured in round 5 and NOT the default - see FoldBatchNormIntoConsumers): move the BatchNorm of
   // every frame-level layer that only feeds other layers into those consumers
-  const char* e = getenv("XVEC_BN_FOLD");
-  if (e && *e && atoi(e) == 1) FoldBatchNormIntoConsumers(&p);
+  if (DebugKnobInt("bn_fold", 0) == 1) FoldBatchNormIntoConsumers(&p);
   return p;
 }
 
@@ -251,14 +251,17 @@ TdnnProgram LowerToProgram(const RawNnet& net, const std::string& output_name) {
 // it) being INCOHERENT over the frames of a chunk, so that the statistics pooling averages them - which they are when the
 // plane holds a centred variable (a trained BatchNorm's output has zero mean by construction), and are not when it holds a
 // non-negative one: sum_k E[r_k] * delta_k is the same in every frame, and e2m1 rounds the small entries of a non-negative
-// fragment towards zero systematically.  Parity outranks 3 %: the fold is OFF unless XVEC_BN_FOLD=1 asks for it.  Nothing
+// fragment towards zero systematically.  Parity outranks 3 %: the fold is OFF unless XVEC_DEBUG=bn_fold=1 asks for it.  Nothing
 // changes for the kernels either way: the producer's epilogue applies "scale, offset" - folded, they are (2^e, 0).  The pooled
 // layer (its statistics are the consumer) and the output layer keep their BatchNorm.
 void FoldBatchNormIntoConsumers(TdnnProgram* p) {
   const int n = (int)p->layers.size();
-  // XVEC_BN_FOLD_MASK (diagnostic): bit i = fold layer i of xv_model_describe's table; default: every layer that qualifies
+  // XVEC_DEBUG=bn_fold_mask=... (diagnostic): bit i = fold layer i of xv_model_describe's table; default: every layer that qualifies
   unsigned long long only = ~0ull;
-  if (const char* m = getenv("XVEC_BN_FOLD_MASK")) only = strtoull(m, nullptr, 0);
+  {
+    const std::string m = DebugKnob("bn_fold_mask");
+    if (!m.empty()) only = strtoull(m.c_str(), nullptr, 0);
+  }
   for (int i = 0; i < n; ++i) {
     AffineLayer& S = p->layers[i];
     if (S.segment_level || !S.relu || !S.bn || S.log_softmax || i == p->pooled_layer || i == p->output_layer) continue;

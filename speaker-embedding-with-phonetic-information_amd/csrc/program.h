@@ -62,7 +62,7 @@ struct TdnnProgram {
 // with a precise message when the graph is outside the supported grammar.
 TdnnProgram LowerToProgram(const RawNnet& net, const std::string& output_name);
 // Moves the BatchNorm of every frame-level relu + batchnorm layer that only feeds other layers into those consumers (program.cc);
-// applied by LowerToProgram only when XVEC_BN_FOLD=1 (opt-in; measured in round 5: +3.4 % throughput, but the fast arithmetics'
+// applied by LowerToProgram only when XVEC_DEBUG=bn_fold=1 (opt-in; measured in round 5: +3.4 % throughput, but the fast arithmetics'
 // weight-side errors stop averaging out over the frames of a chunk - program.cc).
 void FoldBatchNormIntoConsumers(TdnnProgram* p);
 

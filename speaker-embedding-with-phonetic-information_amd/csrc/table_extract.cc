@@ -1,13 +1,18 @@
 // Table-driven extraction loop.  See table_extract.h.
 #include "table_extract.h"
 
+#include <dirent.h>
 #include <math.h>
+#include <pthread.h>
+#include <sys/resource.h>
+#include <sys/time.h>
 #include <memory>
 #include <string.h>
 
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <fstream>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -16,6 +21,7 @@
 
 #include "backend.h"
 #include "calib_file.h"
+#include "knobs.h"
 #include "kio.h"
 
 namespace xv {
@@ -230,6 +236,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
   std::unique_ptr<RandomAccessVectorReader> vad;
   if (!opt.vad_rspecifier.empty()) vad.reset(new RandomAccessVectorReader(opt.vad_rspecifier));
   TableWriter writer(vec_wspec);
+  FileMapper mapper;   // declared before everything that can hold a view of its mappings (batches, work slots, reader threads)
   std::mutex mu;
   std::condition_variable cv;
   std::deque<Batch> queue;
@@ -255,7 +262,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
   // Everything that can fail on a user error happens before a thread exists (the indexer opens the table here).
   const bool opt_is_scp = ParseRspecifier(feat_rspec).is_scp;
   int n_readers = std::min(16, 4 * NE);
-  if (const char* e = getenv("XVEC_READERS")) n_readers = std::max(1, std::min(16, atoi(e)));
+  n_readers = std::max(1, std::min(16, DebugKnobInt("readers", n_readers)));
   std::unique_ptr<MatrixTableIndexer> indexer;
   if (n_readers > 1) {
     indexer.reset(new MatrixTableIndexer(feat_rspec));
@@ -397,6 +404,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     cv.notify_all();
   };
   auto index_pass = [&] {
+    (void)pthread_setname_np(pthread_self(), "xv-index");
     try {
       index_pass_body();
     } catch (const std::exception& ex) {
@@ -405,6 +413,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
       reader_failed("unknown error in the index pass");
     }
   };
+  const bool use_views = DebugKnobInt("mmap", 1) != 0;
   auto parallel_reader_body = [&] {
     Input in;
     std::string in_path;
@@ -430,7 +439,9 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
       for (MatrixTableIndexer::Entry& e : pb.entries) {
         Utt u;
         try {
-          ReadIndexedMatrix(e, &in, &in_path, &u.feats);
+          // a float matrix in a regular file is not read at all: the utterance is a view of the mapped archive, and its bytes
+          // are touched once, by the copy into the pinned staging buffer
+          if (!use_views || !mapper.View(e, &u.feats)) ReadIndexedMatrix(e, &in, &in_path, &u.feats);
         } catch (const std::exception& ex) {
           if (e.offset >= 0 && !opt_is_scp) {   // a damaged archive is fatal, as in the sequential reader
             std::unique_lock<std::mutex> lk(mu);
@@ -460,6 +471,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     }
   };
   auto parallel_reader = [&] {
+    (void)pthread_setname_np(pthread_self(), "xv-read");
     try {
       parallel_reader_body();
     } catch (const std::exception& ex) {
@@ -550,6 +562,8 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
   } reader_guard{threads, mu, cv, stop};
 
   const auto t0 = std::chrono::steady_clock::now();
+  struct rusage ru0;
+  getrusage(RUSAGE_SELF, &ru0);
   const bool has_backend = !opt.backend_mean.empty() || !opt.backend_transform.empty() || opt.backend_normalize;
   std::string fatal;
   std::mutex fatal_mu;
@@ -723,7 +737,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
             ++C.num_fail;
             continue;
           }
-          uptr.push_back(u.feats.data.data());
+          uptr.push_back(u.feats.Data());
           urows.push_back(u.feats.rows);
           idx.push_back((int)i);
         }
@@ -763,7 +777,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
               }
             }
             keep_idx.push_back(idx[k]);
-            rawp.push_back(u.feats.data.data());
+            rawp.push_back(u.feats.Data());
             vadp.push_back(v ? v->data() : nullptr);
             rrows.push_back(T);
           }
@@ -941,7 +955,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
           try {
             std::vector<CalibUtt> cu;
             for (const Batch& hb : held)
-              for (const Utt& u : hb.utts) cu.push_back(CalibUtt{&u.key, u.feats.data.data(), u.feats.rows, u.feats.cols});
+              for (const Utt& u : hb.utts) cu.push_back(CalibUtt{&u.key, u.feats.Data(), u.feats.rows, u.feats.cols});
             if (!cu.empty()) {
               log("LOG", "calibration sample: the first " + std::to_string(std::min(cu.size(), (size_t)opt.calibrate_utts)) +
                              " utterances of the stream (a stream cannot be sampled any other way)");
@@ -994,6 +1008,42 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     m << "consumer stages" << (NE > 1 ? " (summed over the engines' threads)" : "") << ": wait for reader " << t_wait << " s, pack "
       << t_pack << " s, plan+submit " << t_start << " s, finish+write " << t_fin << " s";
     log("LOG", m.str());
+    // host budget of the table loop: CPU seconds of ALL threads of the process (readers, copy threads, consumers, writer, the
+    // runtime's own) between the first batch and the last write - what eight ranks on one node have to share
+    struct rusage ru1;
+    getrusage(RUSAGE_SELF, &ru1);
+    auto tv = [](const timeval& a, const timeval& b) { return (double)(b.tv_sec - a.tv_sec) + 1e-6 * (double)(b.tv_usec - a.tv_usec); };
+    const double user = tv(ru0.ru_utime, ru1.ru_utime), sys = tv(ru0.ru_stime, ru1.ru_stime);
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const long n_all = res.num_success + res.num_fail;
+    std::ostringstream h;
+    h.precision(4);
+    h << "host cost of the table loop: " << user << " s user + " << sys << " s system over " << wall << " s = " << (user + sys) / std::max(wall, 1e-9)
+      << " cores; " << (n_all ? 1e6 * (user + sys) / n_all : 0.0) << " us of CPU per utterance (" << n_all << " utterances, "
+      << (ru1.ru_minflt - ru0.ru_minflt) << " minor page faults)";
+    log("LOG", h.str());
+    // ... and who spent it: CPU seconds per thread NAME since the threads were created (/proc/self/task/*/schedstat; the HIP
+    // runtime's own threads carry the process name)
+    std::map<std::string, std::pair<double, int>> by_name;
+    if (DIR* d = opendir("/proc/self/task")) {
+      while (dirent* de = readdir(d)) {
+        if (de->d_name[0] == '.') continue;
+        const std::string base = std::string("/proc/self/task/") + de->d_name;
+        std::ifstream c(base + "/comm"), st(base + "/schedstat");
+        std::string name;
+        unsigned long long ns = 0;
+        if (std::getline(c, name) && (st >> ns)) {
+          by_name[name].first += 1e-9 * (double)ns;
+          by_name[name].second += 1;
+        }
+      }
+      closedir(d);
+    }
+    std::ostringstream t;
+    t.precision(3);
+    t << "CPU seconds by thread name (threads):";
+    for (const auto& kv : by_name) t << " " << kv.first << " " << kv.second.first << " (" << kv.second.second << ")";
+    log("LOG", t.str());
   }
   {
     std::unique_lock<std::mutex> lk(mu);
@@ -1027,7 +1077,7 @@ TableExtractResult RunTableCompute(Engine* engine, int max_batch_rows, bool appl
     offs.assign(1, 0);
     size_t r = 0;
     for (const Utt& u : batch) {
-      memcpy(&packed[r * D], u.feats.data.data(), (size_t)u.feats.rows * D * 4);
+      memcpy(&packed[r * D], u.feats.Data(), (size_t)u.feats.rows * D * 4);
       r += u.feats.rows;
       offs.push_back((int32_t)r);
     }

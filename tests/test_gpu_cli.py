@@ -106,7 +106,7 @@ def test_cli_truncated_archive_is_an_error_at_index_time(job):
     written = [k for k, _ in kio.read_ark(str(d / "cut_out.ark"), "vector")]
     good = [k for k, x in utts[:-1] if x.shape[0] > 0]      # (--pad-input: the 10-frame utterance is padded to 25; the empty one fails)
     assert written == good, (written, good)
-    env = dict(os.environ, XVEC_READERS="1")    # the sequential reader: the same verdict
+    env = dict(os.environ, XVEC_DEBUG="readers=1")    # the sequential reader: the same verdict
     r = _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine",
               str(d / "final.raw"), "ark:%s/cut.ark" % d, "ark:/dev/null"], env=env)
     assert r.returncode == 255 and b"unexpected end of file" in r.stderr, r.stderr.decode()[-600:]

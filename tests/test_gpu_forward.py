@@ -523,15 +523,15 @@ def test_calibration_mixes_the_two_fast_arithmetics_on_the_cvector_network():
 
 
 def test_bn_fold_opt_in_is_the_same_function(monkeypatch):
-    """XVEC_BN_FOLD=1 (csrc/program.cc FoldBatchNormIntoConsumers, profiles/r05_bn_fold.md): the folded program computes the same
+    """XVEC_DEBUG=bn_fold=1 (csrc/program.cc FoldBatchNormIntoConsumers, profiles/r05_bn_fold.md): the folded program computes the same
     function - the parity-grade arithmetic agrees with the fp64 oracle as closely as the unfolded one, the shipped default stays
     within the bar - on the x-vector and on the two-branch c-vector graph (a consumer with two folded sources)."""
     P = H.pkg()
     for topology in ("v2_xvector", "v5_cvector"):
         net, line = H.synth_model(topology)
-        monkeypatch.setenv("XVEC_BN_FOLD", "1")
+        monkeypatch.setenv("XVEC_DEBUG", "bn_fold=1")
         model = P.Model(raw=net.to_bytes(True), nnet_config=line)
-        monkeypatch.delenv("XVEC_BN_FOLD")
+        monkeypatch.delenv("XVEC_DEBUG")
         assert "bn(folded)" in model.describe()
         ev64 = _oracle(net, line, np.float64)
         utts = [H.features(4400 + i, T) for i, T in enumerate([400, 21, 137, 333])]

@@ -340,7 +340,7 @@ def test_cli_devices_all_on_a_multi_gpu_node_equals_one_gpu(tmp_path):
 
 def test_cli_several_engines_threaded_consumers_write_the_one_engine_archive(tmp_path):
     """The several-engine table loop (a consumer thread per engine, batches dealt round-robin, the calling thread writes in
-    table order) on a ONE-GPU box: XVEC_ENGINES_ON_ONE_DEVICE=3 builds three engines on device 0 (test knob, no RCCL).  Archive
+    table order) on a ONE-GPU box: XVEC_DEBUG=engines_on_one_device=3 builds three engines on device 0 (test knob, no RCCL).  Archive
     and script file are those of the one-engine job byte for byte - with calibration on (the choice of engine 0 is shared), with
     utterances that fail in different places (empty, too short, wrong dimension), for two batch sizes."""
     utts = _cli_job(tmp_path, 400)
@@ -351,7 +351,7 @@ def test_cli_several_engines_threaded_consumers_write_the_one_engine_archive(tmp
     for bf in ("4096", "20000"):
         r0 = _cli(tmp_path, "one" + bf, ["--batch-frames=" + bf])
         assert r0.returncode == 0, r0.stderr[-2000:]
-        r1 = _cli(tmp_path, "three" + bf, ["--batch-frames=" + bf], env={"XVEC_ENGINES_ON_ONE_DEVICE": "3", "XVEC_TIMING": "1"})
+        r1 = _cli(tmp_path, "three" + bf, ["--batch-frames=" + bf], env={"XVEC_DEBUG": "engines_on_one_device=3", "XVEC_TIMING": "1"})
         assert r1.returncode == 0 and "3 engines on device" in r1.stderr, r1.stderr[-2000:]
         assert "summed over the engines' threads" in r1.stderr
         assert (tmp_path / ("three%s.ark" % bf)).read_bytes() == (tmp_path / ("one%s.ark" % bf)).read_bytes()
@@ -374,7 +374,7 @@ def test_cli_several_engines_threaded_consumers_write_the_one_engine_archive(tmp
                "--backend-normalize-length=true"]
     q0 = _cli(tmp_path, "fe_one", fe_args)
     assert q0.returncode == 0, q0.stderr[-2000:]
-    q1 = _cli(tmp_path, "fe_three", fe_args, env={"XVEC_ENGINES_ON_ONE_DEVICE": "3"})
+    q1 = _cli(tmp_path, "fe_three", fe_args, env={"XVEC_DEBUG": "engines_on_one_device=3"})
     assert q1.returncode == 0 and "3 engines on device" in q1.stderr, q1.stderr[-2000:]
     assert (tmp_path / "fe_three.ark").read_bytes() == (tmp_path / "fe_one.ark").read_bytes()
     assert done(q0).split("Done")[-1] == done(q1).split("Done")[-1], (done(q0), done(q1))
@@ -386,7 +386,7 @@ def test_cli_several_engines_threaded_consumers_write_the_one_engine_archive(tmp
     r = subprocess.run([exe, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=tdnn6.affine",
                         "--batch-frames=4096", str(tmp_path / "final.raw"), "ark:%s/cut.ark" % tmp_path, "ark:%s/cut_out.ark" % tmp_path],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
-                       env=dict(os.environ, XVEC_ENGINES_ON_ONE_DEVICE="2"))
+                       env=dict(os.environ, XVEC_DEBUG="engines_on_one_device=2"))
     assert r.returncode != 0, r.stderr[-1500:]
     got = list(kio.read_ark(str(tmp_path / "cut_out.ark"), "vector")) if os.path.getsize(tmp_path / "cut_out.ark") else []
     ref = dict(kio.read_ark(str(tmp_path / "one4096.ark"), "vector"))

@@ -1,6 +1,6 @@
 """The stream-K GEMM variant (persistent grid, tiles split along K between neighbouring workgroups, 256- or 512-row
 tiles) accumulates every output element in the plain K order, so it must reproduce the per-tile kernels bit for bit.
-The variant is chosen per process (XVEC_GEMM_VARIANT, XVEC_SK_MF), hence the child processes."""
+The variant is chosen per process (XVEC_DEBUG=gemm_variant=...,sk_mf=...), hence the child processes."""
 import os
 import subprocess
 import sys
@@ -32,9 +32,9 @@ def _run(tmp_path, tag, env, *args):
 ])
 def test_stream_k_is_bit_identical_to_per_tile_kernels(tmp_path, prec, topology, n, T, ragged):
     args = [topology, prec, n, T] + (["ragged"] if ragged else [])
-    ref = _run(tmp_path, "v2", {"XVEC_GEMM_VARIANT": "2"}, *args)
-    sk8 = _run(tmp_path, "sk8", {"XVEC_GEMM_VARIANT": "4", "XVEC_SK_MF": "8"}, *args)
-    sk4 = _run(tmp_path, "sk4", {"XVEC_GEMM_VARIANT": "4", "XVEC_SK_MF": "4"}, *args)
+    ref = _run(tmp_path, "v2", {"XVEC_DEBUG": "gemm_variant=2"}, *args)
+    sk8 = _run(tmp_path, "sk8", {"XVEC_DEBUG": "gemm_variant=4,sk_mf=8"}, *args)
+    sk4 = _run(tmp_path, "sk4", {"XVEC_DEBUG": "gemm_variant=4,sk_mf=4"}, *args)
     assert np.isfinite(ref).all()
     assert np.array_equal(ref, sk4)
     assert np.array_equal(ref, sk8)

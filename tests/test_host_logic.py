@@ -403,15 +403,15 @@ def test_blob_layer_table_is_validated_before_anything_becomes_a_device_pointer(
 
 
 def test_bn_fold_is_opt_in_and_moves_the_mantissa_into_the_consumer(monkeypatch):
-    """XVEC_BN_FOLD=1 (csrc/program.cc FoldBatchNormIntoConsumers; OFF by default - measured in round 5, it costs the fast
+    """XVEC_DEBUG=bn_fold=1 (csrc/program.cc FoldBatchNormIntoConsumers; OFF by default - measured in round 5, it costs the fast
     arithmetics the averaging of their weight-side errors): the packed image of tdnn4 then holds W * diag(m) with m the mantissa
     of tdnn3.batchnorm's scale, and the describe table says which layers gave their BatchNorm away."""
     net = H.nm.synthesize(H.tiny_config(), seed=3)
     plain = P.Model(raw=net.to_bytes(True))
     assert "folded" not in plain.describe()
-    monkeypatch.setenv("XVEC_BN_FOLD", "1")
+    monkeypatch.setenv("XVEC_DEBUG", "bn_fold=1")
     folded = P.Model(raw=net.to_bytes(True))
-    monkeypatch.delenv("XVEC_BN_FOLD")
+    monkeypatch.delenv("XVEC_DEBUG")
     d = folded.describe()
     assert d.count("bn(folded)") == 4 and "tdnn5.batchnorm" in d     # tdnn1-4 feed other layers; tdnn5 feeds the pooling
     blob = folded.pack(P.PREC_BF16X3)

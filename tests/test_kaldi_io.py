@@ -153,13 +153,13 @@ def test_archive_through_a_pipe_is_drained_by_a_second_thread(tmp_path):
     """`ark:cmd |` - the form extract_xvectors_new.sh:79 feeds features in: a drain thread does the read(2) calls into a ring of
     1 MiB blocks, the parser consumes from it (kio.cc PipeDrain).  A large archive (many ring wrap-arounds, matrices that
     straddle blocks), compressed and text objects, a slow producer and an early close must all behave exactly like the plain
-    stdio path (XVEC_PIPE_DRAIN=0) and like the file."""
+    stdio path (XVEC_DEBUG=pipe_drain=0) and like the file."""
     rng = np.random.default_rng(3)
     utts = [("u%04d" % i, rng.standard_normal((int(rng.integers(1, 900)), 23)).astype(np.float32)) for i in range(700)]   # ~29 MB
     src = str(tmp_path / "big.ark")
     kio.write_ark_matrices(src, utts)
     want = open(src, "rb").read()
-    for env in ({}, {"XVEC_PIPE_DRAIN": "0"}):
+    for env in ({}, {"XVEC_DEBUG": "pipe_drain=0"}):
         dst = str(tmp_path / ("out%d.ark" % len(env)))
         r = _run("copy-feats", "ark:cat %s |" % src, "ark:" + dst, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr.decode()[-500:]

@@ -51,7 +51,7 @@ def main():
     loop = float(m.group(1)) if m else None
     print(json.dumps({"input": "pipe" if pipe else "file", "utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
                       "loop_s": loop, "loop_utt_per_s": n / loop if loop else None,
-                      "feature_GB": n * T * 23 * 4 / 1e9, "frames_per_s": n * T / loop if loop else None, "topology": topo, "tail": [l for l in err.strip().splitlines() if "stages" in l or "calibration" in l or "Done" in l or "WaitHost" in l]}))
+                      "feature_GB": n * T * 23 * 4 / 1e9, "frames_per_s": n * T / loop if loop else None, "topology": topo, "tail": [l for l in err.strip().splitlines() if "stages" in l or "calibration" in l or "Done" in l or "WaitHost" in l or "host cost" in l or "CPU seconds" in l]}))
     for fn in os.listdir(d):
         os.remove(os.path.join(d, fn))
     os.rmdir(d)

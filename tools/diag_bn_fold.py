@@ -1,5 +1,5 @@
 """GPU box: which layer's folded BatchNorm moves the error of the fast arithmetics?  One model, 32 chunks of 400 frames, each
-fast mode against the fp64 oracle with XVEC_BN_FOLD_MASK = nothing / one layer at a time / everything (a fresh process per
+fast mode against the fp64 oracle with XVEC_DEBUG=bn_fold_mask = nothing / one layer at a time / everything (a fresh process per
 setting: the mask is read when the model is lowered).  usage: diag_bn_fold.py [v2|v5] [trained seed | init]"""
 import os
 import subprocess
@@ -31,6 +31,6 @@ if len(sys.argv) > 3 and sys.argv[3] == "--worker":
 which, seed = (sys.argv[1] if len(sys.argv) > 1 else "v2"), (sys.argv[2] if len(sys.argv) > 2 else "11")
 masks = [("none", "0"), ("all", str((1 << 63) - 1))] + [("layer %d" % i, str(1 << i)) for i in range(4 if which == "v2" else 9)]
 for name, m in masks:
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), which, seed, "--worker"], env=dict(os.environ, XVEC_BN_FOLD_MASK=m),
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), which, seed, "--worker"], env=dict(os.environ, XVEC_DEBUG="bn_fold=1,bn_fold_mask=%s" % m),
                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     print("%s %s fold %-8s %s" % (which, seed, name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "FAILED"), flush=True)

@@ -86,7 +86,7 @@ def main():
         inject = None
     if not os.path.exists(lib):
         raise SystemExit("no fuzz build at %s (make -C speaker-embedding-with-phonetic-information_amd/csrc fuzz)" % lib)
-    families = [("p8", {}), ("sk", {"XVEC_P8": "0"}), ("v2", {"XVEC_GEMM_VARIANT": "2"})]
+    families = [("p8", {}), ("sk", {"XVEC_DEBUG": "p8=0"}), ("v2", {"XVEC_DEBUG": "gemm_variant=2"})]
     # (mode, lite mask): the mixtures run fp16mxe (a lite layer that still writes its residual plane) and fp16mx layers inside fp16mx2
     modes = [("fp16mx", 0), ("fp16mx2", 0), ("fp16mx2", 0b0101010), ("fp16mx2", 0b1111100), ("fp16x3", 0), ("fp16x2", 0), ("fp16", 0), ("bf16", 0)]
     shapes = [(256, 400, 0), (97, 300, 1), (5, 137, 0)]

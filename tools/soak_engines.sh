@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the several-engine table loop (consumer thread per engine, ordered writer; XVEC_ENGINES_ON_ONE_DEVICE test knob) against
+# GPU box: the several-engine table loop (consumer thread per engine, ordered writer; XVEC_DEBUG=engines_on_one_device test knob) against
 # the one-engine job, many times over batch sizes and engine counts: archives must be byte-identical.  usage: tools/soak_engines.sh [rounds]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 N=${1:-30}
@@ -24,7 +24,7 @@ for i in $(seq 1 $N); do
   bf=$(( (RANDOM % 60 + 2) * 1024 ))
   ne=$(( RANDOM % 4 + 2 ))
   $B $A --batch-frames=$bf $D/final.raw ark:$D/feats.ark ark:$D/one.ark 2> $D/one.log || { echo "one-engine job failed"; bad=$((bad+1)); }
-  XVEC_ENGINES_ON_ONE_DEVICE=$ne timeout 120 $B $A --batch-frames=$bf $D/final.raw ark:$D/feats.ark ark:$D/many.ark 2> $D/many.log || { echo "round $i: $ne engines, batch-frames $bf: exit $?"; bad=$((bad+1)); }
+  XVEC_DEBUG=engines_on_one_device=$ne timeout 120 $B $A --batch-frames=$bf $D/final.raw ark:$D/feats.ark ark:$D/many.ark 2> $D/many.log || { echo "round $i: $ne engines, batch-frames $bf: exit $?"; bad=$((bad+1)); }
   cmp -s $D/one.ark $D/many.ark || { echo "round $i: $ne engines, batch-frames $bf: archives differ"; bad=$((bad+1)); }
 done
 echo "soak: $N rounds, $bad problems"
