@@ -12,8 +12,10 @@ Rank 0 prints ONE JSON line.
            weights at start-up - SURVEY.md §8(e))
   dtype    the arithmetic the dominant kernel computed in.  Default `--precision default` = what every entry point of the
            library ships (XV_PREC_DEFAULT): the model is packed for fp16mx2 (fp16 MFMA + two block-scaled 4-bit products for the
-           rounding residuals of weights and activations, 1.5 passes) and - like nnet3-xvector-compute does on its own table -
-           calibrated on 64 chunks spread evenly over the workload, outside the timed region: the lighter fp16mx (1.25 passes)
+           rounding residuals of weights and activations, 1.5 passes - what the command-line tools run when nothing else is
+           said, a function of the model alone: `other_modes.fp16mx2`) and then MEASURED like a recipe's shared calibration
+           file is (xv_ctx_calibrate = `nnet3-xvector-compute --calibration=<file>` on this table):
+           64 chunks spread evenly over the workload, outside the timed region: the lighter fp16mx (1.25 passes)
            runs only if its worst embedding stays within 7.5e-5 of the three-pass fp16x3 result, which it does on this model
            (Kaldi's initialisation distribution, what BASELINE.json asks for) and does not on the heavy-tailed model of
            `parity_trained_like_model`, where the same policy keeps fp16mx2.  `config.calibration` holds what was measured and
@@ -303,8 +305,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="default", choices=sorted(PRECISION_NOTES),
-                    help="default = what the command-line tools ship (XV_PREC_DEFAULT): the context is packed as fp16mx2 and, like "
-                         "nnet3-xvector-compute does on its own table, calibrated on 64 chunks spread over the workload "
+                    help="default = what the command-line tools ship (XV_PREC_DEFAULT): the context is packed as fp16mx2 and, like a "
+                         "recipe's shared calibration file (nnet3-xvector-compute --calibration), measured on 64 chunks spread over the workload "
                          "(xv_ctx_calibrate, outside the timed region): fp16mx if its error against fp16x3 is within 7.5e-5 on the worst chunk, else fp16mx2")
     ap.add_argument("--no-parity-sweep", action="store_true",
                     help="skip the every-chunk comparison against fp16x3 (profiling runs: the last forward pass of the process is then the timed workload's)")

@@ -79,7 +79,8 @@ int TryArchive(const std::string& bytes) {
 
 // The indexed readers against the sequential one: same keys, same matrices, same order.  Returns 0 ok, 1 mismatch,
 // 2 "not addressable" (text archive: the caller checks that this is what usable() says).
-int CheckIndexer(const std::string& rspec, const std::string& seq_rspec) {
+int CheckIndexer(const std::string& rspec, const std::string& seq_rspec, long* views) {
+  xv::FileMapper mapper;
   xv::MatrixTableIndexer idx(rspec);
   if (!idx.usable()) return 2;
   xv::SequentialMatrixReader rd(seq_rspec);
@@ -95,6 +96,15 @@ int CheckIndexer(const std::string& rspec, const std::string& seq_rspec) {
     xv::ReadIndexedMatrix(e, &in, &in_path, &got);
     if (got.rows != want.rows || got.cols != want.cols || got.data != want.data) return 1;
     if (e.rows >= 0 && (e.rows != want.rows || e.cols != want.cols)) return 1;
+    // the VIEW of the same object in the mapped file (what the reader threads of a table job hand out): a binary float matrix
+    // must be viewable and hold the same bytes (compared with memcmp: the view has the archive's alignment, not a float's)
+    xv::Matrix view;
+    if (mapper.View(e, &view)) {
+      ++*views;
+      if (view.rows != want.rows || view.cols != want.cols || !view.data.empty() ||
+          memcmp(view.Data(), want.data.data(), want.data.size() * sizeof(float)) != 0)
+        return 1;
+    }
   }
 }
 
@@ -107,7 +117,17 @@ int TryIndexedFile(const std::string& path) {
     std::string in_path;
     xv::MatrixTableIndexer::Entry e;
     xv::Matrix m;
-    for (int n = 0; n < 100000 && idx.Next(&e); ++n) xv::ReadIndexedMatrix(e, &in, &in_path, &m);
+    xv::FileMapper mapper;
+    for (int n = 0; n < 100000 && idx.Next(&e); ++n) {
+      xv::Matrix view;
+      if (mapper.View(e, &view) && (long)view.rows * view.cols > 0) {   // a view of a damaged file must stay inside the file
+        volatile unsigned char first = *(const unsigned char*)view.Data();
+        volatile unsigned char last = ((const unsigned char*)view.Data())[(size_t)view.rows * view.cols * 4 - 1];
+        (void)first;
+        (void)last;
+      }
+      xv::ReadIndexedMatrix(e, &in, &in_path, &m);
+    }
     return 0;
   } catch (const xv::KioError&) {
     return 1;
@@ -181,9 +201,14 @@ int main(int argc, char** argv) {
         xv::Matrix m;
         while (rd2.Next(&key, &m, &err)) ws.WriteMat(key, m);
       }
-      if (CheckIndexer("ark:" + tb, "ark:" + tb) != 0 || CheckIndexer("scp:" + ts, "ark:" + tb) != 0 ||
-          CheckIndexer("ark:" + tt, "ark:" + tt) != 2) {
+      long views = 0;
+      if (CheckIndexer("ark:" + tb, "ark:" + tb, &views) != 0 || CheckIndexer("scp:" + ts, "ark:" + tb, &views) != 0 ||
+          CheckIndexer("ark:" + tt, "ark:" + tt, &views) != 2) {
         fprintf(stderr, "host_selftest: the indexed table readers disagree with the sequential reader\n");
+        return 1;
+      }
+      if (views == 0) {
+        fprintf(stderr, "host_selftest: no object of the binary archive could be viewed in the mapped file\n");
         return 1;
       }
       // damaged copies of the binary archive through the index pass (truncations and bit flips, on disk: the indexer seeks)
