@@ -1505,6 +1505,13 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   Calibration c;
   c.chosen = fast_mode();
   if (!can_switch_fast_mode() || B <= 0) return c;
+  {
+    // fault injection for the tests of the callers' error paths (XVEC_DEBUG=calib_fail=1: the first call of the process fails,
+    // 2: every call)
+    static int calls = 0;
+    const int inject = DebugKnobInt("calib_fail", 0);
+    if ((inject == 1 && calls++ == 0) || inject == 2) throw EngineError("injected failure (XVEC_DEBUG=calib_fail)");
+  }
   // Chunks each fast mode would run fast - pooled frames as FillPlan counts them.  fp16mx2 is validated on every chunk IT
   // runs (from mx2_min_pooled_ frames, where its error is largest), fp16mx on those it runs (from mx_min_pooled_).
   const BlobLayerInfo& pl = info_.layers[info_.pooled_layer];

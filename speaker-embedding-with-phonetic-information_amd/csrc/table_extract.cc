@@ -81,7 +81,19 @@ Engine::Calibration CalibrateOnUtterances(Engine* engine, const ExtractOptions& 
   }
   const int n = (int)offs.size() - 1;
   const auto t_cal = std::chrono::steady_clock::now();
-  if (n > 0) c = engine->Calibrate(feats.data(), offs.data(), n, opt.calibrate_tol);
+  // A measurement that fails - a device fault in a candidate arithmetic, a stream-K time-out, a device that does not reproduce
+  // its own bits (Engine::Calibrate checks) - is REPEATED ONCE, with a WARNING that says why: the first forward passes of a
+  // job's context are where four co-tenant jobs of a recipe meet on one GPU (GPUTEST r05, profiles/r06_cotenancy.md), and a
+  // job of an hour should not die of - nor silently take another arithmetic from - one odd pass of its start-up measurement.
+  // The second failure ends the job with its message.  (Errors of the EXTRACTION are never retried: a result is a result.)
+  if (n > 0) {
+    try {
+      c = engine->Calibrate(feats.data(), offs.data(), n, opt.calibrate_tol);
+    } catch (const EngineError& ex) {
+      log("WARNING", std::string("calibration attempt failed (") + ex.what() + "); the measurement is repeated once");
+      c = engine->Calibrate(feats.data(), offs.data(), n, opt.calibrate_tol);
+    }
+  }
   if (getenv("XVEC_TIMING")) {
     std::ostringstream t;
     t << "calibration: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_cal).count() << " s for " << n << " chunks";

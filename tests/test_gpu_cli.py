@@ -225,6 +225,40 @@ def test_cli_calibration_sample(tmp_path):
     assert "calibration on" not in outs["plain"][1] and "calibration sample" not in outs["plain"][1], outs["plain"][1]
 
 
+def test_cli_failed_measurement_is_repeated_once_and_a_second_failure_ends_the_job(tmp_path):
+    """A calibration that fails (device fault in a candidate arithmetic, a device that does not reproduce its own bits:
+    Engine::Calibrate checks) is repeated ONCE with a WARNING that names the cause, and the job then computes what an undisturbed
+    job computes; a second failure ends the job: ERROR, exit 255, no output - never another arithmetic with exit 0 (ADVICE r05:
+    round 5 caught the exception, kept fp16mx2 and went on).  Fault injection: XVEC_DEBUG=calib_fail=1 / 2."""
+    d = tmp_path
+    net, line = H.synth_model("v2_xvector")
+    (d / "final.raw").write_bytes(net.to_bytes(True))
+    utts = [("utt%03d" % i, H.features(900 + i, 400)) for i in range(24)]
+    kio.write_ark_matrices(str(d / "feats.ark"), utts)
+
+    def run(tag, extra, debug):
+        env = dict(os.environ)
+        if debug:
+            env["XVEC_DEBUG"] = debug
+        return _run([os.path.join(BIN, "nnet3-xvector-compute"), "--min-chunk-size=25", "--output-node=tdnn6.affine"] + extra +
+                    [str(d / "final.raw"), "ark:%s/feats.ark" % d, "ark:%s/x_%s.ark" % (d, tag)], env=env)
+    for form, extra in (("self", ["--calibrate=true"]), ("file", ["--calibration=%s/CAL.calib" % d])):
+        ext = lambda tag: [a.replace("CAL", tag) for a in extra]
+        good = run(form + "_good", ext("good"), None)
+        assert good.returncode == 0 and b"calibration attempt failed" not in good.stderr, good.stderr.decode()[-800:]
+        once = run(form + "_once", ext("once"), "calib_fail=1")
+        err = once.stderr.decode()
+        assert once.returncode == 0, err[-800:]
+        assert "WARNING" in err and "calibration attempt failed (injected failure" in err and "repeated once" in err, err[-800:]
+        assert (d / ("x_%s_once.ark" % form)).read_bytes() == (d / ("x_%s_good.ark" % form)).read_bytes()
+        twice = run(form + "_twice", ext("twice"), "calib_fail=2")
+        err = twice.stderr.decode()
+        assert twice.returncode == 255 and "ERROR" in err and "injected failure" in err, (twice.returncode, err[-800:])
+        assert not os.path.exists(str(d / "twice.calib"))          # nothing is published by a job that could not measure
+        out = d / ("x_%s_twice.ark" % form)
+        assert not out.exists() or out.stat().st_size == 0
+
+
 def test_cli_profile_json(job):
     import json
     d, utts, ev = job
@@ -395,6 +429,13 @@ def test_four_concurrent_processes_share_one_gpu(tmp_path, topology, precision, 
             assert "read from" in solo_err and "calibration on" not in solo_err, _arith_lines(solo_err)
         elif mode == "fixed":
             assert not any("calibration on" in e for e in errs + [solo_err])     # nothing is measured: a function of the model
+        # a measurement the tool had to repeat (table_extract.cc: one retry, with a WARNING that says why) does not fail the test -
+        # the outputs decide - but it must not go unseen either: it ends up in pytest's warnings summary
+        for tag, e in zip(("solo", "1", "2", "3", "4"), [solo_err] + errs):
+            for ln in e.splitlines():
+                if "calibration attempt failed" in ln:
+                    import warnings
+                    warnings.warn("process %s of %s/%s: %s" % (tag, topology, mode, ln[-600:]))
         solo = open(os.path.join(d, "xvector.solo.ark"), "rb").read()
         report = []
         for j in (1, 2, 3, 4):
