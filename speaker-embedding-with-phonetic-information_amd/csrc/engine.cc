@@ -813,6 +813,7 @@ Engine::~Engine() {
     fr(S.d_raw);
     fr(S.d_prefix);
     fr(S.d_fetab);
+    fr(S.d_cm);
     if (S.h_fetab) (void)hipHostFree(S.h_fetab);
     if (S.h_feats) (void)hipHostFree(S.h_feats);
     if (S.h_out) (void)hipHostFree(S.h_out);
@@ -1840,7 +1841,9 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
   FillPlan(row_offsets, B, S.plan.get(), &tables);
   const size_t fbytes = (size_t)row_offsets[B] * info_.input_dim * 4;
   const size_t obytes = (size_t)(frame_mode_ ? S.plan->n_out : B) * info_.output_dim * 4;
-  const size_t hbytes = fe ? (size_t)fe->raw_off[fe->n_utts] * info_.input_dim * 4 : fbytes;   // what the pinned buffer holds
+  const bool fe_cm = fe && fe->cm_off != nullptr;
+  // what the pinned buffer holds: the batch's chunks, raw float rows for the front-end, or compressed objects for it
+  const size_t hbytes = fe_cm ? fe->cm_bytes : fe ? (size_t)fe->raw_off[fe->n_utts] * info_.input_dim * 4 : fbytes;
   if (hbytes > S.h_feats_bytes) throw EngineError("SubmitHost: the batch is larger than the buffer HostFeats returned");
   if (fe && fe->n_out != row_offsets[B]) throw EngineError("SubmitHost: front-end output rows do not match row_offsets");
   // (re)allocation frees device memory, which waits for the device: buffers only grow
@@ -1865,8 +1868,9 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
     const int D = info_.input_dim;
     const long raw_rows = fe->raw_off[fe->n_utts];
     const size_t o_off = 0, o_row = Align256((size_t)(fe->n_utts + 1) * 4), o_utt = Align256(o_row + (size_t)fe->n_out * 4);
-    const size_t tab = Align256(o_utt + (size_t)fe->n_out * 4);
-    grow(&S.d_raw, hbytes);
+    const size_t o_cm = Align256(o_utt + (size_t)fe->n_out * 4);
+    const size_t tab = Align256(o_cm + (fe_cm ? (size_t)fe->n_utts * 8 : 0));
+    grow(&S.d_raw, (size_t)raw_rows * D * 4);
     grow(&S.d_prefix, (size_t)(raw_rows + fe->n_utts) * D * 8);
     grow(&S.d_fetab, tab);
     EnsurePinned(&S.h_fetab, &S.h_fetab_bytes, tab);
@@ -1874,10 +1878,27 @@ void Engine::SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, c
     memcpy(ht + o_off, fe->raw_off, (size_t)(fe->n_utts + 1) * 4);
     memcpy(ht + o_row, fe->sel_row, (size_t)fe->n_out * 4);
     memcpy(ht + o_utt, fe->sel_utt, (size_t)fe->n_out * 4);
+    if (fe_cm) memcpy(ht + o_cm, fe->cm_off, (size_t)fe->n_utts * 8);
     Check(hipMemcpyAsync(S.d_fetab.p, S.h_fetab, tab, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(front-end tables)");
-    Check(hipMemcpyAsync(S.d_raw.p, S.h_feats, hbytes, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(raw feats)");
+    if (fe_cm) {
+      grow(&S.d_cm, hbytes);
+      Check(hipMemcpyAsync(S.d_cm.p, S.h_feats, hbytes, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(compressed feats)");
+    } else {
+      Check(hipMemcpyAsync(S.d_raw.p, S.h_feats, hbytes, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(raw feats)");
+    }
     Check(hipEventRecord(S.h2d_done, cs), "hipEventRecord(upload)");
     Check(hipStreamWaitEvent(s, S.h2d_done, 0), "hipStreamWaitEvent(upload)");
+    if (fe_cm) {   // one byte per element came up; the float rows are made here
+      CmExpandArgs ca;
+      ca.cm = (const uint8_t*)S.d_cm.p;
+      ca.cm_off = (const int64_t*)((const uint8_t*)S.d_fetab.p + o_cm);
+      ca.raw_off = (const int32_t*)((const uint8_t*)S.d_fetab.p + o_off);
+      ca.n_utts = fe->n_utts;
+      ca.dim = D;
+      ca.max_rows = fe->max_rows;
+      ca.out = (float*)S.d_raw.p;
+      Check(launch_cm_expand(ca, s), "cm_expand launch");
+    }
     FrontEndArgs fa;
     fa.raw = (const float*)S.d_raw.p;
     fa.raw_off = (const int32_t*)((const uint8_t*)S.d_fetab.p + o_off);

@@ -112,6 +112,11 @@ class Engine {
     int cmn_window;
     bool center;
     int min_window;
+    // The pinned buffer holds COMPRESSED objects instead of float rows (Kaldi "CM" matrices, kernels.h CmExpandArgs): cm_off[u]
+    // = byte offset of utterance u's object in it, cm_bytes = all of them, max_rows = the longest utterance.  Null: float rows.
+    const int64_t* cm_off = nullptr;
+    size_t cm_bytes = 0;
+    int max_rows = 0;
   };
   void SubmitHost(int slot, long seq, const int32_t* row_offsets, int B, const FrontEndJob* fe = nullptr);
   const float* WaitHost(int slot);
@@ -232,6 +237,7 @@ class Engine {
     size_t h_tables_bytes = 0;
     Buf d_feats, d_out, d_tables;
     Buf d_raw, d_prefix, d_fetab;   // front-end: raw rows, per-utterance prefix sums (double), tables
+    Buf d_cm;                       // front-end on compressed input: the uploaded objects
     void* h_fetab = nullptr;        // pinned
     size_t h_fetab_bytes = 0;
     hipEvent_t done = nullptr;

@@ -287,7 +287,8 @@ void ExtractJob::StartPtrs(Engine* eng, const ExtractOptions& opt, int slot, lon
 }
 
 bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot, long seq, int n_utts, const float* const* raw,
-                               const int32_t* raw_rows, const float* const* vad) {
+                               const int32_t* raw_rows, const float* const* vad, const uint8_t* const* cm,
+                               const size_t* cm_bytes) {
   const int D = eng->info().input_dim;
   std::vector<Chunk> chunks;
   std::vector<int32_t> ok(n_utts, 0), kept(n_utts, 0);
@@ -314,6 +315,18 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
     total_kept += k;
   }
   if (chunks.empty() || total_kept > opt.max_batch_rows || (int)chunks.size() > opt.max_batch_chunks) return false;
+  // compressed input: all or nothing (a mixed batch goes the host way - decided before this job takes any state)
+  bool all_cm = cm != nullptr && cm_bytes != nullptr;
+  for (int u = 0; u < n_utts && all_cm; ++u)
+    if (ok[u] && !cm[u]) all_cm = false;
+  size_t cm_total = 0;
+  int max_rows = 0;
+  for (int u = 0; u < n_utts; ++u) {
+    if (!ok[u]) continue;
+    if (!all_cm && !raw[u]) return false;   // a compressed view without floats in a batch that cannot go compressed
+    if (all_cm) cm_total += (cm_bytes[u] + 15) & ~(size_t)15;
+    max_rows = std::max(max_rows, raw_rows[u]);
+  }
   eng_ = eng;
   opt_ = opt;
   slot_ = slot;
@@ -323,15 +336,23 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
   chunks_ = chunks;
   ok_ = ok;
   why_ = why;
-  float* buf = eng->HostFeats(slot, (size_t)total_raw);
+  float* buf = eng->HostFeats(slot, all_cm ? (cm_total + (size_t)D * 4 - 1) / ((size_t)D * 4) : (size_t)total_raw);
   std::vector<int32_t> raw_off(1, 0), sel_row, sel_utt, offs(1, 0);
+  std::vector<int64_t> cm_off;
   sel_row.reserve(total_kept);
   sel_utt.reserve(total_kept);
   int j = 0;   // index among the utterances that enter the device batch
+  size_t cm_pos = 0;
   for (int u = 0; u < n_utts; ++u) {
     if (!ok[u]) continue;
     const int base = raw_off.back();
-    memcpy(buf + (size_t)base * D, raw[u], (size_t)raw_rows[u] * D * 4);
+    if (all_cm) {
+      memcpy((uint8_t*)buf + cm_pos, cm[u], cm_bytes[u]);
+      cm_off.push_back((int64_t)cm_pos);
+      cm_pos += (cm_bytes[u] + 15) & ~(size_t)15;
+    } else {
+      memcpy(buf + (size_t)base * D, raw[u], (size_t)raw_rows[u] * D * 4);
+    }
     for (int t = 0; t < raw_rows[u]; ++t)
       if (!vad[u] || vad[u][t] != 0.f) {
         sel_row.push_back(base + t);
@@ -350,6 +371,11 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
   fe.cmn_window = opt.cmn_window;
   fe.center = opt.cmn_center;
   fe.min_window = opt.cmn_min_window;
+  if (all_cm) {
+    fe.cm_off = cm_off.data();
+    fe.cm_bytes = cm_total;
+    fe.max_rows = max_rows;
+  }
   eng->SubmitHost(slot, seq, offs.data(), j, &fe);
   async_ = true;
   return true;

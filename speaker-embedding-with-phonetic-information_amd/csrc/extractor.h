@@ -78,8 +78,13 @@ class ExtractJob {
   // decisions (or null: keep every row; every utterance keeps at least one).  When every utterance maps to exactly one
   // unpadded chunk (the normal case) the raw rows are staged, CMN + selection + network run on the device without a
   // host round trip, and true is returned; otherwise nothing is submitted and the caller uses FrontEndHost + Start.
+  // cm / cm_bytes (optional): utterances that arrive as COMPRESSED views of a mapped archive (kio.h Matrix::cm) - when every
+  // utterance of the batch has one, the objects are staged as they are (one byte per element) and expanded on the device;
+  // raw[u] may then be null.  A batch in which only some utterances are compressed returns false like any other batch the
+  // device path cannot take (the caller expands on the host).
   bool StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot, long seq, int n_utts, const float* const* raw,
-                     const int32_t* raw_rows, const float* const* vad);
+                     const int32_t* raw_rows, const float* const* vad, const uint8_t* const* cm = nullptr,
+                     const size_t* cm_bytes = nullptr);
   void Finish(float* out, int32_t* ok, std::vector<std::string>* why);
   bool active() const { return eng_ != nullptr; }
 

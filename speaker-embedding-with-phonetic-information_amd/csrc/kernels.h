@@ -428,6 +428,22 @@ struct FrontEndArgs {
 };
 hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s);
 
+// Kaldi's compressed matrices ("CM": the storage format of the recipes' raw features, make_mfcc.sh --compress true) expanded on
+// the device, in front of the front-end above: the host uploads one byte per element instead of expanding four on a core first
+// (4.5 ns per element in round 5, 1 ns with a table per column - still more than everything else a reader thread does).
+// Object of utterance u, at cm + cm_off[u] (any alignment): {float min_value, range; int32 rows, cols; uint16 percentiles[cols][4];
+// uint8 data[cols][rows]} - what follows the "CM " token in the archive.  Element (r, c) = the piecewise-linear value of byte
+// data[c][r] between the column's 0 / 25 / 75 / 100 % points (compressed-matrix.h: CharToFloat), written to
+// out[(raw_off[u] + r) * dim + c] with exactly the host reader's float operations (no fused multiply-add): the same bits.
+struct CmExpandArgs {
+  const uint8_t* cm;
+  const int64_t* cm_off;    // [n_utts]
+  const int32_t* raw_off;   // [n_utts + 1] rows of every utterance in out
+  int n_utts, dim, max_rows;
+  float* out;               // [raw_off[n_utts]][dim]
+};
+hipError_t launch_cm_expand(const CmExpandArgs& a, hipStream_t s);
+
 // Speaker-level back-end on the device (the chain of egs/sre/v2/run_sre10.sh:238-241:
 // ivector-subtract-global-mean | transform-vec | ivector-normalize-length):
 //   y = T (x - mean)   [T linear (cols == dim) or affine (cols == dim + 1), each stage optional]

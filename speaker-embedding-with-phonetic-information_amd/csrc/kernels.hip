@@ -4009,6 +4009,69 @@ __global__ __launch_bounds__(256) void cmn_select_kernel(const FrontEndArgs a) {
   a.out[idx] = (float)((double)x - mean);
 }
 
+// cm_expand: one workgroup per (64-row block, utterance).  The column's bytes are contiguous in the object (coalesced reads along
+// the rows), the floats go through LDS so that the block's 64 x dim rows leave as one contiguous run.
+__global__ __launch_bounds__(256) void cm_expand_kernel(const CmExpandArgs a) {
+  // every multiplication and addition below is rounded on its own, like the host reader's: hipcc contracts a * b + c into one
+  // fused operation by default (one ulp here and there), and ROCm's __fmul_rn / __fadd_rn are plain operators defined where
+  // contraction is allowed - hence plain operators HERE, under the pragma
+#pragma clang fp contract(off)
+  const int u = blockIdx.y;
+  const int r0 = blockIdx.x * 64;
+  const int rows = a.raw_off[u + 1] - a.raw_off[u];
+  if (r0 >= rows) return;
+  const int D = a.dim;
+  const uint8_t* obj = a.cm + a.cm_off[u];
+  __shared__ float pt[4][64];
+  __shared__ float tile[64 * 64];
+  const int tid = threadIdx.x;
+  auto rd32 = [&](const uint8_t* p) __attribute__((always_inline)) {
+    return (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24);
+  };
+  if (tid < D) {
+    const float mn = __uint_as_float(rd32(obj)), range = __uint_as_float(rd32(obj + 4));
+    const uint8_t* h = obj + 16 + (size_t)tid * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned v = (unsigned)h[2 * q] | ((unsigned)h[2 * q + 1] << 8);
+      // min_value + range * 1.52590218966964e-05F * v, left to right, every operation rounded on its own
+      const float scaled = range * 1.52590218966964e-05F;
+      const float prod = scaled * (float)v;
+      pt[q][tid] = mn + prod;
+    }
+  }
+  __syncthreads();
+  const uint8_t* data = obj + 16 + (size_t)D * 8;
+  const int nr = min(64, rows - r0);
+  for (int i = tid; i < 64 * D; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r >= nr) continue;
+    const int v = data[(size_t)c * rows + r0 + r];
+    const float p0 = pt[0][c], p25 = pt[1][c], p75 = pt[2][c], p100 = pt[3][c];
+    float x;
+    if (v <= 64) {
+      const float t1 = (p25 - p0) * (float)v, t2 = t1 * (1 / 64.0f);
+      x = p0 + t2;
+    } else if (v <= 192) {
+      const float t1 = (p75 - p25) * (float)(v - 64), t2 = t1 * (1 / 128.0f);
+      x = p25 + t2;
+    } else {
+      const float t1 = (p100 - p75) * (float)(v - 192), t2 = t1 * (1 / 63.0f);
+      x = p75 + t2;
+    }
+    tile[r * D + c] = x;
+  }
+  __syncthreads();
+  float* dst = a.out + ((size_t)a.raw_off[u] + r0) * D;
+  for (int i = tid; i < nr * D; i += 256) dst[i] = tile[i];
+}
+
+hipError_t launch_cm_expand(const CmExpandArgs& a, hipStream_t s) {
+  if (a.dim < 1 || a.dim > 64 || a.n_utts < 1 || a.max_rows < 1) return hipErrorInvalidValue;
+  XV_LAUNCH(cm_expand_kernel, dim3((unsigned)((a.max_rows + 63) / 64), (unsigned)a.n_utts), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s) {
   if (a.dim > 64) return hipErrorInvalidValue;
   if (a.cmn_window > 0 && a.n_utts > 0) XV_LAUNCH(cmn_prefix_kernel, dim3(a.n_utts), dim3(64), 0, s, a);

@@ -556,6 +556,60 @@ void ReadVector(Input& in, bool binary, std::vector<float>* v) {
 
 static inline float U16ToFloat(float mn, float range, uint16_t v) { return mn + range * 1.52590218966964e-05F * v; }
 
+// "CM": per-column percentiles + one byte per element, column-major
+static void ExpandCm(float min_value, float range, int rows, int cols, const uint16_t* hdr, const uint8_t* bytes, Matrix* m) {
+  const size_t total = (size_t)rows * cols;
+  m->rows = rows;
+  m->cols = cols;
+  m->ext = nullptr;
+  m->cm = nullptr;
+  m->cm_bytes = 0;
+  // One table of the 256 values a byte can stand for per COLUMN (same expressions as Kaldi's CharToFloat, evaluated once per
+  // value instead of once per element: the same floats), then the transposition column-major bytes -> row-major floats in
+  // blocks of rows that stay in the L1.  The raw feats.scp of the recipes is compressed (make_mfcc.sh --compress true), and
+  // with the device front-end it is what the reader threads of a table job see: 4.5 ns per element before, the decompression
+  // was 41 us of host time per 400-frame utterance - six times the whole remaining host budget (profiles/r06_host_cost.md).
+  m->data.resize(total);
+  std::vector<float> lut((size_t)cols * 256);
+  for (int c = 0; c < cols; ++c) {
+    uint16_t q[4];
+    memcpy(q, (const uint8_t*)hdr + (size_t)c * 8, 8);   // (a view's header has the archive's alignment)
+    const float p0 = U16ToFloat(min_value, range, q[0]);
+    const float p25 = U16ToFloat(min_value, range, q[1]);
+    const float p75 = U16ToFloat(min_value, range, q[2]);
+    const float p100 = U16ToFloat(min_value, range, q[3]);
+    float* t = lut.data() + (size_t)c * 256;
+    for (int v = 0; v < 256; ++v) {
+      float x;
+      if (v <= 64) x = p0 + (p25 - p0) * v * (1 / 64.0f);
+      else if (v <= 192) x = p25 + (p75 - p25) * (v - 64) * (1 / 128.0f);
+      else x = p75 + (p100 - p75) * (v - 192) * (1 / 63.0f);
+      t[v] = x;
+    }
+  }
+  constexpr int kRowBlock = 64;
+  float* out = m->data.data();
+  for (int r0 = 0; r0 < rows; r0 += kRowBlock) {
+    const int r1 = std::min(rows, r0 + kRowBlock);
+    for (int c = 0; c < cols; ++c) {
+      const uint8_t* col = bytes + (size_t)c * rows;  // column-major payload
+      const float* t = lut.data() + (size_t)c * 256;
+      for (int r = r0; r < r1; ++r) out[(size_t)r * cols + c] = t[col[r]];
+    }
+  }
+}
+
+void ExpandCompressedView(const Matrix& view, Matrix* out) {
+  if (!view.cm || view.cm_bytes < 16) throw KioError("ExpandCompressedView: not a compressed view");
+  float mr[2];
+  int32_t rc[2];
+  memcpy(mr, view.cm, 8);
+  memcpy(rc, view.cm + 8, 8);
+  if (rc[0] != view.rows || rc[1] != view.cols || view.cm_bytes != 16 + (size_t)rc[1] * 8 + (size_t)rc[0] * rc[1])
+    throw KioError("ExpandCompressedView: the view does not match its header");
+  ExpandCm(mr[0], mr[1], rc[0], rc[1], (const uint16_t*)(view.cm + 16), view.cm + 16 + (size_t)rc[1] * 8, out);
+}
+
 static void ReadCompressed(Input& in, const std::string& tok, Matrix* m) {
   struct {
     float min_value, range;
@@ -571,37 +625,7 @@ static void ReadCompressed(Input& in, const std::string& tok, Matrix* m) {
     ReadGrow(in, &hdr, (size_t)h.cols * 4);
     std::vector<uint8_t> bytes;
     ReadGrow(in, &bytes, total);
-    // One table of the 256 values a byte can stand for per COLUMN (same expressions as Kaldi's CharToFloat, evaluated once per
-    // value instead of once per element: the same floats), then the transposition column-major bytes -> row-major floats in
-    // blocks of rows that stay in the L1.  The raw feats.scp of the recipes is compressed (make_mfcc.sh --compress true), and
-    // with the device front-end it is what the reader threads of a table job see: 4.5 ns per element before, the decompression
-    // was 41 us of host time per 400-frame utterance - six times the whole remaining host budget (profiles/r06_host_cost.md).
-    m->data.resize(total);
-    std::vector<float> lut((size_t)h.cols * 256);
-    for (int c = 0; c < h.cols; ++c) {
-      const float p0 = U16ToFloat(h.min_value, h.range, hdr[4 * c]);
-      const float p25 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 1]);
-      const float p75 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 2]);
-      const float p100 = U16ToFloat(h.min_value, h.range, hdr[4 * c + 3]);
-      float* t = lut.data() + (size_t)c * 256;
-      for (int v = 0; v < 256; ++v) {
-        float x;
-        if (v <= 64) x = p0 + (p25 - p0) * v * (1 / 64.0f);
-        else if (v <= 192) x = p25 + (p75 - p25) * (v - 64) * (1 / 128.0f);
-        else x = p75 + (p100 - p75) * (v - 192) * (1 / 63.0f);
-        t[v] = x;
-      }
-    }
-    constexpr int kRowBlock = 64;
-    float* out = m->data.data();
-    for (int r0 = 0; r0 < h.rows; r0 += kRowBlock) {
-      const int r1 = std::min(h.rows, r0 + kRowBlock);
-      for (int c = 0; c < h.cols; ++c) {
-        const uint8_t* col = bytes.data() + (size_t)c * h.rows;  // column-major payload
-        const float* t = lut.data() + (size_t)c * 256;
-        for (int r = r0; r < r1; ++r) out[(size_t)r * h.cols + c] = t[col[r]];
-      }
-    }
+    ExpandCm(h.min_value, h.range, h.rows, h.cols, hdr.data(), bytes.data(), m);
   } else if (tok == "CM2") {
     std::vector<uint16_t> d;
     ReadGrow(in, &d, total);
@@ -642,6 +666,9 @@ void SkipBinaryMatrix(Input& in, int* rows, int* cols) {
 }
 
 void ReadMatrix(Input& in, bool binary, Matrix* m) {
+  m->ext = nullptr;   // (a matrix object that was a view before owns its floats from here on)
+  m->cm = nullptr;
+  m->cm_bytes = 0;
   if (binary) {
     std::string tok;
     ReadToken(in, true, &tok);
@@ -1014,25 +1041,48 @@ FileMapper::Mapped FileMapper::Map(const std::string& path) {
   return f;
 }
 
-bool FileMapper::View(const MatrixTableIndexer::Entry& e, Matrix* m) {
+bool FileMapper::View(const MatrixTableIndexer::Entry& e, Matrix* m, bool allow_compressed) {
   if (e.offset < 0 || e.rows < 0 || e.cols < 0) return false;
   const Mapped f = Map(e.rx);
-  // "\0B" "FM " '\4' <int32 rows> '\4' <int32 cols> <rows * cols floats>
-  const size_t head = 2 + 3 + 5 + 5;
-  if (!f.base || (size_t)e.offset + head > f.size) return false;
+  if (!f.base || (size_t)e.offset + 5 > f.size) return false;
   const uint8_t* p = f.base + e.offset;
-  if (p[0] != 0 || p[1] != 'B' || p[2] != 'F' || p[3] != 'M' || p[4] != ' ' || p[5] != 4 || p[10] != 4) return false;
-  int32_t r, c;
-  memcpy(&r, p + 6, 4);
-  memcpy(&c, p + 11, 4);
-  if (r != e.rows || c != e.cols || r < 0 || c < 0) return false;
-  const size_t bytes = (size_t)r * c * 4;
-  if ((size_t)e.offset + head + bytes > f.size) return false;
-  m->rows = r;
-  m->cols = c;
-  m->data.clear();
-  m->ext = (const float*)(p + head);
-  return true;
+  if (p[0] != 0 || p[1] != 'B') return false;
+  if (p[2] == 'F' && p[3] == 'M' && p[4] == ' ') {
+    // "\0B" "FM " '\4' <int32 rows> '\4' <int32 cols> <rows * cols floats>
+    const size_t head = 2 + 3 + 5 + 5;
+    if ((size_t)e.offset + head > f.size || p[5] != 4 || p[10] != 4) return false;
+    int32_t r, c;
+    memcpy(&r, p + 6, 4);
+    memcpy(&c, p + 11, 4);
+    if (r != e.rows || c != e.cols || r < 0 || c < 0) return false;
+    const size_t bytes = (size_t)r * c * 4;
+    if ((size_t)e.offset + head + bytes > f.size) return false;
+    m->rows = r;
+    m->cols = c;
+    m->data.clear();
+    m->cm = nullptr;
+    m->cm_bytes = 0;
+    m->ext = (const float*)(p + head);
+    return true;
+  }
+  if (allow_compressed && p[2] == 'C' && p[3] == 'M' && p[4] == ' ') {
+    // "\0B" "CM " {float min_value, range; int32 rows, cols} <cols x 4 uint16> <cols x rows bytes>
+    const size_t head = 2 + 3;
+    if ((size_t)e.offset + head + 16 > f.size) return false;
+    int32_t rc[2];
+    memcpy(rc, p + head + 8, 8);
+    if (rc[0] != e.rows || rc[1] != e.cols || rc[0] < 0 || rc[1] < 0) return false;
+    const size_t bytes = 16 + (size_t)rc[1] * 8 + (size_t)rc[0] * rc[1];
+    if ((size_t)e.offset + head + bytes > f.size) return false;
+    m->rows = rc[0];
+    m->cols = rc[1];
+    m->data.clear();
+    m->ext = nullptr;
+    m->cm = p + head;
+    m->cm_bytes = bytes;
+    return true;
+  }
+  return false;
 }
 
 FileMapper::~FileMapper() {

@@ -109,6 +109,12 @@ struct Matrix {
   // A VIEW instead of a copy (ViewIndexedMatrix): rows x cols floats that live in a mapped archive file.  The address has the
   // alignment the archive gave it (a key of any length precedes the object): memcpy from it, never dereference it as float.
   const float* ext = nullptr;
+  // ... or of a COMPRESSED matrix ("CM": one byte per element, Kaldi's default for stored features): cm points behind the "CM "
+  // token of the object - {float min_value, range; int32 rows, cols; uint16 percentiles[cols][4]; uint8 data[cols][rows]},
+  // cm_bytes of them, any alignment.  rows / cols are set, data is empty, ext is null: such a matrix can only be handed to the
+  // device front-end (which expands it on the GPU, kernels.h CmExpandArgs) or expanded with ExpandCompressedView.
+  const uint8_t* cm = nullptr;
+  size_t cm_bytes = 0;
   const float* Data() const { return ext ? ext : data.data(); }
   float* Row(int r) { return data.data() + (size_t)r * cols; }
   const float* Row(int r) const { return Data() + (size_t)r * cols; }
@@ -116,6 +122,8 @@ struct Matrix {
 
 // Reads FM / DM / CM / CM2 / CM3 (binary) or " [ ... ]" (text).
 void ReadMatrix(Input& in, bool binary, Matrix* m);
+// Expands a compressed view (Matrix::cm) into floats on the host: *out owns them (the same floats ReadMatrix delivers).
+void ExpandCompressedView(const Matrix& view, Matrix* out);
 // Regular files, positioned behind the "\0B" of a binary matrix (FM / DM / CM / CM2 / CM3): reads the header only, reports the
 // dimensions and moves to the end of the object (the index pass of the parallel table readers).
 void SkipBinaryMatrix(Input& in, int* rows, int* cols);
@@ -203,7 +211,8 @@ class FileMapper {
   ~FileMapper();
   FileMapper(const FileMapper&) = delete;
   FileMapper& operator=(const FileMapper&) = delete;
-  bool View(const MatrixTableIndexer::Entry& e, Matrix* m);
+  // allow_compressed: a "CM" object becomes a compressed view (Matrix::cm) instead of `false`
+  bool View(const MatrixTableIndexer::Entry& e, Matrix* m, bool allow_compressed = false);
 
  private:
   struct Mapped {

@@ -11,8 +11,10 @@
 //   p8_whole (0 | 1 | 2, 0)           how that kernel deals its tiles out (engine.cc); read per context
 //   first_kernel (0 | 1, 1)           0: layers on the network input go through prep_input + the generic GEMM
 //   readers (1..16, 4 per engine)  copy_threads (0..15, 3)  pipe_drain (0 | 1, 1)  mmap (0 | 1, 1)  spin_wait (0 | 1, 0)
+//   cm_on_device (0 | 1, 1)
 //                                     host side of a table job: reader / copy threads, the pipe's drain thread, mapped archives,
-//                                     hipEventSynchronize instead of the sleeping wait
+//                                     hipEventSynchronize instead of the sleeping wait, compressed matrices of a front-end
+//                                     job expanded on the GPU (0: by the reader threads)
 //   engines_on_one_device (n, 0)      test knob: n engines on ONE device behind the several-engine table loop
 //   bn_fold (0 | 1, 0)  bn_fold_mask (bits)   the opt-in lowering of DESIGN.md section 3.5
 //   tail_over_tol (factor, 1.10)      study knob of tools/tail_error.py: the calibration's projected-tail condition

@@ -426,6 +426,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     }
   };
   const bool use_views = DebugKnobInt("mmap", 1) != 0;
+  const bool cm_on_device = DebugKnobInt("cm_on_device", 1) != 0;   // compressed matrices of a front-end job: expanded on the GPU
   auto parallel_reader_body = [&] {
     Input in;
     std::string in_path;
@@ -453,7 +454,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
         try {
           // a float matrix in a regular file is not read at all: the utterance is a view of the mapped archive, and its bytes
           // are touched once, by the copy into the pinned staging buffer
-          if (!use_views || !mapper.View(e, &u.feats)) ReadIndexedMatrix(e, &in, &in_path, &u.feats);
+          if (!use_views || !mapper.View(e, &u.feats, use_frontend && cm_on_device)) ReadIndexedMatrix(e, &in, &in_path, &u.feats);
         } catch (const std::exception& ex) {
           if (e.offset >= 0 && !opt_is_scp) {   // a damaged archive is fatal, as in the sequential reader
             std::unique_lock<std::mutex> lk(mu);
@@ -627,6 +628,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     std::vector<int32_t> ok;
     std::vector<std::string> why;
     long num_fail = 0;   // utterances rejected before they reached the device
+    long num_cm_device = 0;   // utterances that went up compressed and were expanded on the device
     double t_pack = 0, t_start = 0, t_fin = 0;
   };
   std::vector<Consumer> cons(NE);
@@ -760,6 +762,9 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
           std::vector<int> keep_idx;
           std::vector<const float*> rawp, vadp;
           std::vector<int32_t> rrows;
+          std::vector<const uint8_t*> cmp;    // compressed views of a mapped archive: expanded on the device (or below, on the host)
+          std::vector<size_t> cmb;
+          bool any_cm = false;
           for (int k = 0; k < n; ++k) {
             const Utt& u = w.b.utts[idx[k]];
             const int T = u.feats.rows;
@@ -789,15 +794,36 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
               }
             }
             keep_idx.push_back(idx[k]);
-            rawp.push_back(u.feats.Data());
+            rawp.push_back(u.feats.cm ? nullptr : u.feats.Data());
+            cmp.push_back(u.feats.cm);
+            cmb.push_back(u.feats.cm_bytes);
+            any_cm = any_cm || u.feats.cm != nullptr;
             vadp.push_back(v ? v->data() : nullptr);
             rrows.push_back(T);
           }
           idx.swap(keep_idx);
           n = (int)idx.size();
           // device path: raw rows in, CMN + selection + network on the lane's stream, nothing comes back but embeddings
-          if (n) submitted = w.job.StartFrontEnd(C.eng, opt, C.cur, C.seq, n, rawp.data(), rrows.data(), vadp.data());
+          if (n)
+            submitted = w.job.StartFrontEnd(C.eng, opt, C.cur, C.seq, n, rawp.data(), rrows.data(), vadp.data(),
+                                            any_cm ? cmp.data() : nullptr, any_cm ? cmb.data() : nullptr);
           if (submitted) ++C.seq;
+          if (submitted && any_cm) C.num_cm_device += n;
+          if (n && !submitted && any_cm) {
+            // the batch cannot go to the device as it is (an utterance cut into several chunks, a mixed batch): the compressed
+            // views are expanded here, into the utterances themselves, and the float paths below see what they always saw
+            for (int k = 0; k < n; ++k) {
+              Utt& u = w.b.utts[idx[k]];
+              if (!u.feats.cm) continue;
+              Matrix full;
+              ExpandCompressedView(u.feats, &full);
+              u.feats = std::move(full);
+              rawp[k] = u.feats.Data();
+            }
+            any_cm = false;
+            submitted = w.job.StartFrontEnd(C.eng, opt, C.cur, C.seq, n, rawp.data(), rrows.data(), vadp.data());
+            if (submitted) ++C.seq;
+          }
           if (n && !submitted) {
             // utterances that are cut into several chunks or padded: front-end result back to the host, then Start()
             sel_row.clear();
@@ -1020,6 +1046,9 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     m << "consumer stages" << (NE > 1 ? " (summed over the engines' threads)" : "") << ": wait for reader " << t_wait << " s, pack "
       << t_pack << " s, plan+submit " << t_start << " s, finish+write " << t_fin << " s";
     log("LOG", m.str());
+    long n_cm = 0;
+    for (const Consumer& C : cons) n_cm += C.num_cm_device;
+    if (n_cm) log("LOG", "front-end: " + std::to_string(n_cm) + " utterances went to the device compressed (one byte per element) and were expanded there");
     // host budget of the table loop: CPU seconds of ALL threads of the process (readers, copy threads, consumers, writer, the
     // runtime's own) between the first batch and the last write - what eight ranks on one node have to share
     struct rusage ru1;

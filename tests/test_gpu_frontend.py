@@ -73,3 +73,50 @@ def test_cli_with_fused_front_end(tmp_path, chunk):
         assert H.rel_err(got[k][None], ref[None]) < 1e-4, k
     assert "No features were judged as voiced for utterance utt2" in err
     assert "Done 3 utterances, failed for 1" in err
+
+
+@pytest.mark.parametrize("chunk", [10000, 150])   # 150: cut into chunks -> the views are expanded on the host, same floats
+def test_compressed_raw_features_are_expanded_on_the_device(tmp_path, chunk):
+    """The recipes' raw features are stored compressed (steps/make_mfcc.sh: compress=true -> Kaldi "CM" matrices, one byte per
+    element).  A table job with the fused front-end maps the archive, uploads the compressed objects as they are and expands them
+    on the GPU (cm_expand_kernel) with the host reader's float operations: the archive it writes is BYTE-IDENTICAL to the one of
+    the same job with the expansion done by the reader threads (XVEC_DEBUG=cm_on_device=0), and matches the oracle - which reads
+    the compressed archive with its own reader - at the parity tolerance."""
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    lens = [500, 120, 333, 900, 64, 401, 77, 260, 640]
+    utts = [("utt%d" % i, H.features(900 + i, T) + 1.5) for i, T in enumerate(lens)]
+    vads = [("utt%d" % i, fe.synthetic_vad(30 + i, T)) for i, T in enumerate(lens)]
+    vads[4] = ("utt4", np.zeros(64, np.float32))                          # nothing voiced -> skipped with a warning
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"), compressed="CM")
+    kio.write_ark_vectors(str(tmp_path / "vad.ark"), vads, scp_path=str(tmp_path / "vad.scp"))
+    stored = dict(kio.read_scp(str(tmp_path / "feats.scp"), "matrix"))     # what a conforming reader reconstructs
+    outs = {}
+    for tag, dbg in (("device", None), ("host", "cm_on_device=0")):
+        env = dict(os.environ, XVEC_TIMING="1")
+        if dbg:
+            env["XVEC_DEBUG"] = dbg
+        r = subprocess.run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=%d" % chunk,
+                            "--output-node=tdnn6.affine", "--cmn-window=300", "--cmn-center=true", "--batch-frames=2000",
+                            "--vad-rspecifier=scp,s,cs:%s/vad.scp" % tmp_path, str(tmp_path / "final.raw"),
+                            "scp:%s/feats.scp" % tmp_path, "ark:%s/x_%s.ark" % (tmp_path, tag)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        err = r.stderr.decode()
+        assert r.returncode == 0, err[-1500:]
+        assert "Done 8 utterances, failed for 1" in err, err[-800:]
+        outs[tag] = (open(tmp_path / ("x_%s.ark" % tag), "rb").read(), err)
+    assert outs["device"][0] == outs["host"][0]
+    if chunk == 10000:
+        assert "utterances went to the device compressed" in outs["device"][1], outs["device"][1][-1500:]
+    assert "went to the device compressed" not in outs["host"][1]
+    n2 = H.nm.Nnet3.from_bytes(net.to_bytes(True))
+    n2.apply_nnet_config(line)
+    ev = H.xo.GraphEvaluator(n2, np.float32)
+    got = dict(kio.read_ark(str(tmp_path / "x_device.ark"), "vector"))
+    for (k, _), (_, v) in zip(utts, vads):
+        x = fe.select_voiced(fe.sliding_cmn(stored[k], 300, True), v)
+        if x is None:
+            assert k not in got
+            continue
+        ref = H.xo.extract_xvector(ev, x, chunk, 25, True)
+        assert H.rel_err(got[k][None], ref[None]) < 1e-4, k

@@ -29,17 +29,26 @@ def main():
         lens = np.full(64, int(targ))
     T = float(lens.mean())
     topo = ([a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("--topology=")] or ["v2_xvector"])[0]   # helpers.TOPOLOGIES
-    extra = [a for a in sys.argv[3:] if a.startswith("--") and a != "--pipe" and not a.startswith("--topology=")]
+    extra = [a for a in sys.argv[3:] if a.startswith("--") and a not in ("--pipe", "--compressed") and not a.startswith("--topology=")]
+    compressed = "--compressed" in sys.argv[3:]   # Kaldi "CM" objects (what make_mfcc.sh stores); with --cmn-window=300 the job runs the device front-end
     pipe = "--pipe" in sys.argv[3:]   # the recipes' form: the features arrive through a pipe (extract_xvectors_new.sh:79)
     wspec = ([a for a in sys.argv[3:] if not a.startswith("--")] or [None])[0]
     d = tempfile.mkdtemp(prefix="xvcli", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     net, line = H.synth_model(topo)
     open(os.path.join(d, "final.raw"), "wb").write(net.to_bytes(True))
     pool = [H.features(1000 + i, int(lens[i])) for i in range(64)]
+    import io
+    blobs = []
+    for m in pool:
+        b = io.BytesIO()
+        if compressed:
+            kio.write_compressed_matrix(b, m, "CM")
+        else:
+            kio.write_matrix(b, m)
+        blobs.append(b.getvalue())
     with open(os.path.join(d, "feats.ark"), "wb") as f:
         for i in range(n):
-            f.write(("utt%07d " % i).encode() + b"\0B")
-            kio.write_matrix(f, pool[i % 64])
+            f.write(("utt%07d " % i).encode() + b"\0B" + blobs[i % 64])
     binp = os.path.join(ROOT, H.PKG_NAME, "bin", "nnet3-xvector-compute")
     cmd = [binp, "--use-gpu=yes", "--min-chunk-size=25", "--chunk-size=10000", "--output-node=" + line.split("input=")[1]] + extra + [
         os.path.join(d, "final.raw"), ("ark:cat %s/feats.ark |" if pipe else "ark:%s/feats.ark") % d, wspec or "ark,scp:%s/x.ark,%s/x.scp" % (d, d)]
@@ -51,7 +60,7 @@ def main():
     loop = float(m.group(1)) if m else None
     print(json.dumps({"input": "pipe" if pipe else "file", "utts": n, "frames": T, "rc": r.returncode, "wall_s": wall, "wall_utt_per_s": n / wall,
                       "loop_s": loop, "loop_utt_per_s": n / loop if loop else None,
-                      "feature_GB": n * T * 23 * 4 / 1e9, "frames_per_s": n * T / loop if loop else None, "topology": topo, "tail": [l for l in err.strip().splitlines() if "stages" in l or "calibration" in l or "Done" in l or "WaitHost" in l or "host cost" in l or "CPU seconds" in l]}))
+                      "feature_GB": n * T * 23 * 4 / 1e9, "frames_per_s": n * T / loop if loop else None, "topology": topo, "tail": [l for l in err.strip().splitlines() if "stages" in l or "calibration" in l or "Done" in l or "WaitHost" in l or "host cost" in l or "CPU seconds" in l or "front-end:" in l]}))
     for fn in os.listdir(d):
         os.remove(os.path.join(d, fn))
     os.rmdir(d)
