@@ -99,11 +99,16 @@ int CheckIndexer(const std::string& rspec, const std::string& seq_rspec, long* v
     // the VIEW of the same object in the mapped file (what the reader threads of a table job hand out): a binary float matrix
     // must be viewable and hold the same bytes (compared with memcmp: the view has the archive's alignment, not a float's)
     xv::Matrix view;
-    if (mapper.View(e, &view)) {
+    if (mapper.View(e, &view, true)) {
       ++*views;
-      if (view.rows != want.rows || view.cols != want.cols || !view.data.empty() ||
-          memcmp(view.Data(), want.data.data(), want.data.size() * sizeof(float)) != 0)
+      if (view.rows != want.rows || view.cols != want.cols || !view.data.empty()) return 1;
+      if (view.cm) {   // a compressed view: what the device front-end uploads; expanded here it is what the reader delivers
+        xv::Matrix full;
+        xv::ExpandCompressedView(view, &full);
+        if (full.rows != want.rows || full.cols != want.cols || full.data != want.data) return 1;
+      } else if (memcmp(view.Data(), want.data.data(), want.data.size() * sizeof(float)) != 0) {
         return 1;
+      }
     }
   }
 }
@@ -120,11 +125,16 @@ int TryIndexedFile(const std::string& path) {
     xv::FileMapper mapper;
     for (int n = 0; n < 100000 && idx.Next(&e); ++n) {
       xv::Matrix view;
-      if (mapper.View(e, &view) && (long)view.rows * view.cols > 0) {   // a view of a damaged file must stay inside the file
-        volatile unsigned char first = *(const unsigned char*)view.Data();
-        volatile unsigned char last = ((const unsigned char*)view.Data())[(size_t)view.rows * view.cols * 4 - 1];
-        (void)first;
-        (void)last;
+      if (mapper.View(e, &view, true) && (long)view.rows * view.cols > 0) {   // a view of a damaged file must stay inside the file
+        if (view.cm) {
+          xv::Matrix full;
+          xv::ExpandCompressedView(view, &full);   // touches every byte of the object
+        } else {
+          volatile unsigned char first = *(const unsigned char*)view.Data();
+          volatile unsigned char last = ((const unsigned char*)view.Data())[(size_t)view.rows * view.cols * 4 - 1];
+          (void)first;
+          (void)last;
+        }
       }
       xv::ReadIndexedMatrix(e, &in, &in_path, &m);
     }
@@ -210,6 +220,32 @@ int main(int argc, char** argv) {
       if (views == 0) {
         fprintf(stderr, "host_selftest: no object of the binary archive could be viewed in the mapped file\n");
         return 1;
+      }
+      // the input archive itself, when it is binary: it may hold COMPRESSED objects (the stored form of the recipes' features),
+      // whose views the device front-end uploads as they are
+      {
+        xv::MatrixTableIndexer probe(std::string("ark:") + argv[3]);
+        if (probe.usable()) {
+          long v2 = 0;
+          if (CheckIndexer(std::string("ark:") + argv[3], std::string("ark:") + argv[3], &v2) != 0) {
+            fprintf(stderr, "host_selftest: the indexed readers / views disagree with the sequential reader on the input archive\n");
+            return 1;
+          }
+          const std::string orig = Slurp(argv[3]), to = std::string(argv[3]) + ".selftest.dmg2";
+          unsigned st2 = 4242;
+          for (int i = 0; i < variants; ++i) {
+            std::string bad = orig;
+            st2 = st2 * 1664525u + 1013904223u;
+            if (i % 2) bad.resize(orig.size() * (size_t)(i + 1) / (variants + 2));
+            else bad[st2 % bad.size()] = (char)(bad[st2 % bad.size()] ^ (1u << ((st2 >> 20) & 7)));
+            {
+              std::ofstream f(to, std::ios::binary);
+              f.write(bad.data(), (std::streamsize)bad.size());
+            }
+            (void)TryIndexedFile(to);
+          }
+          remove(to.c_str());
+        }
       }
       // damaged copies of the binary archive through the index pass (truncations and bit flips, on disk: the indexer seeks)
       const std::string good = Slurp(tb), td = std::string(argv[3]) + ".selftest.dmg";

@@ -24,7 +24,7 @@ def selftest():
     return EXE
 
 
-@pytest.mark.parametrize("binary_model,ark_form", [(True, "FM"), (False, "CM2"), (True, "text")])
+@pytest.mark.parametrize("binary_model,ark_form", [(True, "FM"), (False, "CM2"), (True, "text"), (True, "CM")])
 def test_parsers_survive_damaged_input_under_asan_ubsan(selftest, tmp_path, binary_model, ark_form):
     net = H.nm.synthesize([H.tiny_config()], seed=3)
     (tmp_path / "tiny.raw").write_bytes(net.to_bytes(binary_model))
