@@ -7,6 +7,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <fstream>
 #include <sstream>
 
@@ -78,8 +79,9 @@ bool PublishCalibrationFile(const std::string& path, const SharedChoice& mine, S
   if (access(path.c_str(), F_OK) != 0) {
     char host[64] = "host";
     (void)gethostname(host, sizeof host - 1);
+    static std::atomic<unsigned> serial{0};   // (several contexts of one process may publish at once)
     std::ostringstream tmp;
-    tmp << path << ".tmp." << host << "." << (long)getpid();
+    tmp << path << ".tmp." << host << "." << (long)getpid() << "." << serial.fetch_add(1);
     {
       std::ofstream f(tmp.str(), std::ios::trunc);
       char model[32];

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <exception>
 #include <sstream>
@@ -1509,9 +1510,9 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
   {
     // fault injection for the tests of the callers' error paths (XVEC_DEBUG=calib_fail=1: the first call of the process fails,
     // 2: every call)
-    static int calls = 0;
+    static std::atomic<int> calls{0};
     const int inject = DebugKnobInt("calib_fail", 0);
-    if ((inject == 1 && calls++ == 0) || inject == 2) throw EngineError("injected failure (XVEC_DEBUG=calib_fail)");
+    if ((inject == 1 && calls.fetch_add(1) == 0) || inject == 2) throw EngineError("injected failure (XVEC_DEBUG=calib_fail)");
   }
   // Chunks each fast mode would run fast - pooled frames as FillPlan counts them.  fp16mx2 is validated on every chunk IT
   // runs (from mx2_min_pooled_ frames, where its error is largest), fp16mx on those it runs (from mx_min_pooled_).
