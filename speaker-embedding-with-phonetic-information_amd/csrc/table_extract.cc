@@ -534,6 +534,9 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
       want_calibrate = true;
     }
   }
+  if (want_calibrate && !shared)
+    log("LOG", "the arithmetic is measured for THIS job only (--calibrate without a --calibration file): jobs over other shards "
+               "of the same list measure their own samples and may choose differently");
   bool calibrated = !want_calibrate;   // nothing to choose: no batch is held back
   if (!calibrated && indexer) {
     // addressable table: the sample is spread over the whole list (SampleTable), drawn before the readers start.  An unreadable
