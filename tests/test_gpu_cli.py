@@ -126,6 +126,37 @@ def test_extract_table_through_the_c_abi(job):
             assert H.rel_err(got[k][None], ref[None]) < TOL, k
 
 
+def test_shared_calibration_through_the_c_abi(tmp_path):
+    """xv_ctx_set_calibration_file / xv_ctx_share_calibration / xv_ctx_model_fingerprint (include/xvec_hip.h): the first table job
+    of a context measures and publishes, a second context reads the file and writes the same bytes; the file names the
+    fingerprint of the packed image, and a context of another model refuses it."""
+    P = H.pkg()
+    net, line = H.synth_model("v2_xvector")
+    utts = [("utt%03d" % i, H.features(900 + i, 400 if i % 3 else 333)) for i in range(24)]
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts)
+    calib = str(tmp_path / "xvec.calib")
+    model = P.Model(raw=net.to_bytes(True), nnet_config=line)
+    a = P.Context(model)
+    assert a.fast_mode == "fp16mx2"
+    a.set_calibration_file(calib)
+    assert a.extract_table("ark:%s/feats.ark" % tmp_path, "ark:%s/a.ark" % tmp_path, 10000, 25, True) == (24, 0)
+    held = P.calibration_file_read(calib)
+    assert held["model"] == a.model_fingerprint != 0 and held["precision"] == a.fast_mode == "fp16mx"   # measured on this table
+    b = P.Context(model)
+    assert b.share_calibration(calib) == "read" and b.fast_mode == "fp16mx"
+    assert b.extract_table("ark:%s/feats.ark" % tmp_path, "ark:%s/b.ark" % tmp_path, 10000, 25, True) == (24, 0)
+    assert (tmp_path / "a.ark").read_bytes() == (tmp_path / "b.ark").read_bytes()
+    c = P.Context(model)                     # publishing into an existing file: the file's choice is adopted, not this context's
+    assert c.fast_mode == "fp16mx2" and c.share_calibration(calib) == "read" and c.fast_mode == "fp16mx"
+    fresh = str(tmp_path / "fresh.calib")
+    e = P.Context(model)
+    assert e.share_calibration(fresh, note="the packed default") == "published" and P.calibration_file_read(fresh)["precision"] == "fp16mx2"
+    other = P.Context(P.Model(raw=H.synth_model("v2_xvector", seed=124)[0].to_bytes(True), nnet_config=line))
+    with pytest.raises(P.XvError) as err:
+        other.share_calibration(calib)
+    assert "another model image" in str(err.value) and other.fast_mode == "fp16mx2"
+
+
 def test_nnet3_compute_cli_frame_level(tmp_path):
     """`nnet3-compute` drop-in (sid/nnet3_cvector/am/extract_bn.sh:68 style): bottleneck features of the AM net."""
     net = H.nm.synthesize([H.config_text("am")], seed=21, head_stddev=1.0)
