@@ -1514,6 +1514,10 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     const int inject = DebugKnobInt("calib_fail", 0);
     if ((inject == 1 && calls.fetch_add(1) == 0) || inject == 2) throw EngineError("injected failure (XVEC_DEBUG=calib_fail)");
   }
+  // (3: the first call of the process sees ONE element of its packed pass move by one ulp - what a device that does not
+  // reproduce its own bits looks like to the check below)
+  static std::atomic<int> perturb_calls{0};
+  const bool perturb = DebugKnobInt("calib_fail", 0) == 3 && perturb_calls.fetch_add(1) == 0;
   // Chunks each fast mode would run fast - pooled frames as FillPlan counts them.  fp16mx2 is validated on every chunk IT
   // runs (from mx2_min_pooled_ frames, where its error is largest), fp16mx on those it runs (from mx_min_pooled_).
   const BlobLayerInfo& pl = info_.layers[info_.pooled_layer];
@@ -1549,6 +1553,7 @@ Engine::Calibration Engine::Calibrate(const float* feats, const int32_t* row_off
     ForwardHost(f.data(), offs.data(), n, mx.data());
     SetFastMode(kPrecFp16Mx2);
     ForwardHost(f.data(), offs.data(), n, mx2.data());
+    if (perturb) mx2[0] = std::nextafterf(mx2[0], INFINITY);
     // The measurement is only worth something if the device computes the same bits twice.  The three passes above are the FIRST
     // forward passes of a job's context (fresh planes, first launches, and - run.pl JOB=1:nj - three other processes doing
     // the same on the same GPU); the reference and the packed arithmetic are run once more and compared byte for byte.  A

@@ -282,6 +282,10 @@ def test_cli_failed_measurement_is_repeated_once_and_a_second_failure_ends_the_j
         assert once.returncode == 0, err[-800:]
         assert "WARNING" in err and "calibration attempt failed (injected failure" in err and "repeated once" in err, err[-800:]
         assert (d / ("x_%s_once.ark" % form)).read_bytes() == (d / ("x_%s_good.ark" % form)).read_bytes()
+        ulp = run(form + "_ulp", ext("ulp"), "calib_fail=3")      # one element of one pass one ulp off: caught, named, repeated
+        err = ulp.stderr.decode()
+        assert ulp.returncode == 0 and "differ in 1 of them" in err and "does not reproduce its own results" in err, err[-800:]
+        assert (d / ("x_%s_ulp.ark" % form)).read_bytes() == (d / ("x_%s_good.ark" % form)).read_bytes()
         twice = run(form + "_twice", ext("twice"), "calib_fail=2")
         err = twice.stderr.decode()
         assert twice.returncode == 255 and "ERROR" in err and "injected failure" in err, (twice.returncode, err[-800:])
