@@ -321,6 +321,7 @@ const char* Usage(const std::string& prog) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  xv::InstallMappedFileFaultHandler(strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0]);
   const char* slash = strrchr(argv[0], '/');
   g_prog = slash ? slash + 1 : argv[0];
   Args a;

@@ -15,6 +15,7 @@
 #include <sys/wait.h>
 
 #include <poll.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -1018,6 +1019,30 @@ void ReadIndexedMatrix(const MatrixTableIndexer::Entry& e, Input* in, std::strin
   in->Seek(e.offset);
   const bool binary = ReadBinaryHeader(*in);
   ReadMatrix(*in, binary, m);
+}
+
+namespace {
+char g_fault_prog[64] = "xvec-hip";
+void MappedFileFault(int) {
+  // async-signal-safe: write(2) and _exit only
+  const char a[] = "ERROR (", b[] = ") an input file changed (was truncated) while it was being read through its mapping\n";
+  (void)!write(2, a, sizeof a - 1);
+  (void)!write(2, g_fault_prog, strlen(g_fault_prog));
+  (void)!write(2, b, sizeof b - 1);
+  _exit(255);
+}
+}  // namespace
+
+void InstallMappedFileFaultHandler(const char* program) {
+  if (program) {
+    strncpy(g_fault_prog, program, sizeof g_fault_prog - 1);
+    g_fault_prog[sizeof g_fault_prog - 1] = 0;
+  }
+  struct sigaction sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = MappedFileFault;
+  sigemptyset(&sa.sa_mask);
+  (void)sigaction(SIGBUS, &sa, nullptr);
 }
 
 FileMapper::Mapped FileMapper::Map(const std::string& path) {

@@ -122,6 +122,11 @@ struct Matrix {
 
 // Reads FM / DM / CM / CM2 / CM3 (binary) or " [ ... ]" (text).
 void ReadMatrix(Input& in, bool binary, Matrix* m);
+// Regular files are read through read-only mappings (Input, FileMapper).  A file that is truncated by someone else WHILE a tool
+// reads it turns a read into SIGBUS where read(2) would have returned short; the command-line tools call this once so that
+// the process then ends like every other input error - "ERROR ... changed while it was being read", exit status 255 - instead
+// of a bare signal.  (Not installed by the library itself: a host process owns its signal handlers.)
+void InstallMappedFileFaultHandler(const char* program);
 // Expands a compressed view (Matrix::cm) into floats on the host: *out owns them (the same floats ReadMatrix delivers).
 void ExpandCompressedView(const Matrix& view, Matrix* out);
 // Regular files, positioned behind the "\0B" of a binary matrix (FM / DM / CM / CM2 / CM3): reads the header only, reports the

@@ -300,6 +300,7 @@ int JobIndexFromWspecifier(const std::string& w) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  xv::InstallMappedFileFaultHandler(strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0]);
   {
     // one source, two drop-ins: invoked as `nnet3-compute` it does the frame-level job (a matrix per utterance)
     const char* base = strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0];

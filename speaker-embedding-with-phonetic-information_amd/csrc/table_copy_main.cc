@@ -14,6 +14,7 @@
 
 int main(int argc, char** argv) {
   const char* prog = strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0];
+  xv::InstallMappedFileFaultHandler(prog);
   const bool vectors = strstr(prog, "vector") != nullptr;
   try {
     std::vector<std::string> pos;

@@ -275,3 +275,31 @@ def test_mapped_files_read_like_stdio(tmp_path, form):
         assert r.returncode == 255 and b"unexpected end" in r.stderr, r.stderr.decode()[-300:]
         errs.append([k for k, _ in kio.read_ark(dst, "matrix")])
     assert errs[0] == errs[1] == [k for k, _ in utts[:-1]]
+
+
+def test_file_truncated_while_it_is_mapped_ends_like_an_input_error(tmp_path):
+    """Mapped input (round 6): a file that someone truncates while a tool reads it raises SIGBUS where read(2) would have come
+    back short.  The tools turn that into their usual ending - ERROR on stderr, exit status 255 - instead of dying of the signal.
+    (A FIFO holds the writer side of the copy so that the truncation lands while the archive is still mapped and unread.)"""
+    import signal
+    import time
+    rng = np.random.default_rng(5)
+    utts = [("u%04d" % i, rng.standard_normal((400, 23)).astype(np.float32)) for i in range(2000)]     # 74 MB: many pages unread
+    src = str(tmp_path / "big.ark")
+    kio.write_ark_matrices(src, utts)
+    fifo = str(tmp_path / "out.fifo")
+    os.mkfifo(fifo)
+    p = subprocess.Popen([os.path.join(H.ROOT, H.PKG_NAME, "bin", "copy-feats"), "ark:" + src, "ark:" + fifo], stderr=subprocess.PIPE)
+    rd = os.open(fifo, os.O_RDONLY)          # the tool can open its output now; it blocks once the FIFO's buffer is full
+    time.sleep(0.5)
+    os.truncate(src, 4096)                   # everything behind the first page is gone
+    got = 0
+    while True:                              # drain: the tool reads on, into pages that no longer exist
+        b = os.read(rd, 1 << 20)
+        if not b:
+            break
+        got += len(b)
+    os.close(rd)
+    err = p.communicate(timeout=60)[1].decode()
+    assert p.returncode == 255, (p.returncode, err[-300:])
+    assert p.returncode != -signal.SIGBUS and "ERROR" in err and ("changed" in err or "unexpected end" in err), err[-300:]
