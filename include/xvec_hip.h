@@ -242,6 +242,14 @@ xv_status xv_extract_table(xv_ctx* c, const char* feature_rspecifier, const char
  * over each whole utterance, then `select-voiced-frames` with vad[r] != 0 (vad: one float per raw row, NULL = keep
  * all).  raw: packed rows, utterance u = rows raw_off[u]..raw_off[u+1]-1; out receives the kept rows (capacity >= the
  * number of raw rows), out_off[n_utts+1] their offsets.  Host buffers, blocking. */
+/* The feature pipeline every extraction script of the reference builds - "ark:apply-cmvn-sliding --norm-vars=false
+ * --center=true --cmn-window=300 scp:feats.scp ark:- | select-voiced-frames ark:- scp,s,cs:vad.scp ark:- |"
+ * (egs/sre/v2/sid/nnet3/xvector/extract_xvectors_new.sh:79 and its siblings) - recognised as text (csrc/fuse_pipe.h): *found = 1
+ * and the inner feature table, the VAD table ("" when there is no selection stage) and the sliding-CMN parameters when the string
+ * is exactly that pipeline with options the device front-end implements; *found = 0 for anything else.  nnet3-xvector-compute
+ * uses it to run the two stages on the device instead of as two CPU tools and two pipes. */
+xv_status xv_recognize_feature_pipeline(const char* rspecifier, int32_t* found, char* feats, size_t feats_cap, char* vad, size_t vad_cap,
+                                        int32_t* cmn_window, int32_t* min_cmn_window, int32_t* center);
 xv_status xv_frontend_cmvn_select(xv_ctx* c, const float* raw, const int32_t* raw_off, int32_t n_utts, const float* vad,
                                   int32_t cmn_window, int32_t center, float* out, int32_t* out_off);
 

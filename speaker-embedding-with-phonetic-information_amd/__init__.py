@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "xv_ctx_info", "xv_forward_batch", "xv_forward_batch_device", "xv_ctx_synchronize", "xv_ctx_set_profiling",
     "xv_ctx_profile_report", "xv_extract_utterances", "xv_ctx_calibrate", "xv_ctx_set_fast_mode", "xv_ctx_fast_mode",
     "xv_calibrate_table", "xv_ctx_set_calibration", "xv_ctx_model_fingerprint", "xv_ctx_share_calibration",
-    "xv_ctx_set_calibration_file", "xv_calibration_file_read", "xv_calibration_file_publish", "xv_ctx_set_lite_layers", "xv_ctx_lite_layers",
+    "xv_ctx_set_calibration_file", "xv_calibration_file_read", "xv_calibration_file_publish", "xv_recognize_feature_pipeline", "xv_ctx_set_lite_layers", "xv_ctx_lite_layers",
     "xv_extract_table", "xv_frontend_cmvn_select", "xv_plan_chunks", "xv_ctx_create_broadcast", "xv_kernel_tdnn_gemm",
     "xv_backend_apply", "xv_segment_mean", "xv_pack_mx_residual", "xv_pack_mx_residual64", "xv_tile_mx_scales", "xv_pack_mx_weights", "xv_pack_mx_weights64",
 ]
@@ -460,6 +460,23 @@ def create_broadcast(model, devices, precision=PREC_DEFAULT):
         c.info, c.precision, c.device = mi, p.value, d.value
         out.append(c)
     return out
+
+
+def recognize_feature_pipeline(rspecifier):
+    """The reference's feature pipeline as text (xv_recognize_feature_pipeline): {"feats", "vad", "cmn_window", "min_cmn_window",
+    "center"} when the string is exactly `ark:apply-cmvn-sliding ... | select-voiced-frames ... |` with options the device
+    front-end implements, else None."""
+    L = lib()
+    L.xv_recognize_feature_pipeline.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, ctypes.c_size_t,
+                                                ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32),
+                                                ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    found, w, mw, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    fb, vb = ctypes.create_string_buffer(4096), ctypes.create_string_buffer(4096)
+    _check(L.xv_recognize_feature_pipeline(rspecifier.encode(), ctypes.byref(found), fb, 4096, vb, 4096, ctypes.byref(w), ctypes.byref(mw),
+                                           ctypes.byref(c)))
+    if not found.value:
+        return None
+    return {"feats": fb.value.decode(), "vad": vb.value.decode(), "cmn_window": w.value, "min_cmn_window": mw.value, "center": bool(c.value)}
 
 
 def calibration_file_read(path):

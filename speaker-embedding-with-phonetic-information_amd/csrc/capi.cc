@@ -13,6 +13,7 @@
 #include "extractor.h"
 #include "kernels.h"
 #include "calib_file.h"
+#include "fuse_pipe.h"
 #include "multi_gpu.h"
 #include "nnet3_raw.h"
 #include "program.h"
@@ -326,6 +327,25 @@ xv_status xv_ctx_set_calibration_file(xv_ctx* c, const char* path) {
   if (!c) return Fail(XV_ERR_ARG, "xv_ctx_set_calibration_file: null context");
   c->calibration_file = path ? path : "";
   return XV_OK;
+}
+
+xv_status xv_recognize_feature_pipeline(const char* rspecifier, int32_t* found, char* feats, size_t feats_cap, char* vad, size_t vad_cap,
+                                        int32_t* cmn_window, int32_t* min_cmn_window, int32_t* center) {
+  if (!rspecifier || !found) return Fail(XV_ERR_ARG, "xv_recognize_feature_pipeline: null argument");
+  return Guard([&] {
+    xv::FusedPipeline p;
+    *found = xv::RecognizeFeaturePipeline(rspecifier, &p) ? 1 : 0;
+    if (*found) {
+      if ((feats && p.feats_rspecifier.size() + 1 > feats_cap) || (vad && p.vad_rspecifier.size() + 1 > vad_cap))
+        return Fail(XV_ERR_ARG, "xv_recognize_feature_pipeline: output buffer too small");
+      if (feats) memcpy(feats, p.feats_rspecifier.c_str(), p.feats_rspecifier.size() + 1);
+      if (vad) memcpy(vad, p.vad_rspecifier.c_str(), p.vad_rspecifier.size() + 1);
+      if (cmn_window) *cmn_window = p.cmn_window;
+      if (min_cmn_window) *min_cmn_window = p.min_cmn_window;
+      if (center) *center = p.center ? 1 : 0;
+    }
+    return XV_OK;
+  });
 }
 
 xv_status xv_calibration_file_read(const char* path, int32_t* found, uint64_t* model, int32_t* precision, uint64_t* lite_mask) {

@@ -18,6 +18,7 @@
 //   engines_on_one_device (n, 0)      test knob: n engines on ONE device behind the several-engine table loop
 //   bn_fold (0 | 1, 0)  bn_fold_mask (bits)   the opt-in lowering of DESIGN.md section 3.5
 //   tail_over_tol (factor, 1.10)      study knob of tools/tail_error.py: the calibration's projected-tail condition
+//   fuse_pipe (0 | 1, 1)              0: the reference's feature pipeline (fuse_pipe.h) is run as commands, not on the device
 //   calib_fail (0 | 1 | 2 | 3, 0)     fault injection: the first / every Engine::Calibrate of the process throws; 3: the first one
 //                                     sees one element of a pass move by an ulp (a device that does not reproduce its bits)
 // The list is parsed on every call (callers that must not change their mind keep the answer in a static).

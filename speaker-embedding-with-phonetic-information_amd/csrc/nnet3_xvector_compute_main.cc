@@ -27,6 +27,7 @@
 #include "engine.h"
 #include "knobs.h"
 #include "extractor.h"
+#include "fuse_pipe.h"
 #include "kio.h"
 #include "nnet3_raw.h"
 #include "program.h"
@@ -108,7 +109,11 @@ const char* kUsage =
     "                                   use the whole node without a change of the script (nnet3-xvector-compute only)\n"
     "  --cmn-window=<int> --cmn-center=true|false --vad-rspecifier=<rspecifier>\n"
     "                                   run apply-cmvn-sliding (--norm-vars=false) and select-voiced-frames on the device\n"
-    "                                   in front of the network; the features rspecifier is then the raw feats.scp\n"
+    "                                   in front of the network; the features rspecifier is then the raw feats.scp.\n"
+    "                                   (A features rspecifier that IS the recipes' pipeline - 'ark:apply-cmvn-sliding\n"
+    "                                   --norm-vars=false --center=.. --cmn-window=.. <table> ark:- | select-voiced-frames ark:-\n"
+    "                                   <vad table> ark:- |', extract_xvectors_new.sh:79 - is recognised and run this way by\n"
+    "                                   itself; the log says so.  Anything else in a pipe is run as a command.)\n"
     "  --backend-mean=<vec> --backend-transform=<mat> --backend-normalize-length=true|false [--backend-scaleup=true]\n"
     "                                   apply ivector-subtract-global-mean | transform-vec | ivector-normalize-length\n"
     "                                   on the device to every embedding before it is written\n"
@@ -344,7 +349,25 @@ int main(int argc, char** argv) {
       fputs(kUsage, stderr);
       return 1;
     }
-    const std::string nnet_rx = pos[0], feat_rspec = pos[1], vec_wspec = pos[2];
+    const std::string nnet_rx = pos[0], vec_wspec = pos[2];
+    std::string feat_rspec = pos[1];
+    // The feature pipeline the reference's extraction scripts build (extract_xvectors_new.sh:79: apply-cmvn-sliding |
+    // select-voiced-frames, two CPU tools and two pipes) is recognised as text and run on the device instead (fuse_pipe.h) -
+    // unless the caller asked for a front-end of their own, or XVEC_DEBUG=fuse_pipe=0 says to run the commands.
+    int fused_min_window = 0;
+    if (!g_frame_job && opt.cmn_window == 0 && opt.vad_rspecifier.empty() && xv::DebugKnobInt("fuse_pipe", 1) != 0) {
+      xv::FusedPipeline fp;
+      if (xv::RecognizeFeaturePipeline(feat_rspec, &fp)) {
+        XLOG("feature pipeline recognised (apply-cmvn-sliding --norm-vars=false --center=" << (fp.center ? "true" : "false")
+             << " --cmn-window=" << fp.cmn_window << (fp.vad_rspecifier.empty() ? "" : " | select-voiced-frames " + fp.vad_rspecifier)
+             << "): it runs on the device, reading " << fp.feats_rspecifier << " directly (XVEC_DEBUG=fuse_pipe=0 runs the commands)");
+        feat_rspec = fp.feats_rspecifier;
+        opt.cmn_window = fp.cmn_window;
+        opt.cmn_center = fp.center;
+        opt.vad_rspecifier = fp.vad_rspecifier;
+        fused_min_window = fp.min_cmn_window;
+      }
+    }
 
     // default: the library's one policy (XV_PREC_DEFAULT, engine.cc PackModelPolicy): fp16mx2 (1.5 MFMA passes, 3-5.5e-5 from
     // the fp32 oracle on every model tried, the heavy-tailed ones included) for pooled outputs where every layer can run
@@ -505,6 +528,7 @@ int main(int argc, char** argv) {
     eo.cmn_window = opt.cmn_window;
     eo.cmn_center = opt.cmn_center;
     eo.vad_rspecifier = opt.vad_rspecifier;
+    if (fused_min_window > 0) eo.cmn_min_window = fused_min_window;
     eo.calibrate = policy_default && opt.calibrate && !g_frame_job;   // no-op unless the context can switch (fp16mx2)
     eo.calibrate_tol = opt.calibrate_tol;
     if (policy_default && !g_frame_job) {

@@ -120,3 +120,44 @@ def test_compressed_raw_features_are_expanded_on_the_device(tmp_path, chunk):
             continue
         ref = H.xo.extract_xvector(ev, x, chunk, 25, True)
         assert H.rel_err(got[k][None], ref[None]) < 1e-4, k
+
+
+def test_the_recipes_feature_pipeline_runs_on_the_device_without_a_script_change(tmp_path):
+    """extract_xvectors_new.sh:79 hands the binary `ark:apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300
+    scp:feats.scp ark:- | select-voiced-frames ark:- scp,s,cs:vad.scp ark:- |`.  nnet3-xvector-compute recognises exactly that
+    string (csrc/fuse_pipe.h) and runs both stages on the device, reading the stored (compressed) features itself: neither tool
+    exists on this box, the job succeeds, says so, and writes byte for byte what the explicit --cmn-window / --vad-rspecifier form
+    writes (which is compared with the oracle above).  A pipeline it does not implement (--norm-vars=true) is left to the shell -
+    where it fails here, for want of the tools; XVEC_DEBUG=fuse_pipe=0 does the same to the recognised one."""
+    net, line = H.synth_model("v2_xvector")
+    (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
+    (tmp_path / "extract.config").write_text(line + "\n")
+    lens = [500, 120, 333, 900, 64, 401]
+    utts = [("utt%d" % i, H.features(900 + i, T) + 1.5) for i, T in enumerate(lens)]
+    vads = [("utt%d" % i, fe.synthetic_vad(30 + i, T)) for i, T in enumerate(lens)]
+    vads[4] = ("utt4", np.zeros(64, np.float32))
+    kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"), compressed="CM")
+    kio.write_ark_vectors(str(tmp_path / "vad.ark"), vads, scp_path=str(tmp_path / "vad.scp"))
+    model = "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), tmp_path, tmp_path)
+    pipe = ("ark:apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300 scp:%s/feats.scp ark:- | "
+            "select-voiced-frames ark:- scp,s,cs:%s/vad.scp ark:- |" % (tmp_path, tmp_path))
+
+    def run(tag, feat, extra=(), env=None):
+        # the script's own argv (extract_xvectors_new.sh:92-93), --use-gpu=no included
+        return subprocess.run([os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=10000"] +
+                              list(extra) + [model, feat, "ark,scp:%s/x_%s.ark,%s/x_%s.scp" % (tmp_path, tag, tmp_path, tag)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, XVEC_TIMING="1", **(env or {})))
+    a = run("pipe", pipe)
+    err = a.stderr.decode()
+    assert a.returncode == 0, err[-1500:]
+    assert "feature pipeline recognised" in err and "runs on the device" in err, err[-1500:]
+    assert "Done 5 utterances, failed for 1" in err and "No features were judged as voiced for utterance utt4" in err, err[-1500:]
+    assert "utterances went to the device compressed" in err            # the stored bytes go up as they are
+    b = run("flags", "scp:%s/feats.scp" % tmp_path, ["--cmn-window=300", "--cmn-center=true", "--vad-rspecifier=scp,s,cs:%s/vad.scp" % tmp_path])
+    assert b.returncode == 0, b.stderr.decode()[-1500:]
+    assert (tmp_path / "x_pipe.ark").read_bytes() == (tmp_path / "x_flags.ark").read_bytes()
+    # not this pipeline: the shell gets it (and has no such tools here)
+    c = run("other", pipe.replace("--norm-vars=false", "--norm-vars=true"))
+    assert c.returncode != 0 and "feature pipeline recognised" not in c.stderr.decode()
+    d = run("off", pipe, env={"XVEC_DEBUG": "fuse_pipe=0"})
+    assert d.returncode != 0 and "feature pipeline recognised" not in d.stderr.decode()

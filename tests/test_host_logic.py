@@ -491,3 +491,52 @@ def test_packed_image_carries_its_fingerprint():
               P.Model(raw=H.synth_model("v2_xvector", seed=124)[0].to_bytes(True), nnet_config=line).pack(),
               P.Model(raw=net.to_bytes(True), nnet_config="output-node name=output input=tdnn7.affine").pack()]
     assert len({fp(a)} | {fp(o) for o in others}) == 4
+
+
+def test_the_reference_feature_pipeline_is_recognised_as_text_and_nothing_else_is():
+    """csrc/fuse_pipe.h: the one rspecifier string every extraction script of the reference builds
+    (extract_xvectors_new.sh:79, extract_xvectors.sh:73, extract_output_new.sh:75, extract_cvectors_with_am.sh:92,
+    extract_cvectors_with_embedding.sh:81, extract_log_post.sh:68-70) is recognised - so that nnet3-xvector-compute can run its
+    two stages on the device - and anything that is not EXACTLY that pipeline is left to the shell."""
+    R = P.recognize_feature_pipeline
+    ref = ("ark:apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300 scp:data/sre10/split8/3/feats.scp ark:- | "
+           "select-voiced-frames ark:- scp,s,cs:data/sre10/split8/3/vad.scp ark:- |")
+    assert R(ref) == {"feats": "scp:data/sre10/split8/3/feats.scp", "vad": "scp,s,cs:data/sre10/split8/3/vad.scp", "cmn_window": 300,
+                      "min_cmn_window": 100, "center": True}
+    # the text the scripts of the reference hold, with their shell variables filled in: every one of them is recognised
+    import glob
+    import re
+    root = "/root/reference/egs/sre/v2/sid"
+    if os.path.isdir(root):
+        seen = 0
+        for f in glob.glob(root + "/nnet3*/**/*.sh", recursive=True):
+            for m in re.finditer(r'feats?="(ark:apply-cmvn-sliding[^"]*)"', open(f).read()):
+                s = m.group(1)
+                for var, val in (("${sdata}", "data/x/split4/1"), ("$sdata", "data/x/split4/1"), ("$norm_vars", "false"),
+                                 ("$center", "true"), ("$cmn_window", "300")):
+                    s = s.replace(var, val)
+                got = R(s)
+                assert got and got["feats"] == "scp:data/x/split4/1/feats.scp" and got["cmn_window"] == 300 and got["center"], (f, s, got)
+                assert got["vad"] in ("", "scp,s,cs:data/x/split4/1/vad.scp"), (f, got)
+                seen += 1
+        assert seen >= 10, seen
+    # variations the device front-end implements
+    assert R("ark:apply-cmvn-sliding --norm-vars=false --center=false --cmn-window=200 --min-cmn-window=50 ark:/x/raw.ark ark:- |") == \
+        {"feats": "ark:/x/raw.ark", "vad": "", "cmn_window": 200, "min_cmn_window": 50, "center": False}
+    assert R("ark:/opt/kaldi/src/featbin/apply-cmvn-sliding --cmn_window=300 --norm_vars=false scp:f.scp ark:- | "
+             "/opt/kaldi/src/ivectorbin/select-voiced-frames ark:- ark:vad.ark ark:- |")["vad"] == "ark:vad.ark"
+    assert R("ark:apply-cmvn-sliding scp:f.scp ark:- |")["cmn_window"] == 600      # the tool's own defaults
+    # ... and everything else is a command line
+    for other in ("scp:feats.scp", "ark:feats.ark", "ark:cat feats.ark |",
+                  ref.replace("--norm-vars=false", "--norm-vars=true"),               # variance normalisation: not implemented
+                  ref.replace("--cmn-window=300", "--cmn-window=300 --max-warnings=5"),   # an option that is not understood
+                  ref.replace("--center=true", "--center=maybe"),
+                  ref.replace("scp:data/sre10/split8/3/feats.scp", "scp:-"),           # reads another stream
+                  ref.replace("scp:data/sre10/split8/3/feats.scp", "scp:filter.pl a b |"),
+                  ref.replace("select-voiced-frames", "select-voiced-frames --verbose=2"),
+                  ref.replace("select-voiced-frames", "some-other-tool"),
+                  ref[:-1] + "| copy-feats ark:- ark:- |",                             # a third stage
+                  ref.replace("ark:- |", "ark:- 2>/dev/null |"),                       # a redirection
+                  ref.replace("scp:data", "scp:$sdata"), ref.replace("apply-cmvn-sliding", "'apply-cmvn-sliding'"),
+                  ref.replace("ark:apply", "ark,s,cs:apply"), ref[:-1], "ark:apply-cmvn-sliding --norm-vars=false ark:- |"):
+        assert R(other) is None, other
