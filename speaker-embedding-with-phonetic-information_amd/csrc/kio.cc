@@ -1248,10 +1248,25 @@ const std::vector<float>& RandomAccessVectorReader::Value(const std::string& key
   if (i < 0) throw KioError("key not found in table: " + key);
   Entry& e = entries_[i];
   if (!e.loaded) {
-    Input in;
-    in.Open(e.rx);
-    bool binary = ReadBinaryHeader(in);
-    ReadVector(in, binary, &e.v);
+    // "file:offset" entries (what copy-vector / compute-vad-decision write): the archive is opened - mapped - once and every
+    // lookup is a seek.  Opening it per key was 8 us per utterance in the consumer thread of a table job with a VAD table, the
+    // wall of the recipes' own pipeline once it ran on the device (100 k utt/s; profiles/r06_host_cost.md).
+    std::string path;
+    const long off = SplitOffset(e.rx, &path);
+    if (off >= 0) {
+      if (!(data_in_.IsOpen() && data_path_ == path)) {
+        data_in_.Open(path);
+        data_path_ = path;
+      }
+      data_in_.Seek(off);
+      const bool binary = ReadBinaryHeader(data_in_);
+      ReadVector(data_in_, binary, &e.v);
+    } else {
+      Input in;
+      in.Open(e.rx);
+      const bool binary = ReadBinaryHeader(in);
+      ReadVector(in, binary, &e.v);
+    }
     e.loaded = true;
   }
   return e.v;

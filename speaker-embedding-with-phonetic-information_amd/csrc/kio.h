@@ -255,6 +255,9 @@ class RandomAccessVectorReader {
   std::vector<Entry> entries_;
   std::unordered_map<std::string, int> index_;
   int Find(const std::string& key);
+  // scp tables: the data file of the previous lookup stays open (mapped); consecutive keys of a job point into the same archive
+  Input data_in_;
+  std::string data_path_;
 };
 
 // A text table of token lists, "key tok1 tok2 ...\n" per entry (spk2utt, "ark:$data/spk2utt").
