@@ -3957,18 +3957,37 @@ hipError_t launch_prep_input(const PrepArgs& a, int precision, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Front-end.  cmn_prefix: one workgroup per utterance, thread d keeps a double running sum of column d (the tool
-// this replaces also accumulates in double).  cmn_select: one thread per (kept frame, column): window bounds as in
+// Front-end.  cmn_prefix: one workgroup per utterance, per-column prefix sums in double (the tool this replaces also
+// accumulates in double).  cmn_select: one thread per (kept frame, column): window bounds as in
 // Kaldi's SlidingWindowCmn, mean from two prefix rows, out = (float)(x - mean).
-__global__ __launch_bounds__(64) void cmn_prefix_kernel(const FrontEndArgs a) {
-  const int u = blockIdx.x, d = threadIdx.x;
-  if (d >= a.dim) return;
+// Round 6: the time axis is cut into S = 1024 / dp segments (dp = 32 or 64 >= dim); thread (s, d) sums its segment, the segment
+// totals are combined in a fixed order (an exclusive sum over at most 32 of them), and a second pass writes the prefix rows.  One
+// thread per column running down the WHOLE utterance (rounds 2-5) was 9000 dependent iterations for a 90-second recording - with
+// the recipes' own pipeline on the device (fuse_pipe.h) that loop, not the network, was what a batch of long utterances waited
+// for (54 M raw frames/s against 98 M without the front-end).  Every prefix value is a sum in one fixed order that depends on
+// the utterance's length only: deterministic, and the same in whatever batch the utterance lands.
+__global__ __launch_bounds__(1024) void cmn_prefix_kernel(const FrontEndArgs a) {
+  const int u = blockIdx.x;
+  const int dp = a.dim <= 32 ? 32 : 64, S = 1024 / dp;
+  const int d = threadIdx.x % dp, sgm = threadIdx.x / dp;
   const int r0 = a.raw_off[u], len = a.raw_off[u + 1] - r0;
-  double* p = a.prefix + ((long)r0 + u) * a.dim + d;
+  const int L = (len + S - 1) / S;
+  const int t0 = min(sgm * L, len), t1 = min(t0 + L, len);
+  __shared__ double tot[32][64];
+  const bool live = d < a.dim;
   const float* x = a.raw + (long)r0 * a.dim + d;
   double acc = 0.0;
-  p[0] = 0.0;
-  for (int t = 0; t < len; ++t) {
+  if (live)
+    for (int t = t0; t < t1; ++t) acc += (double)x[(long)t * a.dim];
+  tot[sgm][d] = acc;
+  __syncthreads();
+  if (!live) return;
+  double base = 0.0;
+  for (int k = 0; k < sgm; ++k) base += tot[k][d];
+  double* p = a.prefix + ((long)r0 + u) * a.dim + d;
+  if (sgm == 0) p[0] = 0.0;
+  acc = base;
+  for (int t = t0; t < t1; ++t) {
     acc += (double)x[(long)t * a.dim];
     p[(long)(t + 1) * a.dim] = acc;
   }
@@ -4074,7 +4093,7 @@ hipError_t launch_cm_expand(const CmExpandArgs& a, hipStream_t s) {
 
 hipError_t launch_frontend(const FrontEndArgs& a, hipStream_t s) {
   if (a.dim > 64) return hipErrorInvalidValue;
-  if (a.cmn_window > 0 && a.n_utts > 0) XV_LAUNCH(cmn_prefix_kernel, dim3(a.n_utts), dim3(64), 0, s, a);
+  if (a.cmn_window > 0 && a.n_utts > 0) XV_LAUNCH(cmn_prefix_kernel, dim3(a.n_utts), dim3(1024), 0, s, a);
   if (a.n_out > 0) {
     const long total = (long)a.n_out * a.dim;
     XV_LAUNCH(cmn_select_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
