@@ -291,16 +291,15 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
                                const size_t* cm_bytes) {
   const int D = eng->info().input_dim;
   std::vector<Chunk> chunks;
-  std::vector<int32_t> ok(n_utts, 0), kept(n_utts, 0);
+  std::vector<int32_t> ok(n_utts, 0), first_chunk(n_utts, 0), n_chunk(n_utts, 0);
   std::vector<std::string> why(n_utts);
-  long total_raw = 0, total_kept = 0;
+  long total_raw = 0, total_kept = 0;   // total_kept: rows of all chunks, replicated edge rows of padded chunks included
   for (int u = 0; u < n_utts; ++u) {
     int k = raw_rows[u];
     if (vad[u]) {
       k = 0;
       for (int t = 0; t < raw_rows[u]; ++t) k += vad[u][t] != 0.f;
     }
-    kept[u] = k;
     const size_t before = chunks.size();
     std::string reason;
     ok[u] = PlanChunks(u, k, opt.chunk_size, opt.min_chunk_size, opt.pad_input, eng->info().min_frames, &chunks, &reason) ? 1 : 0;
@@ -308,11 +307,14 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
       why[u] = reason;
       continue;
     }
-    if (chunks.size() != before + 1) return false;   // cut into several chunks: host path
-    const Chunk& c = chunks.back();
-    if (c.start != 0 || c.len != k || c.left_pad != 0 || c.right_pad != 0) return false;
+    // An utterance may be cut into several chunks (a five-minute recording at --chunk-size=10000: the recipes' own setting and
+    // the recipes' own data) and a short chunk may be padded by edge replication: both are SELECTIONS of the utterance's kept
+    // rows - consecutive ranges, an edge row listed several times - so the device front-end takes them as they are.  (Rounds
+    // 2-5 sent such batches back through the host: 25 M raw frames/s where single-chunk utterances ran at 100 M.)
+    first_chunk[u] = (int32_t)before;
+    n_chunk[u] = (int32_t)(chunks.size() - before);
+    for (size_t c = before; c < chunks.size(); ++c) total_kept += chunks[c].left_pad + chunks[c].len + chunks[c].right_pad;
     total_raw += raw_rows[u];
-    total_kept += k;
   }
   if (chunks.empty() || total_kept > opt.max_batch_rows || (int)chunks.size() > opt.max_batch_chunks) return false;
   // compressed input: all or nothing (a mixed batch goes the host way - decided before this job takes any state)
@@ -339,6 +341,7 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
   float* buf = eng->HostFeats(slot, all_cm ? (cm_total + (size_t)D * 4 - 1) / ((size_t)D * 4) : (size_t)total_raw);
   std::vector<int32_t> raw_off(1, 0), sel_row, sel_utt, offs(1, 0);
   std::vector<int64_t> cm_off;
+  std::vector<int32_t> kidx;
   sel_row.reserve(total_kept);
   sel_utt.reserve(total_kept);
   int j = 0;   // index among the utterances that enter the device batch
@@ -353,13 +356,21 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
     } else {
       memcpy(buf + (size_t)base * D, raw[u], (size_t)raw_rows[u] * D * 4);
     }
-    for (int t = 0; t < raw_rows[u]; ++t)
-      if (!vad[u] || vad[u][t] != 0.f) {
-        sel_row.push_back(base + t);
-        sel_utt.push_back(j);
-      }
+    // kept rows of the utterance in order (identity without a VAD table), then chunk by chunk
+    kidx.clear();
+    if (vad[u])
+      for (int t = 0; t < raw_rows[u]; ++t)
+        if (vad[u][t] != 0.f) kidx.push_back(t);
+    auto row_of = [&](int i) { return base + (vad[u] ? kidx[i] : i); };
+    for (int c = first_chunk[u]; c < first_chunk[u] + n_chunk[u]; ++c) {
+      const Chunk& ch = chunks[c];
+      for (int p = 0; p < ch.left_pad; ++p) sel_row.push_back(row_of(ch.start));
+      for (int i = ch.start; i < ch.start + ch.len; ++i) sel_row.push_back(row_of(i));
+      for (int p = 0; p < ch.right_pad; ++p) sel_row.push_back(row_of(ch.start + ch.len - 1));
+      sel_utt.resize(sel_row.size(), j);
+      offs.push_back((int32_t)sel_row.size());
+    }
     raw_off.push_back(base + raw_rows[u]);
-    offs.push_back((int32_t)sel_row.size());
     ++j;
   }
   Engine::FrontEndJob fe;
@@ -376,7 +387,7 @@ bool ExtractJob::StartFrontEnd(Engine* eng, const ExtractOptions& opt, int slot,
     fe.cm_bytes = cm_total;
     fe.max_rows = max_rows;
   }
-  eng->SubmitHost(slot, seq, offs.data(), j, &fe);
+  eng->SubmitHost(slot, seq, offs.data(), (int)chunks_.size(), &fe);
   async_ = true;
   return true;
 }

@@ -75,9 +75,10 @@ class ExtractJob {
   void StartPtrs(Engine* eng, const ExtractOptions& opt, int slot, long seq, const float* const* utt, const int32_t* rows,
                  int n_utts);
   // Table jobs with the device front-end: raw[u] = the utterance's raw rows (raw_rows[u] of them), vad[u] = its VAD
-  // decisions (or null: keep every row; every utterance keeps at least one).  When every utterance maps to exactly one
-  // unpadded chunk (the normal case) the raw rows are staged, CMN + selection + network run on the device without a
-  // host round trip, and true is returned; otherwise nothing is submitted and the caller uses FrontEndHost + Start.
+  // decisions (or null: keep every row; every utterance keeps at least one).  The raw rows are staged, CMN + selection + network
+  // run on the device without a host round trip, and true is returned - for single-chunk utterances, for utterances cut into
+  // several chunks and for short chunks padded by edge replication alike (all of them selections of the kept rows); false
+  // (nothing submitted, the caller uses FrontEndHost + Start) only when the batch does not fit one forward batch.
   // cm / cm_bytes (optional): utterances that arrive as COMPRESSED views of a mapped archive (kio.h Matrix::cm) - when every
   // utterance of the batch has one, the objects are staged as they are (one byte per element) and expanded on the device;
   // raw[u] may then be null.  A batch in which only some utterances are compressed returns false like any other batch the

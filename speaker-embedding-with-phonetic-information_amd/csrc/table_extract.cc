@@ -632,6 +632,7 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     std::vector<std::string> why;
     long num_fail = 0;   // utterances rejected before they reached the device
     long num_cm_device = 0;   // utterances that went up compressed and were expanded on the device
+    long num_fe_host = 0;     // batches of a front-end job that had to take the host round trip
     double t_pack = 0, t_start = 0, t_fin = 0;
   };
   std::vector<Consumer> cons(NE);
@@ -828,7 +829,8 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
             if (submitted) ++C.seq;
           }
           if (n && !submitted) {
-            // utterances that are cut into several chunks or padded: front-end result back to the host, then Start()
+            ++C.num_fe_host;
+            // a batch that does not fit one forward batch: front-end result back to the host, then Start()
             sel_row.clear();
             sel_utt.clear();
             poffs.assign(1, 0);
@@ -1052,6 +1054,9 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
     long n_cm = 0;
     for (const Consumer& C : cons) n_cm += C.num_cm_device;
     if (n_cm) log("LOG", "front-end: " + std::to_string(n_cm) + " utterances went to the device compressed (one byte per element) and were expanded there");
+    long n_feh = 0;
+    for (const Consumer& C : cons) n_feh += C.num_fe_host;
+    if (n_feh) log("LOG", "front-end: " + std::to_string(n_feh) + " batches did not fit one forward batch and took the host round trip");
     // host budget of the table loop: CPU seconds of ALL threads of the process (readers, copy threads, consumers, writer, the
     // runtime's own) between the first batch and the last write - what eight ranks on one node have to share
     struct rusage ru1;
