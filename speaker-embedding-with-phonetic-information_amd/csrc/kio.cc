@@ -1272,6 +1272,15 @@ const std::vector<float>& RandomAccessVectorReader::Value(const std::string& key
   return e.v;
 }
 
+void RandomAccessVectorReader::Forget(const std::string& key) {
+  const int i = Find(key);
+  if (i < 0) return;
+  Entry& e = entries_[i];
+  if (e.rx.empty() || !e.loaded) return;   // an archive loaded as a whole has no way to read the value again
+  std::vector<float>().swap(e.v);
+  e.loaded = false;
+}
+
 // ------------------------------------------------------------------------------------- writer
 TableWriter::TableWriter(const std::string& wspecifier) {
   opts_ = ParseWspecifier(wspecifier);

@@ -249,6 +249,10 @@ class RandomAccessVectorReader {
   explicit RandomAccessVectorReader(const std::string& rspecifier);
   bool HasKey(const std::string& key);
   const std::vector<float>& Value(const std::string& key);
+  // scp tables: gives the memory of a loaded value back (it is read again if the key is asked for once more).  A table job
+  // forgets the VAD decisions of a batch once the batch is on the device: kept, a hundred thousand four-minute recordings are
+  // 10 GB of them by the end of the job.  (What Kaldi's "scp,s,cs:" options promise its reader it may do.)
+  void Forget(const std::string& key);
 
  private:
   struct Entry { std::string key, rx; std::vector<float> v; bool loaded = false; };

@@ -855,6 +855,11 @@ TableExtractResult RunTableExtraction(const std::vector<Engine*>& engines, const
             offs = poffs;
           }
         }
+        if (vad && use_frontend) {
+          // the VAD decisions of this batch have done their work (the selection tables are built, or the host path has run)
+          std::unique_lock<std::mutex> vlk(vad_mu);
+          for (const Utt& u : w.b.utts) vad->Forget(u.key);
+        }
         const auto tp1 = now();
         C.t_pack += secs(tp0, tp1);
         if (n) {
