@@ -84,10 +84,13 @@ def test_compressed_raw_features_are_expanded_on_the_device(tmp_path, chunk):
     the compressed archive with its own reader - at the parity tolerance."""
     net, line = H.synth_model("v2_xvector")
     (tmp_path / "final.raw").write_bytes(net.to_bytes(True))
-    lens = [500, 120, 333, 900, 64, 401, 77, 260, 640]
+    lens = [500, 120, 333, 900, 64, 401, 77, 260, 640, 40]
     utts = [("utt%d" % i, H.features(900 + i, T) + 1.5) for i, T in enumerate(lens)]
     vads = [("utt%d" % i, fe.synthetic_vad(30 + i, T)) for i, T in enumerate(lens)]
     vads[4] = ("utt4", np.zeros(64, np.float32))                          # nothing voiced -> skipped with a warning
+    few = np.zeros(40, np.float32)
+    few[[3, 4, 5, 9, 17, 18, 19, 20, 30, 31, 33, 39]] = 1.0               # 12 voiced frames < --min-chunk-size: ONE chunk, padded by
+    vads[9] = ("utt9", few)                                               # edge replication to 25 (--pad-input) - on the device too
     kio.write_ark_matrices(str(tmp_path / "feats.ark"), utts, scp_path=str(tmp_path / "feats.scp"), compressed="CM")
     kio.write_ark_vectors(str(tmp_path / "vad.ark"), vads, scp_path=str(tmp_path / "vad.scp"))
     stored = dict(kio.read_scp(str(tmp_path / "feats.scp"), "matrix"))     # what a conforming reader reconstructs
@@ -103,7 +106,7 @@ def test_compressed_raw_features_are_expanded_on_the_device(tmp_path, chunk):
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         err = r.stderr.decode()
         assert r.returncode == 0, err[-1500:]
-        assert "Done 8 utterances, failed for 1" in err, err[-800:]
+        assert "Done 9 utterances, failed for 1" in err, err[-800:]
         outs[tag] = (open(tmp_path / ("x_%s.ark" % tag), "rb").read(), err)
     assert outs["device"][0] == outs["host"][0]
     # chunk = 150 cuts every utterance into several chunks and pads the short last ones: still selections of the kept rows, still
