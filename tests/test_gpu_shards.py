@@ -3,7 +3,9 @@ speaker-sorted list per speaker (:72, utils/data/split_data.sh -> utils/split_sc
 nnet3-xvector-compute per split on a feature PIPE (:79, :91-93) and concatenates the outputs (:99).  Kaldi's fp32 gives an
 utterance the same vector whatever shard it lands in; here that has to hold for every arithmetic the command line can end up in:
   * the default (plain fp16mx2: a function of the model, nothing is measured);
-  * a measured choice shared through --calibration / $XVEC_CALIBRATION - created by whichever job comes first, adopted by all.
+  * a measured choice shared through --calibration / $XVEC_CALIBRATION - created by whichever job comes first, adopted by all;
+  * the script's OWN feature string (apply-cmvn-sliding | select-voiced-frames over the stored, compressed features and the VAD
+    table), recognised and run on the device - the reference's launch mode to the letter.
 Four separate processes, started together, on the four per-speaker splits, each through `ark:copy-feats scp:... ark:- |`; their
 archives concatenated in job order must be byte-identical to the 1-way job's archive - on the v2 x-vector and the v5 c-vector."""
 import importlib
@@ -34,12 +36,15 @@ def _speaker_sorted_table(d, n_spk=23, seed=5):
             key = "spk%02d-utt%02d" % (s, u)
             utts.append((key, (H.features(1000 * s + u, T) * gain).astype(np.float32)))
             utt2spk[key] = "spk%02d" % s
-    kio.write_ark_matrices(os.path.join(d, "feats.ark"), utts, scp_path=os.path.join(d, "feats.scp"))
+    kio.write_ark_matrices(os.path.join(d, "feats.ark"), utts, scp_path=os.path.join(d, "feats.scp"), compressed="CM")
+    from oracle import frontend as fe
+    kio.write_ark_vectors(os.path.join(d, "vad.ark"), [(k, fe.synthetic_vad(7 + i, m.shape[0])) for i, (k, m) in enumerate(utts)],
+                          scp_path=os.path.join(d, "vad.scp"))
     return utts, utt2spk
 
 
 @pytest.mark.parametrize("topology", ["v2_xvector", "v5_cvector"])
-@pytest.mark.parametrize("mode", ["default", "shared-calibration"])
+@pytest.mark.parametrize("mode", ["default", "shared-calibration", "recipe-pipeline"])
 def test_four_way_split_through_pipes_is_byte_identical_to_the_one_way_job(tmp_path, topology, mode):
     d = str(tmp_path)
     net, line = H.synth_model(topology)
@@ -58,10 +63,14 @@ def test_four_way_split_through_pipes_is_byte_identical_to_the_one_way_job(tmp_p
 
     def cmd(scp, out):
         # extract_xvectors_new.sh:59,79,92-93 with the recipe's options (run_xvector_new.sh:83,88)
+        feats = "ark:%s scp:%s ark:- |" % (os.path.join(BIN, "copy-feats"), scp)
+        if mode == "recipe-pipeline":
+            # the script's OWN feature string (:79), neither Kaldi tool installed: recognised and run on the device (csrc/fuse_pipe.h)
+            feats = ("ark:apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300 scp:%s ark:- | "
+                     "select-voiced-frames ark:- scp,s,cs:%s/vad.scp ark:- |" % (scp, d))
         return [os.path.join(BIN, "nnet3-xvector-compute"), "--use-gpu=no", "--min-chunk-size=25", "--chunk-size=10000",
                 "%s --nnet-config=%s/extract.config %s/final.raw - |" % (os.path.join(BIN, "nnet3-copy"), d, d),
-                "ark:%s scp:%s ark:- |" % (os.path.join(BIN, "copy-feats"), scp),
-                "ark,scp:%s.ark,%s.scp" % (out, out)]
+                feats, "ark,scp:%s.ark,%s.scp" % (out, out)]
 
     procs = [subprocess.Popen(cmd(os.path.join(d, "split4", str(j), "feats.scp"), os.path.join(d, "xvector.%d" % j)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for j in (1, 2, 3, 4)]
@@ -78,7 +87,9 @@ def test_four_way_split_through_pipes_is_byte_identical_to_the_one_way_job(tmp_p
             if "calibration attempt failed" in ln:
                 import warnings
                 warnings.warn("job %s of %s/%s: %s" % (tag, topology, mode, ln[-600:]))
-    if mode == "default":
+    if mode == "recipe-pipeline":
+        assert all("feature pipeline recognised" in e for e in errs + [one_err])
+    if mode in ("default", "recipe-pipeline"):
         assert not any(arith(e) for e in errs + [one_err]), [arith(e) for e in errs + [one_err]]     # nothing measured, nothing chosen
     else:
         # the heads of the four shards are different speakers: whoever published, all five jobs name the same choice
